@@ -1,0 +1,94 @@
+/* TEST INFRASTRUCTURE - not part of the product.
+
+   Raw-score harness around the *compiled reference*: links the reference's own object
+   files (built from /root/reference by oracle/Makefile into oracle/_ref/) and calls its
+   DP kernels directly, printing what each lane width returns for EVERY database
+   sequence -- including the saturated values the CLI never shows.  Used to pin the C
+   restatement in sw_oracle.c and to generate tests/golden/*.raw.tsv.
+
+   It re-creates only the argument plumbing of the reference's search_init
+   (swipe.cc:1183-1251: dprofile, hearray, qtable[i] = dprofile + 64*qsym) and calls
+   search7 / search7_ssse3 / search16 / fullsw exactly as search_chunk does
+   (swipe.cc:1432-1585).  Nothing here is shipped or timed.
+
+   usage: ref_harness <db> <query.fasta> <symtype 0|1> <matrix|-> <gapopen> <gapextend>
+                      [match mismatch]
+   output (one line per db sequence and query strand):
+     seqno strand len s7_ssse3 s7_sse2 s16 bestpos16 s63
+*/
+#include "swipe.h"   /* found via -I/root/reference */
+
+int main(int argc, char** argv)
+{
+  if (argc < 7) {
+    fprintf(stderr, "usage: %s db query symtype matrix gapopen gapextend [match mismatch]\n", argv[0]);
+    return 2;
+  }
+  databasename = argv[1];
+  queryname = argv[2];
+  symtype = atol(argv[3]);
+  matrixname = (argv[4][0] == '-' && !argv[4][1]) ? "BLOSUM62" : argv[4];
+  gapopen = atol(argv[5]);
+  gapextend = atol(argv[6]);
+  matchscore = argc > 7 ? atol(argv[7]) : 1;
+  mismatchscore = argc > 8 ? atol(argv[8]) : -3;
+  gapopenextend = gapopen + gapextend;
+  querystrands = 3;
+  cpu_feature_ssse3 = 1;
+
+  db_open(symtype, databasename, 0);
+  score_matrix_init();
+  query_init(queryname, symtype, querystrands);
+  if (!query_read()) { fprintf(stderr, "no query\n"); return 1; }
+
+  struct db_thread_s* dbt = db_thread_create();
+  BYTE* dprofile = (BYTE*) xmalloc(4 * 16 * 32);
+
+  int nstrands = symtype == 0 ? 2 : 1;
+  printf("# SCORELIMIT_7=%ld SCORELIMIT_16=%ld gapopenextend=%ld gapextend=%ld\n",
+         SCORELIMIT_7, SCORELIMIT_16, gapopenextend, gapextend);
+
+  long seqbase = 0;
+  for (long vol = 0; vol < db_getvolumecount(); vol++) {
+    long n = db_getseqcount_volume(vol);
+    if (n == 0) continue;
+    db_mapsequences(dbt, seqbase, seqbase + n - 1);
+    long* seqnos = (long*) xmalloc(n * sizeof(long));
+    long* s7a = (long*) xmalloc(n * sizeof(long));
+    long* s7b = (long*) xmalloc(n * sizeof(long));
+    long* s16 = (long*) xmalloc(n * sizeof(long));
+    long* bp16 = (long*) xmalloc(n * sizeof(long));
+    for (long i = 0; i < n; i++) seqnos[i] = (seqbase + i) << 3;
+
+    for (int s = 0; s < nstrands; s++) {
+      char* q = symtype == 0 ? query.nt[s].seq : query.aa[0].seq;
+      long qlen = symtype == 0 ? query.nt[s].len : query.aa[0].len;
+      BYTE** qtable = (BYTE**) xmalloc((qlen > 0 ? qlen : 1) * sizeof(BYTE*));
+      for (long i = 0; i < qlen; i++) qtable[i] = dprofile + 64 * q[i];
+      BYTE* hearray = (BYTE*) xmalloc((qlen > 0 ? qlen : 1) * 32);
+
+      search7_ssse3(qtable, gapopenextend, gapextend, (BYTE*) score_matrix_7t, dprofile, hearray,
+                    dbt, n, seqnos, s7a, qlen);
+      search7(qtable, gapopenextend, gapextend, (BYTE*) score_matrix_7, dprofile, hearray,
+              dbt, n, seqnos, s7b, qlen);
+      search16((WORD**) qtable, gapopenextend, gapextend, (WORD*) score_matrix_16, (WORD*) dprofile,
+               (WORD*) hearray, dbt, n, seqnos, s16, bp16, qlen);
+
+      for (long i = 0; i < n; i++) {
+        char* address; long length, ntlen;
+        db_getsequence(dbt, seqbase + i, 0, 0, &address, &length, &ntlen, 0);
+        long* he63 = (long*) xmalloc((qlen > 0 ? qlen : 1) * 2 * sizeof(long));
+        long s63 = fullsw(address, address + length - 1, q, q + qlen, he63, score_matrix_63,
+                          gapopenextend, gapextend);
+        free(he63);
+        printf("%ld\t%d\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\n", seqbase + i, s, length - 1,
+               s7a[i], s7b[i], s16[i], bp16[i], s63);
+      }
+      free(qtable);
+      free(hearray);
+    }
+    free(seqnos); free(s7a); free(s7b); free(s16); free(bp16);
+    seqbase += n;
+  }
+  return 0;
+}

@@ -1,0 +1,501 @@
+/* TEST INFRASTRUCTURE - see sw_oracle.h.  Plain C11 restatement of the reference hot path;
+   every function cites the reference lines (file:line into /root/reference) it follows. */
+#define _GNU_SOURCE
+#include "sw_oracle.h"
+#include "refdata.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+/* NCBIstdaa letter -> code, reference query.cc:51-69 (map_ncbi_aa); -1 for anything else */
+static int aa_code(int c)
+{
+  static const char order[] = "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ";
+  if (c == 0) return -1;
+  const char* p = strchr(order, toupper(c));
+  return p ? (int)(p - order) : -1;
+}
+
+/* ------------------------------------------------------------------ matrices ---------- */
+
+void swo_matrix_clear(long* M)
+{
+  for (int i = 0; i < 1024; i++) M[i] = -1;          /* memset(..., -1, ...) matrices.cc:531 */
+}
+
+int swo_matrix_builtin(const char* name, long* M)
+{
+  swo_matrix_clear(M);
+  for (int k = 0; k < REFDATA_NMATRICES; k++)
+    if (strcasecmp(name, refdata_matrix_names[k]) == 0) {
+      for (int a = 0; a < 28; a++)
+        for (int b = 0; b < 28; b++)
+          M[(a << 5) + b] = refdata_matrices[k][a][b];
+      return 1;
+    }
+  return 0;
+}
+
+void swo_matrix_nucleotide(long match, long mismatch, long* M)
+{
+  swo_matrix_clear(M);
+  for (int a = 1; a < 16; a++)                       /* matrices.cc:533-538 */
+    for (int b = 1; b < 16; b++)
+      M[(a << 5) + b] = (a == b) ? match : mismatch;
+}
+
+/* The text form accepted by score_matrix_read_file/_string (matrices.cc:352-517):
+   '#' and blank lines skipped; a line starting with blank/tab lists the column symbols;
+   every other line is "<row symbol> v v v ...", stored at [(row<<5)+col]. */
+int swo_matrix_parse(const char* text, long* M)
+{
+  int order[256];
+  int symbols = 0;
+  swo_matrix_clear(M);
+  const char* s = text;
+  while (*s) {
+    const char* eol = strchr(s, '\n');
+    size_t len = eol ? (size_t)(eol - s) : strlen(s);
+    if (len > 0 && s[0] != '#') {
+      if (s[0] == ' ' || s[0] == '\t') {
+        int k = 0;                                    /* q = order restarts, matrices.cc:391 */
+        for (size_t i = 1; i < len; i++)
+          if (!strchr(" \t\n", s[i])) { order[k++ & 255] = aa_code((unsigned char)s[i]); symbols++; }
+      } else {
+        int a = aa_code((unsigned char)s[0]);
+        const char* p = s + 1;
+        const char* end = s + len;
+        for (int i = 0; i < symbols; i++) {
+          char* q;
+          while (p < end && isspace((unsigned char)*p)) p++;
+          if (p >= end) break;
+          long sc = strtol(p, &q, 10);
+          if (q == p) return 0;
+          int b = order[i & 255];
+          if (a >= 0 && b >= 0 && a < 32 && b < 32) M[(a << 5) + b] = sc;
+          p = q;
+        }
+      }
+    }
+    s += len + (eol ? 1 : 0);
+  }
+  return 1;
+}
+
+void swo_score_limits(const long* M, long* lo, long* hi, long* limit7, long* limit16)
+{
+  long l = 100, h = -100;                             /* matrices.cc:561-572 */
+  for (int i = 0; i < 1024; i++) {
+    if (M[i] < l) l = M[i];
+    if (M[i] > h) h = M[i];
+  }
+  if (lo) *lo = l;
+  if (hi) *hi = h;
+  if (limit7) *limit7 = 128 - h;                      /* matrices.cc:575 */
+  if (limit16) *limit16 = 65536 - h;                  /* matrices.cc:577 */
+}
+
+/* ------------------------------------------------------------------ 63-bit kernel ----- */
+
+long swo_fullsw(const unsigned char* dseq, long dlen, const unsigned char* qseq, long qlen,
+                const long* M, unsigned char gapopenextend, unsigned char gapextend)
+{
+  /* search63.cc:28-89: column-major sweep, he[2i] = H of the previous column at row i,
+     he[2i+1] = E.  H floored at 0 (64-65); E and F are not. */
+  long best = 0;
+  long* he = (long*)calloc((size_t)(qlen > 0 ? 2 * qlen : 1), sizeof(long));
+  for (long j = 0; j < dlen; j++) {
+    const long* row = M + ((long)dseq[j] << 5);
+    long f = 0, diag = 0;
+    for (long i = 0; i < qlen; i++) {
+      long up_left_next = he[2 * i];
+      long e = he[2 * i + 1];
+      long h = diag + row[qseq[i]];
+      if (e > h) h = e;
+      if (f > h) h = f;
+      if (h < 0) h = 0;
+      if (h > best) best = h;
+      he[2 * i] = h;
+      e -= gapextend;
+      f -= gapextend;
+      h -= gapopenextend;
+      if (h > e) e = h;
+      if (h > f) f = h;
+      he[2 * i + 1] = e;
+      diag = up_left_next;
+    }
+  }
+  free(he);
+  return best;
+}
+
+/* ------------------------------------------------------------------ 7-bit lane -------- */
+
+static inline uint8_t adds8(uint8_t a, uint8_t b)      /* paddsb */
+{
+  int r = (int8_t)a + (int8_t)b;
+  if (r > 127) r = 127;
+  if (r < -128) r = -128;
+  return (uint8_t)(int8_t)r;
+}
+static inline uint8_t subs8(uint8_t a, uint8_t b)      /* psubsb */
+{
+  int r = (int8_t)a - (int8_t)b;
+  if (r > 127) r = 127;
+  if (r < -128) r = -128;
+  return (uint8_t)(int8_t)r;
+}
+static inline uint8_t maxu8(uint8_t a, uint8_t b) { return a > b ? a : b; }   /* pmaxub */
+
+long swo_search7_lane(const unsigned char* dseq, long dlen, const unsigned char* qseq, long qlen,
+                      const long* M, unsigned char gapopenextend, unsigned char gapextend)
+{
+  /* One SSE byte lane of search7: hearray bytes start at 0x80 (search7.cc:787; a fresh
+     sequence is masked back to 0x80 at 698-705), S starts at Z (812), every 4-column block
+     starts with H0-3 = F0-3 = Z (INITIALIZE, 565-583), residues past the end are symbol 0
+     (840-843, 922-925).  A channel always runs at least one block (919-928). */
+  const uint8_t Z = 0x80;
+  const uint8_t Q = gapopenextend, R = gapextend;
+  uint8_t* H = (uint8_t*)malloc((size_t)(qlen > 0 ? qlen : 1));
+  uint8_t* E = (uint8_t*)malloc((size_t)(qlen > 0 ? qlen : 1));
+  memset(H, Z, (size_t)(qlen > 0 ? qlen : 1));
+  memset(E, Z, (size_t)(qlen > 0 ? qlen : 1));
+  uint8_t S = Z;
+  long blocks = (dlen + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  for (long b = 0; b < blocks; b++) {
+    unsigned char d[4];
+    for (int c = 0; c < 4; c++) d[c] = (4 * b + c < dlen) ? dseq[4 * b + c] : 0;
+    uint8_t hd[4] = {Z, Z, Z, Z}, f[4] = {Z, Z, Z, Z};
+    for (long i = 0; i < qlen; i++) {
+      uint8_t n0 = H[i], e = E[i], hn[4];
+      for (int c = 0; c < 4; c++) {                    /* ONESTEP, search7.cc:585-595 */
+        uint8_t p = (uint8_t)(signed char)M[((long)d[c] << 5) + qseq[i]];   /* (char) cast, matrices.cc:585 */
+        uint8_t h = adds8(hd[c], p);
+        h = maxu8(h, f[c]);
+        h = maxu8(h, e);
+        S = maxu8(S, h);
+        f[c] = subs8(f[c], R);
+        e = subs8(e, R);
+        hn[c] = h;
+        h = subs8(h, Q);
+        e = maxu8(e, h);
+        f[c] = maxu8(f[c], h);
+      }
+      H[i] = hn[3];
+      E[i] = e;
+      hd[0] = n0; hd[1] = hn[0]; hd[2] = hn[1]; hd[3] = hn[2];
+    }
+  }
+  free(H);
+  free(E);
+  return (long)S - 0x80;                               /* search7.cc:894 */
+}
+
+/* ------------------------------------------------------------------ 16-bit lane ------- */
+
+static inline uint16_t adds16(uint16_t a, uint16_t b)   /* paddsw */
+{
+  int r = (int16_t)a + (int16_t)b;
+  if (r > 32767) r = 32767;
+  if (r < -32768) r = -32768;
+  return (uint16_t)(int16_t)r;
+}
+static inline uint16_t subs16(uint16_t a, uint16_t b)   /* psubsw */
+{
+  int r = (int16_t)a - (int16_t)b;
+  if (r > 32767) r = 32767;
+  if (r < -32768) r = -32768;
+  return (uint16_t)(int16_t)r;
+}
+static inline uint16_t maxs16(uint16_t a, uint16_t b) { return (int16_t)a > (int16_t)b ? a : b; }  /* pmaxsw */
+
+long swo_search16_lane(const unsigned char* dseq, long dlen, const unsigned char* qseq, long qlen,
+                       const long* M, unsigned short gapopenextend, unsigned short gapextend,
+                       long* bestpos)
+{
+  /* search16.cc:99-109 (ONESTEP), 320-546 (driver).  Same structure as the 7-bit lane with
+     0x8000-biased words and a signed max; after each block the column position is recorded
+     if S rose (search16.cc:411-414, 528-534). */
+  const uint16_t Z = 0x8000;
+  const uint16_t Q = gapopenextend, R = gapextend;
+  size_t n = (size_t)(qlen > 0 ? qlen : 1);
+  uint16_t* H = (uint16_t*)malloc(n * sizeof(uint16_t));
+  uint16_t* E = (uint16_t*)malloc(n * sizeof(uint16_t));
+  for (size_t i = 0; i < n; i++) H[i] = E[i] = Z;
+  uint16_t S = Z, SL = Z;
+  long best = 0;
+  long blocks = (dlen + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  for (long b = 0; b < blocks; b++) {
+    unsigned char d[4];
+    for (int c = 0; c < 4; c++) d[c] = (4 * b + c < dlen) ? dseq[4 * b + c] : 0;
+    uint16_t hd[4] = {Z, Z, Z, Z}, f[4] = {Z, Z, Z, Z};
+    for (long i = 0; i < qlen; i++) {
+      uint16_t n0 = H[i], e = E[i], hn[4];
+      for (int c = 0; c < 4; c++) {
+        uint16_t p = (uint16_t)(short)M[((long)d[c] << 5) + qseq[i]];       /* (short) cast, matrices.cc:589 */
+        uint16_t h = adds16(hd[c], p);
+        h = maxs16(h, f[c]);
+        h = maxs16(h, e);
+        S = maxs16(S, h);
+        f[c] = subs16(f[c], R);
+        e = subs16(e, R);
+        hn[c] = h;
+        h = subs16(h, Q);
+        e = maxs16(e, h);
+        f[c] = maxs16(f[c], h);
+      }
+      H[i] = hn[3];
+      E[i] = e;
+      hd[0] = n0; hd[1] = hn[0]; hd[2] = hn[1]; hd[3] = hn[2];
+    }
+    if ((int16_t)S > (int16_t)SL) {                    /* _mm_cmpgt_epi16(S, SL) */
+      long pos = 4 * (b + 1);
+      best = pos < dlen ? pos : dlen;                  /* d_pos stops at d_end */
+    }
+    SL = S;
+  }
+  free(H);
+  free(E);
+  if (bestpos) *bestpos = best;
+  return (long)(S ^ 0x8000);                           /* search16.cc:462 */
+}
+
+/* ------------------------------------------------------------------ escalation -------- */
+
+void swo_search_chunk(const unsigned char* residues, const int64_t* offsets, long nseq,
+                      const unsigned char* qseq, long qlen, const long* M,
+                      long gapopenextend, long gapextend, long* scores, swo_counters* counters)
+{
+  /* swipe.cc:1416-1592: every sequence goes through the 7-bit kernel; those whose score is
+     not < SCORELIMIT_7 are redone at 16 bit; those not < SCORELIMIT_16 by fullsw.  The gap
+     penalties narrow to BYTE / WORD / BYTE at the three call sites (swipe.h:200-258). */
+  long limit7, limit16;
+  swo_score_limits(M, 0, 0, &limit7, &limit16);
+  swo_counters c = {0, 0, 0};
+  for (long s = 0; s < nseq; s++) {
+    const unsigned char* d = residues + offsets[s];
+    long dlen = (long)(offsets[s + 1] - offsets[s]);
+    c.compute7++;
+    long sc = swo_search7_lane(d, dlen, qseq, qlen, M, (unsigned char)gapopenextend, (unsigned char)gapextend);
+    if (!(sc < limit7)) {
+      c.compute16++;
+      sc = swo_search16_lane(d, dlen, qseq, qlen, M, (unsigned short)gapopenextend, (unsigned short)gapextend, 0);
+      if (!(sc < limit16)) {
+        c.compute63++;
+        sc = swo_fullsw(d, dlen, qseq, qlen, M, (unsigned char)gapopenextend, (unsigned char)gapextend);
+      }
+    }
+    scores[s] = sc;
+  }
+  if (counters) *counters = c;
+}
+
+typedef struct {
+  const unsigned char* residues; const int64_t* offsets; long nseq;
+  const unsigned char* qseq; long qlen; const long* M; long goe, ge; long* scores;
+  long next; pthread_mutex_t mu;
+} all63_job;
+
+static void* all63_worker(void* arg)
+{
+  all63_job* j = (all63_job*)arg;
+  for (;;) {
+    pthread_mutex_lock(&j->mu);
+    long lo = j->next;
+    j->next += 256;
+    pthread_mutex_unlock(&j->mu);
+    if (lo >= j->nseq) break;
+    long hi = lo + 256 < j->nseq ? lo + 256 : j->nseq;
+    for (long s = lo; s < hi; s++)
+      j->scores[s] = swo_fullsw(j->residues + j->offsets[s], (long)(j->offsets[s + 1] - j->offsets[s]),
+                                j->qseq, j->qlen, j->M, (unsigned char)j->goe, (unsigned char)j->ge);
+  }
+  return 0;
+}
+
+void swo_search_all63(const unsigned char* residues, const int64_t* offsets, long nseq,
+                      const unsigned char* qseq, long qlen, const long* M,
+                      long gapopenextend, long gapextend, long* scores, int threads)
+{
+  all63_job j = {residues, offsets, nseq, qseq, qlen, M, gapopenextend, gapextend, scores, 0,
+                 PTHREAD_MUTEX_INITIALIZER};
+  if (threads < 1) threads = 1;
+  pthread_t* t = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  for (int i = 0; i < threads; i++) pthread_create(&t[i], 0, all63_worker, &j);
+  for (int i = 0; i < threads; i++) pthread_join(t[i], 0);
+  free(t);
+}
+
+/* ------------------------------------------------------------------ statistics -------- */
+
+int swo_stats_protein(const char* matrix, long gapopen, long gapextend, swo_ka* p)
+{
+  /* stats.cc:169-247: first row whose (open, extend) match within 0.1 */
+  for (int t = 0; t < REFDATA_NKA; t++)
+    if (strcasecmp(matrix, refdata_ka_tables[t].name) == 0) {
+      for (int i = 0; i < refdata_ka_tables[t].n; i++) {
+        const refdata_ka_row* r = &refdata_ka_tables[t].rows[i];
+        if (fabs(r->go - (double)gapopen) < 0.1 && fabs(r->ge - (double)gapextend) < 0.1) {
+          p->lambda = r->lambda; p->K = r->K; p->H = r->H; p->alpha = r->alpha; p->beta = r->beta;
+          return 1;
+        }
+      }
+      return 0;
+    }
+  return 0;
+}
+
+int swo_stats_default_gaps(const char* matrix, long* gapopen, long* gapextend)
+{
+  /* stats.cc:249-325: the row flagged BLAST_MATRIX_BEST */
+  for (int t = 0; t < REFDATA_NKA; t++)
+    if (strcasecmp(matrix, refdata_ka_tables[t].name) == 0)
+      for (int i = 0; i < refdata_ka_tables[t].n; i++)
+        if (refdata_ka_tables[t].rows[i].best) {
+          *gapopen = (long)refdata_ka_tables[t].rows[i].go;
+          *gapextend = (long)refdata_ka_tables[t].rows[i].ge;
+          return 1;
+        }
+  return 0;
+}
+
+int swo_stats_nucleotide(long match, long mismatch, long gapopen, long gapextend, swo_ka* p)
+{
+  /* stats.cc:44-167: table by (reward, penalty); penalties at or above both maxima select the
+     (0, 0) "linear" row (stats.cc:147-151) */
+  for (int t = 0; t < REFDATA_NNT; t++)
+    if (refdata_nt_tables[t].match == match && refdata_nt_tables[t].mismatch == mismatch) {
+      const refdata_nt_table* nt = &refdata_nt_tables[t];
+      if (gapopen >= nt->gomax && gapextend >= nt->gemax) { gapopen = 0; gapextend = 0; }
+      for (int i = 0; i < nt->n; i++)
+        if (fabs(nt->rows[i][0] - (double)gapopen) < 0.1 && fabs(nt->rows[i][1] - (double)gapextend) < 0.1) {
+          p->lambda = nt->rows[i][2]; p->K = nt->rows[i][3]; p->H = nt->rows[i][4];
+          p->alpha = nt->rows[i][5]; p->beta = nt->rows[i][6];
+          return 1;
+        }
+      return 0;
+    }
+  return 0;
+}
+
+int swo_length_adjustment(double K, double logK, double alpha_d_lambda, double beta,
+                          int query_length, long db_length, int db_num_seqs, int* adj)
+{
+  /* blastkar_partial.c:656-748 (NCBI public domain): fixed point of
+       ell = alpha/lambda * (ln K + ln((m-ell)(n-N ell))) + beta
+     by at most 20 bracketed iterations; floor of the largest ell known to be below it. */
+  const double m = query_length, n = (double)db_length, N = db_num_seqs;
+  double lo = 0.0, hi, cur = 0.0, next = 0.0;
+  int ok = 0;
+  {
+    double a = N, mb = m * N + n;
+    double c = n * m - (m > n ? m : n) / K;
+    if (c < 0) { *adj = 0; return 1; }
+    hi = 2 * c / (mb + sqrt(mb * mb - 4 * a * c));
+  }
+  for (int it = 1; it <= 20; it++) {
+    cur = next;
+    double space = (m - cur) * (n - N * cur);
+    double prop = alpha_d_lambda * (logK + log(space)) + beta;
+    if (prop >= cur) {
+      lo = cur;
+      if (prop - lo <= 1.0) { ok = 1; break; }
+      if (lo >= hi) break;
+    } else {
+      hi = cur;
+    }
+    if (lo <= prop && prop <= hi) next = prop;
+    else next = (it == 1) ? hi : (lo + hi) / 2;
+  }
+  if (ok) {
+    *adj = (int)lo;
+    double up = ceil(lo);
+    if (up <= hi) {
+      double space = (m - up) * (n - N * up);
+      if (alpha_d_lambda * (logK + log(space)) + beta >= up) *adj = (int)up;
+    }
+  } else {
+    *adj = (int)lo;
+  }
+  return ok ? 0 : 1;
+}
+
+/* ------------------------------------------------------------------ hit list ---------- */
+
+swo_hits* swo_hits_new(long descriptions, long alignments, long minscore, long maxscore,
+                       double minexpect, double expect, int symtype, int querystrands,
+                       const char* matrix, long match, long mismatch, long gapopen, long gapextend,
+                       long qlen, long dbseqs, long dbsyms, long effdbsize)
+{
+  /* hits.cc:283-511 for symtype 0 and 1 */
+  swo_hits* h = (swo_hits*)calloc(1, sizeof(swo_hits));
+  h->keephits = descriptions > alignments ? descriptions : alignments;
+  long maxhits = dbseqs;
+  if (symtype == 0 && querystrands == 3) maxhits *= 2;              /* hits.cc:290-294 */
+  if (h->keephits > maxhits) h->keephits = maxhits;
+  h->list = (swo_hit*)calloc((size_t)(h->keephits > 0 ? h->keephits : 1), sizeof(swo_hit));
+  swo_ka p;
+  int avail = symtype == 0 ? swo_stats_nucleotide(match, mismatch, gapopen, gapextend, &p)
+                           : swo_stats_protein(matrix, gapopen, gapextend, &p);
+  h->stats_available = avail;
+  h->scorethreshold = minscore;
+  h->upperscorethreshold = maxscore;
+  if (avail) {
+    h->lambda = p.lambda;
+    h->K = p.K;
+    h->logK = log(p.K);
+    h->lambda_d_log2 = p.lambda / log(2.0);
+    h->logK_d_log2 = h->logK / log(2.0);
+    int seqcount = (int)dbseqs;                                      /* "int seqcount", hits.cc:330 */
+    long dlen = effdbsize > 0 ? effdbsize : dbsyms;
+    int lenadj = 0;
+    swo_length_adjustment(p.K, h->logK, p.alpha / p.lambda, p.beta, (int)qlen, dlen, seqcount, &lenadj);
+    h->lenadj = lenadj;
+    h->m = qlen - lenadj;
+    h->n = effdbsize > 0 ? effdbsize : dlen - (long)seqcount * lenadj;
+    h->Kmn = p.K * (double)h->m * (double)h->n;
+    long minscore_expect = (long)(ceil(-log(expect / h->Kmn) / p.lambda));   /* hits.cc:491 */
+    if (minscore_expect > minscore) h->scorethreshold = minscore_expect;
+    if (minexpect > 0.0) {
+      long maxscore_expect = (long)(floor(-log(minexpect / h->Kmn) / p.lambda));
+      if (maxscore_expect < maxscore) h->upperscorethreshold = maxscore_expect;
+    }
+  }
+  h->init_threshold = h->scorethreshold;
+  return h;
+}
+
+void swo_hits_enter(swo_hits* h, long seqno, long score, long qstrand, long qframe, long dstrand, long dframe)
+{
+  /* hits.cc:163-222: bounded list kept sorted by (score desc, seqno desc) */
+  if (score > h->upperscorethreshold) h->obvious++;
+  if (score >= h->init_threshold) h->totalhits++;
+  if (score < h->scorethreshold || score > h->upperscorethreshold) return;
+  long place = h->count;
+  while (place > 0 && (score > h->list[place - 1].score ||
+                       (score == h->list[place - 1].score && seqno > h->list[place - 1].seqno)))
+    place--;
+  long move = (h->count < h->keephits ? h->count : h->keephits - 1) - place;
+  for (long j = move; j > 0; j--) h->list[place + j] = h->list[place + j - 1];
+  if (place < h->keephits) {
+    swo_hit e = {seqno, score, qstrand, qframe, dstrand, dframe};
+    h->list[place] = e;
+    if (h->count < h->keephits) h->count++;
+  }
+  if (h->count == h->keephits && h->keephits > 0) h->scorethreshold = h->list[h->keephits - 1].score;
+}
+
+double swo_hits_expect(const swo_hits* h, long score) { return h->Kmn * exp(-h->lambda * score); }      /* hits.cc:1777 */
+double swo_hits_bits(const swo_hits* h, long score) { return h->lambda_d_log2 * score - h->logK_d_log2; } /* hits.cc:1779 */
+
+void swo_hits_free(swo_hits* h)
+{
+  if (h) { free(h->list); free(h); }
+}
