@@ -1,0 +1,133 @@
+/* swipe_amd - MI355X-native inter-sequence Smith-Waterman database search.
+
+   C ABI of the drop-in boundary described in SURVEY.md section 8(b).  SWIPE has no plugin
+   API; its narrowest seam around the hot path is search_chunk() (swipe.cc:1365-1596):
+   input = a contiguous range of database sequence numbers, output = one exact local
+   alignment score per sequence, handed to hits_enter().  The functions below replace
+   exactly that seam and the few reference functions that feed it:
+
+     reference (file:line)                              this ABI
+     --------------------------------------------------------------------------------------
+     db_open + db_mapsequences  (database.cc:775,1082)  swa_db_open / swa_db_from_memory
+     db_getseqcount/symcount/longest (swipe.h:305-309)  swa_db_info
+     score_matrix_init -> score_matrix_63, limits
+                        (matrices.cc:520-591)           swa_set_scoring
+     search7 + search16 + fullsw under search_chunk
+                        (swipe.h:200-258, swipe.cc:1416-1592)  swa_search
+     hits_enter loop + top-K list (hits.cc:163-222)     swa_search_topk / swa_hits_*
+     hits_init thresholds, E-values (hits.cc:283-511,
+                        1777-1779; stats.cc)            swa_stats_init / swa_evalue / swa_bits
+     search16s end points (swipe.h:237-249)             swa_search_endpoints
+
+   Conventions: plain pointers and sizes, caller owns every buffer, the callee keeps no host
+   pointer past return.  Every function returns SWA_OK (0) or a negative SWA_E* code; the
+   message for the last failure on the calling thread is swa_last_error().  (The reference
+   never returns an error: fatal() prints and exit(1)s, swipe.cc:158-170 - the CLI driver on
+   top of this ABI reproduces that.)  One host thread per device handle.
+   There is NO CPU fallback: without a usable HIP device every compute entry point fails.
+*/
+#ifndef SWIPE_AMD_H
+#define SWIPE_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWA_OK          0
+#define SWA_EINVAL     -1   /* bad argument */
+#define SWA_ENODEV     -2   /* no HIP device / HIP runtime error */
+#define SWA_ENOMEM     -3
+#define SWA_EIO        -4   /* database files unreadable or malformed */
+#define SWA_ESTATE     -5   /* call order (e.g. search before set_scoring) */
+
+#define SWA_SYMTYPE_NUCLEOTIDE 0   /* reference symtype 0: 4-bit base masks, A=1 C=2 G=4 T=8 */
+#define SWA_SYMTYPE_PROTEIN    1   /* reference symtype 1: NCBIstdaa codes 0..27 */
+
+typedef struct swa_db swa_db;     /* one database shard resident in HBM, read-only after open */
+
+typedef struct {
+  int64_t seqcount;      /* sequences in this shard */
+  int64_t symcount;      /* residues in this shard */
+  int64_t longest;       /* longest sequence in this shard */
+  int64_t first_seqno;   /* global number of the shard's first sequence */
+  int64_t total_seqcount, total_symcount;   /* whole database (all shards), for statistics */
+  int64_t hbm_bytes;     /* device memory held */
+} swa_db_info_t;
+
+/* counters of the escalation loop; the reference's compute7/compute16/compute63
+   (swipe.cc:111-119) counted sequences per lane width in the same way */
+typedef struct {
+  int64_t narrow;        /* sequences scored by the packed 16-bit-lane kernel */
+  int64_t wide;          /* re-queued to the 32-bit kernel (score >= narrow limit) */
+  int64_t full;          /* re-queued to the 64-bit kernel (score >= 2^31 - hi) */
+  int64_t cells;         /* DP cells computed in the first pass (symcount * qlen) */
+  double  kernel_ms;     /* device time of the first-pass kernel (HIP events) */
+  double  total_ms;      /* device time of the whole search (HIP events) */
+} swa_counters_t;
+
+typedef struct { int64_t seqno; int64_t score; } swa_hit_t;
+
+const char* swa_last_error(void);
+int swa_device_count(void);
+
+/* ---- database --------------------------------------------------------------------------- */
+/* Opens BLAST v4 volume(s) `basename` (.pin/.psq or .nin/.nsq, or a .pal/.nal alias) and loads
+   the sequences [first_seqno, last_seqno] (last_seqno < 0: to the end) onto `device`,
+   re-formatted for the kernels.  Mirrors db_open + db_mapsequences. */
+int swa_db_open(const char* basename, int symtype, int device,
+                int64_t first_seqno, int64_t last_seqno, swa_db** out);
+/* Same from host arrays: sequence s = residues[offsets[s] .. offsets[s+1]) in reference symbol
+   codes.  total_* describe the whole database when this is one shard of it (pass 0 to use
+   the shard's own counts). */
+int swa_db_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq,
+                       int symtype, int device, int64_t first_seqno,
+                       int64_t total_seqcount, int64_t total_symcount, swa_db** out);
+int swa_db_info(const swa_db* db, swa_db_info_t* info);
+void swa_db_close(swa_db* db);
+
+/* ---- scoring ------------------------------------------------------------------------------ */
+/* matrix: 32*32 scores, index (db_symbol << 5) | query_symbol, as score_matrix_63
+   (matrices.cc:583-590); gapopenextend = gapopen + gapextend (swipe.cc:1126). */
+int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapopenextend, int64_t gapextend);
+
+/* ---- search --------------------------------------------------------------------------------- */
+/* Exact Smith-Waterman score of `query` (reference symbol codes) against every sequence of the
+   shard: scores[s - first_seqno].  `scores` may be NULL (bench: results stay on device). */
+int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores,
+               swa_counters_t* counters);
+/* The hits_enter loop on device: keeps the `keep` best (score desc, seqno desc) among
+   minscore <= score <= maxscore; *totalhits counts scores >= minscore, *obvious counts scores
+   > maxscore (hits.cc:174-178).  hits[] receives *nhits entries, already ordered. */
+int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep,
+                    int64_t minscore, int64_t maxscore, swa_hit_t* hits, int64_t* nhits,
+                    int64_t* totalhits, int64_t* obvious, swa_counters_t* counters);
+/* Merge per-shard top-K lists (each ordered) into the global top-K with the reference's
+   comparator - what the MPI master does with tag_search_report (swipe.cc:1951-1974). */
+int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
+                   int64_t keep, swa_hit_t* out, int64_t* nout);
+
+/* ---- statistics (host arithmetic, bit-exact with hits.cc/stats.cc) ------------------------- */
+typedef struct {
+  int available;                       /* 0: no K-A parameters for this scoring system */
+  double lambda, K, H, alpha, beta;
+  double Kmn, logK, lambda_d_log2, logK_d_log2;
+  int64_t lenadj, m, n;
+  int64_t scorethreshold, upperscorethreshold;   /* after the E-value cut, hits.cc:486-508 */
+} swa_stats_t;
+int swa_stats_init(int symtype, const char* matrixname, int64_t match, int64_t mismatch,
+                   int64_t gapopen, int64_t gapextend, int64_t qlen,
+                   int64_t db_seqcount, int64_t db_symcount, int64_t effdbsize,
+                   int64_t minscore, int64_t maxscore, double minexpect, double expect,
+                   swa_stats_t* out);
+double swa_evalue(const swa_stats_t* st, int64_t score);   /* hits.cc:1777 */
+double swa_bits(const swa_stats_t* st, int64_t score);     /* hits.cc:1779 */
+/* Built-in matrices by name (matrices.cc:540-559); returns SWA_EINVAL for unknown names. */
+int swa_matrix_builtin(const char* name, int64_t* matrix);
+int swa_matrix_nucleotide(int64_t match, int64_t mismatch, int64_t* matrix);
+int swa_matrix_parse(const char* text, int64_t* matrix);
+int swa_default_gaps(const char* matrixname, int64_t* gapopen, int64_t* gapextend);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""swipe_amd: MI355X-native Smith-Waterman database search (the inter-sequence DP fill of
+torognes/swipe rebuilt as gfx950 HIP kernels behind a C ABI).
+
+Python here is plumbing over libswipe_amd.so - see include/swipe_amd.h for the boundary and
+DESIGN.md for the data layout and kernels."""
+from .api import (Database, SwaError, matrix_builtin, matrix_nucleotide, matrix_parse, default_gaps,
+                  stats_init, merge_hits, synth_db)
+
+__all__ = ["Database", "SwaError", "matrix_builtin", "matrix_nucleotide", "matrix_parse", "default_gaps",
+           "stats_init", "merge_hits", "synth_db"]

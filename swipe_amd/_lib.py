@@ -1,0 +1,82 @@
+"""ctypes binding of swipe_amd/libswipe_amd.so (the C ABI in include/swipe_amd.h).
+
+The library is the product: if it is missing this module raises - there is no Python or CPU
+fallback for any compute entry point."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswipe_amd.so")
+
+
+class DbInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("seqcount", "symcount", "longest", "first_seqno",
+                                         "total_seqcount", "total_symcount", "hbm_bytes")]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("narrow", "wide", "full", "cells")] + \
+               [("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("seqno", C.c_int64), ("score", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("available", C.c_int)] + \
+               [(n, C.c_double) for n in ("lam", "K", "H", "alpha", "beta", "Kmn", "logK",
+                                          "lambda_d_log2", "logK_d_log2")] + \
+               [(n, C.c_int64) for n in ("lenadj", "m", "n", "scorethreshold", "upperscorethreshold")]
+
+
+EXPORTS = [
+    "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
+    "swa_db_close", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_hits_merge",
+    "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
+    "swa_matrix_parse", "swa_default_gaps",
+    "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C swipe_amd/csrc` (swipe_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i64p = C.c_void_p, C.c_int64, C.POINTER(C.c_int64)
+    L.swa_last_error.restype = C.c_char_p
+    L.swa_device_count.restype = C.c_int
+    L.swa_db_open.argtypes = [C.c_char_p, C.c_int, C.c_int, i64, i64, C.POINTER(vp)]
+    L.swa_db_from_memory.argtypes = [vp, vp, i64, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp)]
+    L.swa_db_info.argtypes = [vp, C.POINTER(DbInfo)]
+    L.swa_db_close.argtypes = [vp]
+    L.swa_db_close.restype = None
+    L.swa_set_scoring.argtypes = [vp, vp, i64, i64]
+    L.swa_search.argtypes = [vp, vp, i64, vp, C.POINTER(Counters)]
+    L.swa_search_topk.argtypes = [vp, vp, i64, i64, i64, i64, C.POINTER(Hit), i64p, i64p, i64p, C.POINTER(Counters)]
+    L.swa_hits_merge.argtypes = [C.POINTER(Hit), i64p, C.c_int, i64, i64, C.POINTER(Hit), i64p]
+    L.swa_stats_init.argtypes = [C.c_int, C.c_char_p, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
+                                 C.c_double, C.c_double, C.POINTER(Stats)]
+    L.swa_evalue.argtypes = [C.POINTER(Stats), i64]
+    L.swa_evalue.restype = C.c_double
+    L.swa_bits.argtypes = [C.POINTER(Stats), i64]
+    L.swa_bits.restype = C.c_double
+    L.swa_matrix_builtin.argtypes = [C.c_char_p, vp]
+    L.swa_matrix_nucleotide.argtypes = [i64, i64, vp]
+    L.swa_matrix_parse.argtypes = [C.c_char_p, vp]
+    L.swa_default_gaps.argtypes = [C.c_char_p, i64p, i64p]
+    L.swa_synth_length.argtypes = [C.c_uint64, i64, vp, vp, i64]
+    L.swa_synth_length.restype = i64
+    L.swa_synth_offsets.argtypes = [C.c_uint64, i64, i64, vp, vp, i64, vp, C.c_int]
+    L.swa_synth_offsets.restype = i64
+    L.swa_synth_fill.argtypes = [C.c_uint64, i64, i64, vp, vp, vp, i64, vp, vp, C.c_int]
+    _lib = L
+    return L

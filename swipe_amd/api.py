@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's interface around the hot path, over the C ABI.
+
+  reference                                   here
+  db_open / db_mapsequences                   Database.open / Database.from_sequences
+  score_matrix_init (+ gap penalties)         Database.set_scoring, matrix_builtin, ...
+  search_chunk -> hits_enter per sequence     Database.search (all scores) / search_topk
+  hits_init thresholds, E-value, bit score    stats_init -> Stats.evalue / .bits
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+class SwaError(RuntimeError):
+    pass
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SwaError(f"[{rc}] {_lib.load().swa_last_error().decode()}")
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def matrix_builtin(name: str) -> np.ndarray:
+    M = np.empty(1024, dtype=np.int64)
+    _check(_lib.load().swa_matrix_builtin(name.encode(), M.ctypes.data))
+    return M
+
+
+def matrix_nucleotide(match: int = 1, mismatch: int = -3) -> np.ndarray:
+    M = np.empty(1024, dtype=np.int64)
+    _check(_lib.load().swa_matrix_nucleotide(match, mismatch, M.ctypes.data))
+    return M
+
+
+def matrix_parse(text: str) -> np.ndarray:
+    M = np.empty(1024, dtype=np.int64)
+    _check(_lib.load().swa_matrix_parse(text.encode(), M.ctypes.data))
+    return M
+
+
+def default_gaps(matrix: str):
+    a, b = C.c_int64(), C.c_int64()
+    _check(_lib.load().swa_default_gaps(matrix.encode(), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+class Stats:
+    def __init__(self, raw):
+        self.raw = raw
+        for f, _ in raw._fields_:
+            setattr(self, f, getattr(raw, f))
+
+    def evalue(self, score: int) -> float:
+        return _lib.load().swa_evalue(C.byref(self.raw), int(score))
+
+    def bits(self, score: int) -> float:
+        return _lib.load().swa_bits(C.byref(self.raw), int(score))
+
+
+def stats_init(*, symtype=1, matrix="BLOSUM62", match=1, mismatch=-3, gapopen=11, gapextend=1, qlen=0,
+               db_seqcount=0, db_symcount=0, effdbsize=0, minscore=1, maxscore=(1 << 62), minexpect=0.0,
+               expect=10.0) -> Stats:
+    s = _lib.Stats()
+    _check(_lib.load().swa_stats_init(symtype, matrix.encode(), match, mismatch, gapopen, gapextend, qlen,
+                                      db_seqcount, db_symcount, effdbsize, minscore, maxscore, minexpect, expect,
+                                      C.byref(s)))
+    return Stats(s)
+
+
+def merge_hits(lists: Sequence[Sequence[tuple]], keep: int):
+    """Global top-`keep` of per-shard ordered hit lists (score desc, seqno desc)."""
+    n = len(lists)
+    stride = max((len(l) for l in lists), default=0)
+    buf = (_lib.Hit * max(1, n * stride))()
+    counts = (C.c_int64 * max(1, n))()
+    for i, l in enumerate(lists):
+        counts[i] = len(l)
+        for j, (seqno, score) in enumerate(l):
+            buf[i * stride + j] = _lib.Hit(int(seqno), int(score))
+    out = (_lib.Hit * max(1, keep))()
+    nout = C.c_int64()
+    _check(_lib.load().swa_hits_merge(buf, counts, n, stride, keep, out, C.byref(nout)))
+    return [(out[i].seqno, out[i].score) for i in range(nout.value)]
+
+
+class Database:
+    """One database shard resident in the HBM of one MI355X."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, basename: str, *, symtype: int = 1, device: int = 0, first_seqno: int = 0, last_seqno: int = -1):
+        h = C.c_void_p()
+        _check(_lib.load().swa_db_open(os.fsencode(basename), symtype, device, first_seqno, last_seqno, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, residues: np.ndarray, offsets: np.ndarray, *, symtype: int = 1, device: int = 0,
+                    first_seqno: int = 0, total_seqcount: int = 0, total_symcount: int = 0):
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = _i64(offsets)
+        h = C.c_void_p()
+        _check(_lib.load().swa_db_from_memory(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1, symtype,
+                                              device, first_seqno, total_seqcount, total_symcount, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_sequences(cls, seqs, **kw):
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        res = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if len(seqs) else np.zeros(0, np.uint8)
+        return cls.from_arrays(res, off, **kw)
+
+    def info(self):
+        i = _lib.DbInfo()
+        _check(_lib.load().swa_db_info(self._h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in i._fields_}
+
+    def set_scoring(self, matrix: np.ndarray, gapopen: int, gapextend: int):
+        """gapopen/gapextend as on the reference command line; the kernels get open+extend (swipe.cc:1126)."""
+        M = _i64(matrix)
+        _check(_lib.load().swa_set_scoring(self._h, M.ctypes.data, gapopen + gapextend, gapextend))
+
+    def search(self, query: np.ndarray, *, want_scores: bool = True):
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        c = _lib.Counters()
+        scores = np.empty(self.info()["seqcount"], dtype=np.int64) if want_scores else None
+        _check(_lib.load().swa_search(self._h, q.ctypes.data, len(q), scores.ctypes.data if want_scores else None,
+                                      C.byref(c)))
+        return scores, {f: getattr(c, f) for f, _ in c._fields_}
+
+    def search_topk(self, query: np.ndarray, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        c = _lib.Counters()
+        hits = (_lib.Hit * max(1, keep))()
+        n, tot, obv = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(_lib.load().swa_search_topk(self._h, q.ctypes.data, len(q), keep, minscore, maxscore, hits,
+                                           C.byref(n), C.byref(tot), C.byref(obv), C.byref(c)))
+        return ([(hits[i].seqno, hits[i].score) for i in range(n.value)], tot.value, obv.value,
+                {f: getattr(c, f) for f, _ in c._fields_})
+
+    def close(self):
+        if self._h:
+            _lib.load().swa_db_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_db(seed: int, nseq: int, *, first: int = 0, query: Optional[np.ndarray] = None, protein: bool = True,
+             threads: int = 0):
+    """(residues uint8, offsets int64) of synthetic sequences [first, first+nseq) - C++ generator."""
+    from . import synth
+    L = _lib.load()
+    threads = threads or os.cpu_count() or 1
+    ltab = np.ascontiguousarray(synth.length_table(), dtype=np.int32)
+    rtab = np.ascontiguousarray(synth.residue_table_protein() if protein else synth.residue_table_nucleotide())
+    q = np.ascontiguousarray(query, dtype=np.uint8) if query is not None else np.zeros(0, np.uint8)
+    qp = q.ctypes.data if len(q) else None
+    off = np.zeros(nseq + 1, dtype=np.int64)
+    total = L.swa_synth_offsets(seed, first, nseq, ltab.ctypes.data, qp, len(q), off.ctypes.data, threads)
+    res = np.empty(total, dtype=np.uint8)
+    L.swa_synth_fill(seed, first, nseq, ltab.ctypes.data, rtab.ctypes.data, qp, len(q), off.ctypes.data,
+                     res.ctypes.data, threads)
+    return res, off

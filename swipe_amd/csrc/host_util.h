@@ -1,0 +1,25 @@
+// Small host-side helpers shared by the library's translation units.
+#ifndef SWA_HOST_UTIL_H
+#define SWA_HOST_UTIL_H
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace swa {
+// records the message returned by swa_last_error() on this thread and returns `code`
+int fail(int code, const std::string& msg);
+
+// A database (or a range of one) read from BLAST v4 files into host memory:
+// sequence s = residues[offsets[s] .. offsets[s+1]) in reference symbol codes.
+struct HostDb {
+  std::vector<uint8_t> residues;
+  std::vector<int64_t> offsets;       // nseq + 1
+  int64_t first_seqno = 0;
+  int64_t total_seqcount = 0, total_symcount = 0, longest = 0;
+  std::string title;
+};
+// Mirrors db_open (alias + volumes, database.cc:775-925) and db_getsequence
+// (database.cc:1237-1401) for symtype 0 and 1.  Returns SWA_OK or records an error.
+int read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out);
+}  // namespace swa
+#endif

@@ -1,0 +1,51 @@
+// Structures shared by the device kernels (sw_kernels.hip) and the host library (swipe_amd.cpp).
+#ifndef SW_DEVICE_H
+#define SW_DEVICE_H
+#include <stdint.h>
+
+#define SWA_SLOTS 8            /* sequences per batch: 4 DPP rows x 2 packed halves */
+#define SWA_PAD 31             /* residue code used past the end of a sequence; scores -1 vs everything.
+                                  No reference alphabet produces code 31 (query.cc:51-109), and the
+                                  reference's matrices leave it at the default -1 (matrices.cc:531). */
+#define SWA_SCORE_IN_64 0x7fffffff   /* scores[i] sentinel: the value lives in scores64[i] */
+
+struct swa_batch {
+  uint32_t offset;             /* start of the batch in the residue stream, in 128-byte chunks */
+  int32_t nchunks;             /* 16-column chunks = ceil(longest sequence of the batch / 16) */
+};
+
+struct swa_query {
+  const uint8_t* qseq;         /* query residues, reference symbol codes (< 32) */
+  const int32_t* matrix;       /* 32x32, (db symbol << 5) | query symbol */
+  int32_t qlen;
+};
+
+struct swa_narrow_params {
+  const swa_query* query;
+  const uint16_t* stream;      /* [batch][chunk][row 0..3][lane 0..15] residue pairs (A | B << 8) */
+  const swa_batch* batches;
+  const int32_t* slots;        /* [batch][SWA_SLOTS] shard-local sequence index or -1 */
+  int32_t nbatches;
+  int32_t* counter;            /* work queue head */
+  int32_t* scores;             /* [nseq] */
+  int32_t limit;               /* 2048 - hi: scores >= limit are re-queued */
+  int32_t* ovf_count;
+  int32_t* ovf_list;
+  uint32_t negQ, negR;         /* packed f16 pairs: -(gapopen+gapextend), -gapextend */
+};
+
+struct swa_wide_params {
+  const swa_query* query;
+  const uint16_t* stream;
+  const swa_batch* batches;
+  const int32_t* slots;
+  int32_t nbatches;
+  int32_t* counter;
+  int32_t* scores;
+  long long* scores64;
+  long long limit;             /* 2^31 - hi for the 32-bit kernel */
+  int32_t* ovf_count;
+  int32_t* ovf_list;
+  long long gapopenextend, gapextend;
+};
+#endif

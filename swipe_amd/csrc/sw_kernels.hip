@@ -1,0 +1,471 @@
+// swipe_amd device code: Smith-Waterman database search kernels for gfx950 (MI355X, CDNA4).
+//
+// What the reference does with 16 SSE byte lanes (search7.cc:565-958), 8 word lanes
+// (search16.cc:99-546) and a scalar loop (search63.cc:28-89) is done here by ONE systolic
+// scheme at three arithmetic widths:
+//
+//   * a 16-lane DPP row (quarter wave) owns one database sequence (narrow kernel: a PAIR of
+//     sequences, one per 16-bit half of every register);
+//   * lane g of the row owns query rows [g*K, (g+1)*K) and keeps their H and E in VGPRs
+//     for the whole sequence - there is no hearray in memory (reference: qlen*32 B of
+//     H/E per thread, swipe.cc:1240);
+//   * at step t lane g computes database column t-g: the column's residue, the H of the
+//     row above and the vertical gap state F arrive from lane g-1 by `row_shr:1` DPP moves,
+//     so the anti-diagonal wavefront never leaves the register file;
+//   * substitution scores come from a per-query profile in LDS laid out
+//     [residue][8-row chunk][lane-in-row] in 16-byte units, so every ds_read_b128 of a
+//     quarter wave hits 16 distinct bank groups whatever residues the lanes hold.
+//
+// Arithmetic: the narrow kernel keeps H/E/F as packed f16 pairs.  Integers of magnitude
+// <= 2048 and their sums are exact in f16, v_pk_maximum3_f16 gives a 3-input max in one
+// instruction, and the zero floor of local alignment comes for free by keeping E >= 0.
+// A sequence whose best score reaches 2048-hi (hi = largest matrix entry) may have left the
+// exact range: it is re-queued - wave ballot + one atomic per wave - for the 32-bit kernel,
+// and from there to the 64-bit kernel at 2^31-hi.  This mirrors the reference's
+// SCORELIMIT_7 / SCORELIMIT_16 escalation (matrices.cc:574-578, swipe.cc:1464,1518); the
+// observable result - the exact score per sequence - is identical.
+//
+// gfx950 has no packed 8-bit integer VALU (only SDWA byte selects), and measured on MI355X
+// every VOP3P op issues at 4 cycles per wave64 (tools/ubench), so the narrowest useful lane
+// is 16 bit; see DESIGN.md "Lane widths".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sw_device.h"
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------ packed f16 primitives
+// hipcc lowers __builtin_elementwise_maximum on a 2 x f16 vector to v_pk_maximum3_f16 (fusing
+// nested calls and literal zero operands) without canonicalising inputs; a + b is v_pk_add_f16.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 pk_max(h2 a, h2 b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ h2 pk_max3(h2 a, h2 b, h2 c)
+{ return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
+__device__ __forceinline__ h2 as_h2(u32 v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ u32 as_u32(h2 v) { return __builtin_bit_cast(u32, v); }
+
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_SHL1 0x101
+#define DPP_ROW_SHR(n) (0x110 + (n))
+
+// value of lane-1 within the 16-lane row; lane 0 of each row receives `fill`
+__device__ __forceinline__ u32 row_shr1(u32 v, u32 fill)
+{ return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_ROW_SHR1, 0xF, 0xF, false); }
+__device__ __forceinline__ u32 row_shl1(u32 v)
+{ return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHL1, 0xF, 0xF, false); }
+
+__device__ __forceinline__ u32 float_to_half_bits(float f)
+{ _Float16 x = (_Float16)f; unsigned short s; __builtin_memcpy(&s, &x, 2); return s; }
+
+// ------------------------------------------------------------------ stream formatting
+// Builds the batch-interleaved residue stream from the raw database.  One thread per
+// (batch, chunk, lane): writes the u16 (residue of slot A | residue of slot B << 8) that the
+// quarter-wave `grp` consumes at step 16*chunk + l.  Reads of a sequence are contiguous over
+// l, writes are fully coalesced.
+extern "C" __global__ void __launch_bounds__(256)
+swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
+                  const int32_t* __restrict__ slots, const swa_batch* __restrict__ batches,
+                  int nbatches, uint16_t* __restrict__ stream, int unpack2bit)
+{
+  const int b = blockIdx.x;
+  if (b >= nbatches) return;
+  const swa_batch bd = batches[b];
+  const int32_t* sl = slots + (int64_t)b * SWA_SLOTS;
+  uint16_t* out = stream + (int64_t)bd.offset * 64;
+  const int total = bd.nchunks * 64;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int chunk = e >> 6, lane = e & 63, grp = lane >> 4, l = lane & 15;
+    const int64_t t = (int64_t)chunk * 16 + l;
+    u32 v = 0;
+    for (int h = 0; h < 2; ++h) {
+      const int32_t s = sl[grp * 2 + h];
+      u32 r = SWA_PAD;
+      if (s >= 0) {
+        const int64_t o = offsets[s], n = offsets[s + 1] - o;
+        if (t < n) r = residues[o + t];
+      }
+      v |= r << (8 * h);
+    }
+    out[e] = (uint16_t)v;
+  }
+  (void)unpack2bit;
+}
+
+// ------------------------------------------------------------------ profile tables in LDS
+// f16 table, 16-byte unit index = (d*C + c)*16 + l, unit holds rows l*K + c*8 + 0..7
+template <int K>
+__device__ __forceinline__ void build_profile_f16(unsigned char* lds, const swa_query* q)
+{
+  constexpr int C = K / 8;
+  unsigned short* t = (unsigned short*)lds;
+  const int total = 32 * C * 16 * 8;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int k = e & 7, l = (e >> 3) & 15, c = (e >> 7) % C, d = (e >> 7) / C;
+    const int row = l * K + c * 8 + k;
+    float v = -1.0f;                                   // padding rows / PAD residue: any value <= 0
+    if (row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
+    t[e] = (unsigned short)float_to_half_bits(v);
+  }
+}
+
+// ------------------------------------------------------------------ narrow kernel (f16 pairs)
+template <int K>
+__global__ void __launch_bounds__(256)
+swa_narrow_kernel(swa_narrow_params p)
+{
+  constexpr int C = K / 8;
+  constexpr u32 CS = C * 256;                            // LDS bytes per residue
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  build_profile_f16<K>(lds, p.query);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const u32 l16 = (u32)(lane & 15) * 16;
+  const h2 negQ = as_h2(p.negQ), negR = as_h2(p.negR);  // packed (-(open+ext)) and (-ext) as f16 pairs
+  const h2 zero = {0, 0};
+  const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
+
+  for (;;) {
+    int b = 0;
+    if (lane == 0) b = atomicAdd(p.counter, 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= p.nbatches) break;
+    const swa_batch bd = p.batches[b];
+    const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
+    const int nchunks = bd.nchunks;
+
+    h2 H[K], E[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { H[r] = zero; E[r] = zero; }
+    h2 S = zero, diag = zero, Fout = zero;
+    u32 cur = PADOFF;
+    u32 raw = nchunks > 0 ? (u32)s[lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
+
+    for (int m = 0; m <= nchunks; ++m) {
+      // residues of the 16 steps of this chunk, pre-scaled to LDS byte offsets
+      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
+
+#pragma unroll 2
+      for (int u = 0; u < 16; ++u) {
+        // residue shift register: lane 0 takes the next residue, the others their neighbour's
+        cur = row_shr1(cur, pl);
+        pl = row_shl1(pl);
+        const h2 hup = as_h2(row_shr1(as_u32(H[K - 1]), 0));   // H[g*K-1][j]
+        h2 F = as_h2(row_shr1(as_u32(Fout), 0));               // F entering row g*K at column j
+        h2 hd = diag;                                          // H[g*K-1][j-1]
+        diag = hup;
+
+        const u32 aoff = (cur & 0xFFFF) | l16;
+        const u32 boff = (cur >> 16) | l16;
+        uint4 pa[C], pb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          pa[c] = *(const uint4*)(lds + aoff + c * 256);
+          pb[c] = *(const uint4*)(lds + boff + c * 256);
+        }
+        h2 hprev = zero;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          const int c = r >> 3, k = r & 7;
+          const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;
+          const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;
+          const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u));
+          h2 h = pk_max3(hd + sc, E[r], F);                    // >= 0 because E >= 0
+          hd = H[r];
+          H[r] = h;
+          const h2 t = h + negQ;
+          E[r] = pk_max3(E[r] + negR, t, zero);
+          F = pk_max(F + negR, t);
+          if (r & 1) S = pk_max3(S, hprev, h); else hprev = h;
+        }
+        if (K & 1) S = pk_max(S, hprev);
+        Fout = F;
+      }
+    }
+
+    // best score of each sequence = max over the 16 lanes of its row
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(8), 0xF, 0xF, true)));
+    const bool writer = (lane & 15) == 15;
+    const int grp = lane >> 4;
+    int sA = -1, sB = -1, idA = -1, idB = -1;
+    if (writer) {
+      idA = p.slots[(int64_t)b * SWA_SLOTS + grp * 2];
+      idB = p.slots[(int64_t)b * SWA_SLOTS + grp * 2 + 1];
+      sA = (int)(float)S.x;
+      sB = (int)(float)S.y;
+      if (idA >= 0) p.scores[idA] = sA;
+      if (idB >= 0) p.scores[idB] = sB;
+    }
+    // overflow re-queue: ballot, one atomic per wave, compacted append
+    const bool oA = writer && idA >= 0 && sA >= p.limit;
+    const bool oB = writer && idB >= 0 && sB >= p.limit;
+    const u64 mA = __ballot(oA), mB = __ballot(oB);
+    const int nA = __popcll(mA), nB = __popcll(mB);
+    if (nA + nB) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(p.ovf_count, nA + nB);
+      base = __builtin_amdgcn_readfirstlane(base);
+      const u64 below = (1ull << lane) - 1;
+      if (oA) p.ovf_list[base + __popcll(mA & below)] = idA;
+      if (oB) p.ovf_list[base + nA + __popcll(mB & below)] = idB;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wide kernels (i32 / i64)
+template <typename T>
+__device__ __forceinline__ T wide_row_shr1(T v)
+{
+  if constexpr (sizeof(T) == 4) {
+    return (T)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR1, 0xF, 0xF, true);
+  } else {
+    const u64 x = (u64)v;
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, DPP_ROW_SHR1, 0xF, 0xF, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(x >> 32), DPP_ROW_SHR1, 0xF, 0xF, true);
+    return (T)(((u64)hi << 32) | lo);
+  }
+}
+template <typename T, int N>
+__device__ __forceinline__ T wide_row_shrn(T v)
+{
+  if constexpr (sizeof(T) == 4) {
+    return (T)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(N), 0xF, 0xF, true);
+  } else {
+    const u64 x = (u64)v;
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, DPP_ROW_SHR(N), 0xF, 0xF, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(x >> 32), DPP_ROW_SHR(N), 0xF, 0xF, true);
+    return (T)(((u64)hi << 32) | lo);
+  }
+}
+template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
+
+// int32 profile table, 16-byte unit index = (d*C4 + c)*16 + l, unit holds rows l*K + c*4 + 0..3
+template <int K>
+__device__ __forceinline__ void build_profile_i32(unsigned char* lds, const swa_query* q)
+{
+  constexpr int C4 = K / 4;
+  int* t = (int*)lds;
+  const int total = 32 * C4 * 16 * 4;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int k = e & 3, l = (e >> 2) & 15, c = (e >> 6) % C4, d = (e >> 6) / C4;
+    const int row = l * K + c * 4 + k;
+    int v = -1;
+    if (row < q->qlen && d != SWA_PAD) v = q->matrix[(d << 5) + q->qseq[row]];
+    t[e] = v;
+  }
+}
+
+// One sequence per 16-lane row (slot A of each group), exact in T.  Same systolic scheme.
+template <typename T, int K>
+__global__ void __launch_bounds__(256)
+swa_wide_kernel(swa_wide_params p)
+{
+  constexpr int C4 = K / 4;
+  constexpr u32 CS = C4 * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  build_profile_i32<K>(lds, p.query);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const u32 l16 = (u32)(lane & 15) * 16;
+  const T Q = (T)p.gapopenextend, R = (T)p.gapextend;
+
+  for (;;) {
+    int b = 0;
+    if (lane == 0) b = atomicAdd(p.counter, 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= p.nbatches) break;
+    const swa_batch bd = p.batches[b];
+    const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
+    const int nchunks = bd.nchunks;
+
+    T H[K], E[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { H[r] = 0; E[r] = 0; }
+    T S = 0, diag = 0, Fout = 0;
+    u32 cur = SWA_PAD * CS;
+    u32 raw = nchunks > 0 ? (u32)s[lane] : (u32)SWA_PAD;
+
+    for (int m = 0; m <= nchunks; ++m) {
+      u32 pl = (raw & 0xFF) * CS;
+      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : (u32)SWA_PAD;
+#pragma unroll 1
+      for (int u = 0; u < 16; ++u) {
+        cur = row_shr1(cur, pl);
+        pl = row_shl1(pl);
+        const T hup = wide_row_shr1<T>(H[K - 1]);
+        T F = wide_row_shr1<T>(Fout);
+        T hd = diag;
+        diag = hup;
+        const u32 aoff = cur | l16;
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+          const int4 pa = *(const int4*)(lds + aoff + c * 256);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = c * 4 + k;
+            const T sc = (T)(k == 0 ? pa.x : k == 1 ? pa.y : k == 2 ? pa.z : pa.w);
+            T h = hd + sc;
+            h = tmax(tmax(h, E[r]), F);                 // >= 0 because E >= 0
+            hd = H[r];
+            H[r] = h;
+            S = tmax(S, h);
+            const T t = h - Q;
+            E[r] = tmax(tmax(E[r] - R, t), (T)0);
+            F = tmax(F - R, t);
+          }
+        }
+        Fout = F;
+      }
+    }
+    S = tmax(S, wide_row_shrn<T, 1>(S));
+    S = tmax(S, wide_row_shrn<T, 2>(S));
+    S = tmax(S, wide_row_shrn<T, 4>(S));
+    S = tmax(S, wide_row_shrn<T, 8>(S));
+    const bool writer = (lane & 15) == 15;
+    const int grp = lane >> 4;
+    int id = -1;
+    if (writer) {
+      id = p.slots[(int64_t)b * SWA_SLOTS + grp * 2];
+      if (id >= 0) {
+        if constexpr (sizeof(T) == 4) p.scores[id] = (int)S;
+        else { p.scores64[id] = (long long)S; p.scores[id] = SWA_SCORE_IN_64; }
+      }
+    }
+    if constexpr (sizeof(T) == 4) {
+      const bool o = writer && id >= 0 && (long long)S >= p.limit;
+      const u64 mo = __ballot(o);
+      const int n = __popcll(mo);
+      if (n) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(p.ovf_count, n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (o) p.ovf_list[base + __popcll(mo & ((1ull << lane) - 1))] = id;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ hit filter
+// The hits_enter acceptance test (hits.cc:174-184) over all scores of the shard: counts
+// totalhits / obvious and compacts candidates (index, score) for the host-side top-K.
+extern "C" __global__ void __launch_bounds__(256)
+swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ scores64, int n,
+                long long minscore, long long maxscore, int* __restrict__ cand_count,
+                int cand_cap, int* __restrict__ cand_idx, long long* __restrict__ cand_score,
+                unsigned long long* __restrict__ tallies)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long total = 0, obvious = 0;
+  for (int base = blockIdx.x * blockDim.x + (int)(threadIdx.x & ~63u); base < n; base += gridDim.x * blockDim.x) {
+    const int i = base + lane;
+    long long sc = -1;
+    const bool valid = i < n;
+    if (valid) { sc = scores[i]; if (sc == SWA_SCORE_IN_64) sc = scores64[i]; }
+    const bool obv = valid && sc > maxscore;
+    const bool tot = valid && sc >= minscore;
+    const bool keep = tot && !obv;
+    obvious += obv;
+    total += tot;
+    const u64 mk = __ballot(keep);
+    const int nk = __popcll(mk);
+    if (nk) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(cand_count, nk);
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int pos = base + __popcll(mk & ((1ull << lane) - 1));
+      if (keep && pos < cand_cap) { cand_idx[pos] = i; cand_score[pos] = sc; }
+    }
+  }
+  for (int sh = 32; sh > 0; sh >>= 1) { total += __shfl_down(total, sh); obvious += __shfl_down(obvious, sh); }
+  if (lane == 0) { if (total) atomicAdd(&tallies[0], total); if (obvious) atomicAdd(&tallies[1], obvious); }
+}
+
+// ------------------------------------------------------------------ launchers
+template <int K>
+static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * (K / 8) * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(swa_narrow_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+template <typename T, int K>
+static hipError_t launch_wide(const swa_wide_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * (K / 4) * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)swa_wide_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((swa_wide_kernel<T, K>), dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+extern "C" int swa_narrow_rows_for(int qlen)
+{
+  static const int ks[] = {8, 16, 24, 32, 40, 48, 64};
+  for (int k : ks) if (qlen <= 16 * k) return k;
+  return 0;
+}
+extern "C" int swa_wide_rows_for(int qlen)
+{
+  static const int ks[] = {8, 16, 24, 32, 48, 64};
+  for (int k : ks) if (qlen <= 16 * k) return k;
+  return 0;
+}
+
+extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+  switch (K) {
+    case 8:  return launch_narrow<8>(*p, blocks, st);
+    case 16: return launch_narrow<16>(*p, blocks, st);
+    case 24: return launch_narrow<24>(*p, blocks, st);
+    case 32: return launch_narrow<32>(*p, blocks, st);
+    case 40: return launch_narrow<40>(*p, blocks, st);
+    case 48: return launch_narrow<48>(*p, blocks, st);
+    case 64: return launch_narrow<64>(*p, blocks, st);
+  }
+  return hipErrorInvalidValue;
+}
+extern "C" hipError_t swa_launch_wide(int K, int bits, const swa_wide_params* p, int blocks, hipStream_t st)
+{
+  if (bits == 32) switch (K) {
+    case 8:  return launch_wide<int, 8>(*p, blocks, st);
+    case 16: return launch_wide<int, 16>(*p, blocks, st);
+    case 24: return launch_wide<int, 24>(*p, blocks, st);
+    case 32: return launch_wide<int, 32>(*p, blocks, st);
+    case 48: return launch_wide<int, 48>(*p, blocks, st);
+    case 64: return launch_wide<int, 64>(*p, blocks, st);
+  } else switch (K) {
+    case 8:  return launch_wide<long long, 8>(*p, blocks, st);
+    case 16: return launch_wide<long long, 16>(*p, blocks, st);
+    case 24: return launch_wide<long long, 24>(*p, blocks, st);
+    case 32: return launch_wide<long long, 32>(*p, blocks, st);
+    case 48: return launch_wide<long long, 48>(*p, blocks, st);
+    case 64: return launch_wide<long long, 64>(*p, blocks, st);
+  }
+  return hipErrorInvalidValue;
+}
+extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
+                                        const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st)
+{
+  if (nbatches <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, long long minscore,
+                                        long long maxscore, int* cand_count, int cand_cap, int* cand_idx,
+                                        long long* cand_score, unsigned long long* tallies, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(swa_filter_hits, dim3(blocks), dim3(256), 0, st, scores, scores64, n, minscore, maxscore,
+                     cand_count, cand_cap, cand_idx, cand_score, tallies);
+  return hipGetLastError();
+}
