@@ -17,7 +17,6 @@
      hits_enter loop + top-K list (hits.cc:163-222)     swa_search_topk / swa_hits_*
      hits_init thresholds, E-values (hits.cc:283-511,
                         1777-1779; stats.cc)            swa_stats_init / swa_evalue / swa_bits
-     search16s end points (swipe.h:237-249)             swa_search_endpoints
 
    Conventions: plain pointers and sizes, caller owns every buffer, the callee keeps no host
    pointer past return.  Every function returns SWA_OK (0) or a negative SWA_E* code; the
@@ -83,6 +82,14 @@ int swa_db_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t 
                        int symtype, int device, int64_t first_seqno,
                        int64_t total_seqcount, int64_t total_symcount, swa_db** out);
 int swa_db_info(const swa_db* db, swa_db_info_t* info);
+/* Host-only: read sequences [first_seqno, last_seqno] of a BLAST v4 database into malloc'ed
+   arrays in reference symbol codes (what db_getsequence returns, database.cc:1237-1401:
+   protein = NCBIstdaa bytes; nucleotide = 4-bit base masks with ambiguities applied).
+   Release both arrays with swa_free.  Needs no GPU. */
+int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
+                     uint8_t** residues, int64_t** offsets, int64_t* nseq,
+                     int64_t* total_seqcount, int64_t* total_symcount, int64_t* longest);
+void swa_free(void* p);
 void swa_db_close(swa_db* db);
 
 /* ---- scoring ------------------------------------------------------------------------------ */

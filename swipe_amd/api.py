@@ -163,6 +163,22 @@ class Database:
             pass
 
 
+def read_blastdb(basename: str, *, symtype: int = 1, first_seqno: int = 0, last_seqno: int = -1):
+    """(residues, offsets, info) of a BLAST v4 database through the C++ loader (host only)."""
+    L = _lib.load()
+    r, o = C.c_void_p(), C.c_void_p()
+    n, ts, ty, lg = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    _check(L.swa_blastdb_read(os.fsencode(basename), symtype, first_seqno, last_seqno, C.byref(r), C.byref(o),
+                              C.byref(n), C.byref(ts), C.byref(ty), C.byref(lg)))
+    try:
+        off = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_int64)), shape=(n.value + 1,)).copy()
+        res = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint8)), shape=(max(int(off[-1]), 1),))[: int(off[-1])].copy()
+    finally:
+        L.swa_free(r)
+        L.swa_free(o)
+    return res, off, {"total_seqcount": ts.value, "total_symcount": ty.value, "longest": lg.value}
+
+
 def synth_db(seed: int, nseq: int, *, first: int = 0, query: Optional[np.ndarray] = None, protein: bool = True,
              threads: int = 0):
     """(residues uint8, offsets int64) of synthetic sequences [first, first+nseq) - C++ generator."""

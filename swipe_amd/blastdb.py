@@ -192,6 +192,35 @@ def write_volume(basename: str, seqs: Sequence[np.ndarray], *, protein: bool = T
         f.write(bytes(hdr))
 
 
+def write_protein_volume_arrays(basename: str, residues: np.ndarray, offsets: np.ndarray, *,
+                                title: str = "swipe_amd synthetic", first_id: int = 0) -> None:
+    """Vectorised protein volume writer from (residues, offsets) arrays (large sample databases)."""
+    residues = np.asarray(residues, dtype=np.uint8)
+    off = np.asarray(offsets, dtype=np.int64) - int(offsets[0])
+    n = len(off) - 1
+    lens = np.diff(off)
+    total = int(off[-1])
+    if total + n + 1 >= (1 << 32):
+        raise ValueError("volume exceeds the 4 GiB u32 offset limit of the v4 format")
+    sq = np.zeros(total + n + 1, dtype=np.uint8)
+    pos = np.arange(total, dtype=np.int64) + np.repeat(np.arange(n, dtype=np.int64), lens) + 1
+    sq[pos] = residues[int(offsets[0]): int(offsets[0]) + total]
+    seq_off = off + np.arange(n + 1, dtype=np.int64) + 1
+    hdrs = [ber_defline(f"s{first_id + i}", f"seq{first_id + i}") for i in range(n)]
+    hdr_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.fromiter((len(h) for h in hdrs), dtype=np.int64, count=n), out=hdr_off[1:])
+    t, d = title.encode(), b"Jan 1, 2026  0:00 AM"
+    pin = struct.pack(">II", 4, 1) + struct.pack(">I", len(t)) + t + struct.pack(">I", len(d)) + d
+    pin += b"\x00" * ((-len(pin)) % 4)
+    pin += struct.pack(">I", n) + struct.pack("<Q", total) + struct.pack(">I", int(lens.max()) if n else 0)
+    pin += hdr_off.astype(">u4").tobytes() + seq_off.astype(">u4").tobytes()
+    with open(basename + ".pin", "wb") as f:
+        f.write(pin)
+    sq.tofile(basename + ".psq")
+    with open(basename + ".phr", "wb") as f:
+        f.write(b"".join(hdrs))
+
+
 def write_alias(basename: str, volume_basenames: Iterable[str], *, protein: bool = True,
                 title: str = "swipe_amd synthetic") -> None:
     """``.pal``/``.nal`` alias listing volumes by file name relative to the alias' directory."""

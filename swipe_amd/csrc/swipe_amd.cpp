@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -410,6 +411,28 @@ extern "C" int swa_db_open(const char* basename, int symtype, int device, int64_
   return swa_db_from_memory(h.residues.data(), h.offsets.data(), int64_t(h.offsets.size()) - 1, symtype, device,
                             h.first_seqno, h.total_seqcount, h.total_symcount, out);
 }
+
+extern "C" int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
+                                uint8_t** residues, int64_t** offsets, int64_t* nseq, int64_t* total_seqcount,
+                                int64_t* total_symcount, int64_t* longest)
+{
+  if (!residues || !offsets || !nseq) return fail(SWA_EINVAL, "null output");
+  swa::HostDb h;
+  const int rc = swa::read_blast_db(basename, symtype, first_seqno, last_seqno, h);
+  if (rc != SWA_OK) return rc;
+  *nseq = int64_t(h.offsets.size()) - 1;
+  *residues = static_cast<uint8_t*>(std::malloc(h.residues.size() ? h.residues.size() : 1));
+  *offsets = static_cast<int64_t*>(std::malloc(h.offsets.size() * sizeof(int64_t)));
+  if (!*residues || !*offsets) { std::free(*residues); std::free(*offsets); return fail(SWA_ENOMEM, "out of host memory"); }
+  if (!h.residues.empty()) std::memcpy(*residues, h.residues.data(), h.residues.size());
+  std::memcpy(*offsets, h.offsets.data(), h.offsets.size() * sizeof(int64_t));
+  if (total_seqcount) *total_seqcount = h.total_seqcount;
+  if (total_symcount) *total_symcount = h.total_symcount;
+  if (longest) *longest = h.longest;
+  return SWA_OK;
+}
+
+extern "C" void swa_free(void* p) { std::free(p); }
 
 extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
 {

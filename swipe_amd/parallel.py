@@ -1,0 +1,63 @@
+"""Multi-GPU search: one process per GPU, the database sharded read-only by residue count.
+
+The reference's only distributed exchange that matters is tag_search_report: each MPI worker
+sends its top-K hit tuples to the master, which re-enters them through hits_enter
+(swipe.cc:1951-1974, 2320).  Here every rank keeps a contiguous seqno range balanced by
+RESIDUES, searches it on its own GPU with no data-path collective, and the
+per-rank top-K lists are exchanged by ONE all_gather of K x 2 int64 (plus 3 counters) - over
+RCCL/xGMI when the tensors live on the GPU ("nccl" backend), over gloo in the CPU tests.  The
+merged list equals the single-list result because the reference's list is exactly the global
+top-K under the total order (score desc, seqno desc) (hits.cc:188-219).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from .api import merge_hits
+
+
+def shard_bounds(offsets: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous [first, last) sequence ranges with near-equal residue counts.
+
+    offsets: int64 [nseq+1] prefix sums of sequence lengths (offsets[0] may be non-zero)."""
+    off = np.asarray(offsets, dtype=np.int64)
+    nseq = len(off) - 1
+    total = int(off[-1] - off[0])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = off[0] + total * r // world_size
+        c = int(np.searchsorted(off, target, side="left"))
+        cuts.append(min(max(c, cuts[-1]), nseq))
+    cuts.append(nseq)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def gather_topk(local_hits: Sequence[Tuple[int, int]], keep: int, totalhits: int = 0, obvious: int = 0,
+                group=None, device=None):
+    """all_gather the per-rank ordered hit lists and merge them with the reference comparator.
+
+    Returns (hits, totalhits_sum, obvious_sum) - identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    buf = torch.zeros(keep * 2 + 3, dtype=torch.int64)
+    n = min(len(local_hits), keep)
+    if n:
+        buf[: 2 * n] = torch.tensor([v for h in local_hits[:n] for v in h], dtype=torch.int64)
+    buf[2 * keep] = n
+    buf[2 * keep + 1] = totalhits
+    buf[2 * keep + 2] = obvious
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    lists, tot, obv = [], 0, 0
+    for t in out:
+        t = t.cpu()
+        k = int(t[2 * keep])
+        lists.append([(int(t[2 * i]), int(t[2 * i + 1])) for i in range(k)])
+        tot += int(t[2 * keep + 1])
+        obv += int(t[2 * keep + 2])
+    return merge_hits(lists, keep), tot, obv

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by running the COMPILED REFERENCE (oracle/_ref/swipe and
+oracle/_ref/ref_harness, built from /root/reference by oracle/Makefile) on the cases of
+tests/cases.py.  Build-container only.  What is stored is data: per-sequence raw kernel outputs
+(7-bit SSSE3 / 7-bit SSE2 / 16-bit + bestpos / 63-bit) and the reference CLI's ranked hit list
+with its printed E-values and bit scores, for 1 and 8 threads."""
+import json, os, re, subprocess, sys, tempfile
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+import numpy as np
+import cases
+from swipe_amd import blastdb
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+def fasta(path, case):
+    alpha = blastdb.NCBISTDAA if case.protein else blastdb.NCBI4NA
+    with open(path, "w") as f:
+        f.write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+
+def run(case):
+    d = tempfile.mkdtemp(prefix="golden_")
+    base = os.path.join(d, case.name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    qf = os.path.join(d, "q.fa")
+    fasta(qf, case)
+    mat = case.matrix
+    if case.matrix == "@text":
+        mat = os.path.join(d, "matrix.txt")
+        open(mat, "w").write(case.matrix_text)
+    sym = "1" if case.protein else "0"
+    h = subprocess.run([os.path.join(REF, "ref_harness"), base, qf, sym, mat if case.protein else "-",
+                        str(case.gapopen), str(case.gapextend), str(case.match), str(case.mismatch)],
+                       capture_output=True, text=True, check=True)
+    lines = h.stdout.splitlines()
+    m = re.match(r"# SCORELIMIT_7=(-?\d+) SCORELIMIT_16=(-?\d+)", lines[0])
+    raw = [list(map(int, l.split())) for l in lines[1:]]
+    out = {"name": case.name, "checksum": case.checksum(), "nseq": len(case.seqs),
+           "scorelimit7": int(m.group(1)), "scorelimit16": int(m.group(2)),
+           "raw_columns": ["seqno", "strand", "len", "s7_ssse3", "s7_sse2", "s16", "bestpos16", "s63"],
+           "raw": raw, "cli": {}}
+    common = [os.path.join(REF, "swipe"), "-d", base, "-i", qf, "-p", sym, "-G", str(case.gapopen), "-E", str(case.gapextend),
+              "-v", str(case.keep), "-e", "10"]
+    if case.protein:
+        common += ["-M", mat]
+    else:
+        common += ["-r", str(case.match), "-q", str(case.mismatch)]
+    for threads in (1, 8):
+        x = subprocess.run(common + ["-a", str(threads), "-m", "7", "-b", "0"], capture_output=True, text=True, check=True)
+        tracks = list(map(int, re.findall(r"<track>(\d+)</track>", x.stdout)))
+        scores = list(map(int, re.findall(r"<score>(-?\d+)</score>", x.stdout)))
+        t = subprocess.run(common + ["-a", str(threads), "-m", "8", "-b", str(case.keep)], capture_output=True, text=True, check=True)
+        ev, bits = [], []
+        for l in t.stdout.splitlines():
+            f = l.split("\t")
+            if len(f) >= 12:
+                ev.append(f[10]); bits.append(f[11])
+            elif len(f) == 11:
+                ev.append(None); bits.append(f[10])
+        p = subprocess.run(common + ["-a", str(threads), "-m", "0", "-b", "0"], capture_output=True, text=True, check=True)
+        strands = re.findall(r"^lcl\|\S+.*? ([+-]) +\d+ +\S+\s*$", p.stdout, re.M) if not case.protein else []
+        out["cli"][str(threads)] = {"seqno": tracks, "score": scores, "evalue": ev, "bits": bits, "strand": strands}
+    return out
+
+def main():
+    names = sys.argv[1:] or [f.__name__[5:] for f in cases.ALL]
+    for n in names:
+        c = cases.get(n)
+        g = run(c)
+        with open(os.path.join(HERE, n + ".json"), "w") as f:
+            json.dump(g, f, separators=(",", ":"))
+        a, b = g["cli"]["1"], g["cli"]["8"]
+        print(n, "nseq", g["nseq"], "limits", g["scorelimit7"], g["scorelimit16"], "hits", len(a["seqno"]),
+              "threads-identical", a == b, "max s63", max(r[7] for r in g["raw"]),
+              ">=lim7", sum(r[3] >= g["scorelimit7"] for r in g["raw"]), ">=lim16", sum(r[5] >= g["scorelimit16"] for r in g["raw"]))
+
+if __name__ == "__main__":
+    main()

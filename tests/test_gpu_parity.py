@@ -1,0 +1,216 @@
+"""GPU (-m gpu): the HIP path through the C ABI against (a) the committed reference outputs,
+(b) the oracle on the same seeded inputs, (c) size-independent properties at larger sizes.
+Integer scores: the bar is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import swipe_amd
+from conftest import case_matrix, load_golden
+from swipe_amd import blastdb, synth
+
+pytestmark = pytest.mark.gpu
+NAMES = [f.__name__[5:] for f in cases.ALL]
+THREADS = os.cpu_count() or 1
+
+
+def strands(case):
+    return [case.query] if case.protein else [case.query, blastdb.revcomp_nt16(case.query)]
+
+
+def open_case(case):
+    db = swipe_amd.Database.from_sequences(case.seqs, symtype=1 if case.protein else 0)
+    db.set_scoring(case_matrix(case, swipe_amd), case.gapopen, case.gapextend)
+    return db
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_scores_equal_reference_for_every_sequence(name):
+    case, g = cases.get(name), load_golden(name)
+    db = open_case(case)
+    for strand, q in enumerate(strands(case)):
+        scores, c = db.search(q)
+        want = [r[7] for r in g["raw"] if r[1] == strand]
+        assert list(scores) == want
+        assert c["narrow"] + (c["wide"] if c["narrow"] == 0 else 0) == len(case.seqs)
+    db.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_hit_list_equals_reference_cli(name):
+    """ranks, scores, E-value and bit-score strings of `swipe -m 8/-m 7` (1 and 8 threads agree)."""
+    case, g = cases.get(name), load_golden(name)
+    cli = g["cli"]["1"]
+    nsym = int(sum(len(s) for s in case.seqs))
+    st = swipe_amd.stats_init(symtype=1 if case.protein else 0, matrix=case.matrix, match=case.match,
+                              mismatch=case.mismatch, gapopen=case.gapopen, gapextend=case.gapextend,
+                              qlen=len(case.query), db_seqcount=len(case.seqs), db_symcount=nsym)
+    db = open_case(case)
+    entries = []
+    total = 0
+    for strand, q in enumerate(strands(case)):
+        hits, tot, obv, _ = db.search_topk(q, keep=case.keep, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
+        total += tot
+        entries += [(seqno, score, strand) for seqno, score in hits]
+    entries.sort(key=lambda e: (-e[1], -e[0]))        # stable: plus-strand entries were entered first
+    entries = entries[:case.keep]
+    assert [e[0] for e in entries] == cli["seqno"]
+    assert [e[1] for e in entries] == cli["score"]
+    if st.available:
+        assert ["%.2g" % st.evalue(e[1]) for e in entries] == cli["evalue"]
+        assert ["%.1f" % st.bits(e[1]) for e in entries] == cli["bits"]
+    if cli["strand"]:
+        assert ["-" if e[2] else "+" for e in entries] == cli["strand"]
+    assert total == sum(r[7] >= st.scorethreshold for r in g["raw"])
+    db.close()
+
+
+def test_open_blast_volumes_and_shard_ranges(tmp_path):
+    case, g = cases.get("multivol"), load_golden("multivol")
+    base = str(tmp_path / "mv")
+    blastdb.write_db(base, case.seqs, protein=True, volumes=case.volumes)
+    want = [r[7] for r in g["raw"]]
+    db = swipe_amd.Database.open(base)
+    info = db.info()
+    assert info["seqcount"] == 400 and info["total_seqcount"] == 400
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    assert list(db.search(case.query)[0]) == want
+    db.close()
+    # a shard that straddles two volumes keeps global sequence numbers
+    sh = swipe_amd.Database.open(base, first_seqno=100, last_seqno=299)
+    assert sh.info()["first_seqno"] == 100 and sh.info()["seqcount"] == 200 and sh.info()["total_seqcount"] == 400
+    sh.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    assert list(sh.search(case.query)[0]) == want[100:300]
+    hits, tot, obv, _ = sh.search_topk(case.query, keep=5, minscore=1)
+    best = sorted(((s, i) for i, s in enumerate(want) if 100 <= i < 300), key=lambda t: (-t[0], -t[1]))[:5]
+    assert hits == [(i, s) for s, i in best]
+    sh.close()
+
+
+def test_width_escalation_16_to_32_to_64():
+    """Scores past the f16-exact range are re-queued to the 32-bit kernel, past 2^31 to the 64-bit one."""
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(12345, 1, 700, rtab)
+    mut = q.copy()
+    mut[::9] = rtab[(np.arange(len(mut[::9])) * 131) % 4096]
+    seqs = [synth._random_residues(777 + k, 1, 200 + 13 * k, rtab) for k in range(40)]
+    seqs += [q, mut, q[:450], np.concatenate([seqs[0], q, seqs[1]]), q[100:]]
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    db = swipe_amd.Database.from_sequences(seqs)
+    db.set_scoring(M, 11, 1)
+    scores, c = db.search(q)
+    res, off = oracle.pack(seqs)
+    want = oracle.search_all63(res, off, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS)
+    assert np.array_equal(scores, want)
+    assert c["narrow"] == len(seqs) and c["wide"] == int((want >= 2048 - 11).sum()) > 0 and c["full"] == 0
+    db.close()
+    # 64-bit: a matrix with 10^7 on the diagonal pushes a 300-residue self hit past 2^31
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    text = "   " + "  ".join(letters) + "\n" + "\n".join(
+        a + " " + " ".join("10000000" if a == b else "-3000000" for b in letters) for a in letters) + "\n"
+    q2 = q[:300]
+    seqs2 = [q2, q2[:200], q2[:250], mut[:300], seqs[3], seqs[4]]
+    db = swipe_amd.Database.from_sequences(seqs2)
+    db.set_scoring(swipe_amd.matrix_parse(text), 200, 50)
+    scores, c = db.search(q2)
+    res, off = oracle.pack(seqs2)
+    want = oracle.search_all63(res, off, q2, oracle.matrix_parse(text), 250, 50)
+    assert np.array_equal(scores, want) and want.max() == 3_000_000_000
+    assert c["narrow"] == 0 and c["wide"] == len(seqs2) and c["full"] == int((want >= 2**31 - 10_000_000).sum()) > 0
+    hits, _, _, _ = db.search_topk(q2, keep=3, minscore=1)
+    assert hits[0] == (0, 3_000_000_000)
+    db.close()
+
+
+@pytest.mark.parametrize("qlen", [1, 2, 15, 16, 17, 127, 128, 129, 255, 375, 384, 385, 511, 640, 767, 1000, 1024])
+def test_every_rows_per_lane_variant(qlen):
+    """query lengths around every 16*K boundary of the kernel templates"""
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(4242 + qlen, 1, qlen, rtab)
+    res, off = swipe_amd.synth_db(5, 600, query=q)
+    extra = [q, q[: max(1, qlen // 2)], np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack([res[off[i]:off[i + 1]] for i in range(600)] + extra)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    scores, _ = db.search(q)
+    want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS)
+    assert np.array_equal(scores, want)
+    db.close()
+
+
+def test_empty_inputs_and_errors():
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    db = swipe_amd.Database.from_sequences([cases.Q375, np.zeros(0, np.uint8)])
+    with pytest.raises(swipe_amd.SwaError) as e:
+        db.search(cases.Q375)
+    assert "swa_set_scoring" in str(e.value)
+    db.set_scoring(M, 11, 1)
+    assert list(db.search(np.zeros(0, np.uint8))[0]) == [0, 0]
+    assert list(db.search(cases.Q375)[0]) == [1957, 0]
+    with pytest.raises(swipe_amd.SwaError):
+        db.search(np.full(5, 40, np.uint8))
+    with pytest.raises(swipe_amd.SwaError):
+        db.search(np.ones(1025, np.uint8))
+    db.close()
+    empty = swipe_amd.Database.from_sequences([])
+    empty.set_scoring(M, 11, 1)
+    assert len(empty.search(cases.Q375)[0]) == 0
+    assert empty.search_topk(cases.Q375, keep=5)[0] == []
+    empty.close()
+
+
+def test_properties_at_scale():
+    """300 k sequences / ~10^8 residues: sample vs oracle, idempotence, shard == slice, permutation
+    invariance, planted self copy, score bounds."""
+    q = cases.Q375
+    n = 300_000
+    res, off = swipe_amd.synth_db(1, n, query=q)
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(M, 11, 1)
+    s1, c1 = db.search(q)
+    s2, _ = db.search(q)
+    assert np.array_equal(s1, s2)                                     # idempotent
+    assert s1.min() >= 0 and (s1 <= 11 * np.minimum(375, np.diff(off))).all()
+    rng = np.random.default_rng(7)
+    pick = np.unique(np.concatenate([rng.integers(0, n, 3000), np.argsort(s1)[-200:], np.argsort(np.diff(off))[-50:]]))
+    r2, o2 = oracle.pack([res[off[i]:off[i + 1]] for i in pick])
+    want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS)
+    assert np.array_equal(s1[pick], want)
+    lo, hi = 100_000, 180_000                                           # a shard is a slice
+    sh = swipe_amd.Database.from_arrays(res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], first_seqno=lo)
+    sh.set_scoring(M, 11, 1)
+    assert np.array_equal(sh.search(q)[0], s1[lo:hi])
+    hits_sh = sh.search_topk(q, keep=50, minscore=45)[0]
+    sh.close()
+    order = sorted(((int(s1[i]), i) for i in range(lo, hi) if s1[i] >= 45), key=lambda t: (-t[0], -t[1]))[:50]
+    assert hits_sh == [(i, s) for s, i in order]
+    perm = rng.permutation(20_000)                                      # order of the database is irrelevant
+    seqs = [res[off[i]:off[i + 1]] for i in perm]
+    pd = swipe_amd.Database.from_sequences(seqs)
+    pd.set_scoring(M, 11, 1)
+    assert np.array_equal(pd.search(q)[0], s1[perm])
+    pd.close()
+    hits, tot, obv, _ = db.search_topk(q, keep=250, minscore=50)
+    order = sorted(((int(s), i) for i, s in enumerate(s1) if s >= 50), key=lambda t: (-t[0], -t[1]))
+    assert hits == [(i, s) for s, i in order[:250]] and tot == len(order) and obv == 0
+    db.close()
+
+
+def test_nucleotide_scale_both_strands():
+    rtab = synth.residue_table_nucleotide()
+    q = synth._random_residues(99, 1, 1000, rtab)
+    res, off = swipe_amd.synth_db(3, 20_000, protein=False)
+    seqs = [res[off[i]:off[i + 1]] for i in range(20_000)] + [q[200:800], blastdb.revcomp_nt16(q[100:900])]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2, symtype=0)
+    db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+    Mo = oracle.matrix_nucleotide(1, -3)
+    for qs in (q, blastdb.revcomp_nt16(q)):
+        scores, _ = db.search(qs)
+        want = oracle.search_all63(r2, o2, qs, Mo, 7, 2, threads=THREADS)
+        assert np.array_equal(scores, want)
+    db.close()

@@ -1,0 +1,167 @@
+"""CPU: host logic of the product (no GPU compute): the C-ABI library loads and exports every
+symbol include/*.h declares; BLAST v4 writer/reader; statistics and matrices bit-identical to
+the oracle; synthetic generator C++ == numpy; hit merge; shard bounds."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import swipe_amd
+from conftest import ROOT, case_matrix
+from swipe_amd import _lib, blastdb, parallel, synth
+
+
+def declared_symbols():
+    names = set()
+    for h in ("swipe_amd.h", "swipe_amd_synth.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(swa_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    decl = declared_symbols()
+    assert decl, "no declarations parsed"
+    for name in sorted(decl):
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+    assert decl == set(_lib.EXPORTS)
+
+
+def test_no_cpu_fallback_without_device():
+    """Compute entry points must fail loudly (not fall back) when no HIP device is usable."""
+    L = _lib.load()
+    if L.swa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    res, off = oracle.pack([cases.Q375])
+    with pytest.raises(swipe_amd.SwaError) as e:
+        swipe_amd.Database.from_arrays(res, off)
+    assert "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["p1k", "nt", "multivol", "edges"])
+def test_blastdb_roundtrip_python_and_cpp(tmp_path, name):
+    case = cases.get(name)
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    vols = blastdb.read_db(base, case.protein)
+    got = [v.sequence(s) for v in vols for s in range(v.nseq)]
+    assert len(got) == len(case.seqs)
+    for a, b in zip(got, case.seqs):
+        assert np.array_equal(a, b)
+    res, off, info = swipe_amd.read_blastdb(base, symtype=1 if case.protein else 0)
+    r2, o2 = oracle.pack(case.seqs)
+    assert np.array_equal(off, o2) and np.array_equal(res, r2)
+    assert info["total_seqcount"] == len(case.seqs) and info["total_symcount"] == int(o2[-1])
+    assert info["longest"] == max(len(s) for s in case.seqs)
+    # a sub-range, as one shard would load it
+    lo, hi = 3, min(40, len(case.seqs) - 1)
+    res, off, _ = swipe_amd.read_blastdb(base, symtype=1 if case.protein else 0, first_seqno=lo, last_seqno=hi)
+    r3, o3 = oracle.pack(case.seqs[lo:hi + 1])
+    assert np.array_equal(off, o3) and np.array_equal(res, r3)
+
+
+def test_blastdb_errors(tmp_path):
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.read_blastdb(str(tmp_path / "missing"))
+    base = str(tmp_path / "bad")
+    blastdb.write_db(base, [cases.Q375], protein=True)
+    raw = bytearray(open(base + ".pin", "rb").read())
+    raw[3] = 5
+    open(base + ".pin", "wb").write(raw)
+    with pytest.raises(swipe_amd.SwaError) as e:
+        swipe_amd.read_blastdb(base)
+    assert "version" in str(e.value)
+
+
+def test_matrices_identical_to_oracle():
+    for n in ["blosum45", "blosum50", "BLOSUM62", "blosum80", "blosum90", "pam30", "pam70", "pam250"]:
+        assert np.array_equal(swipe_amd.matrix_builtin(n), oracle.matrix_builtin(n))
+    assert np.array_equal(swipe_amd.matrix_nucleotide(2, -5), oracle.matrix_nucleotide(2, -5))
+    for t in (cases.ASYM_MATRIX, cases.BIG_MATRIX):
+        assert np.array_equal(swipe_amd.matrix_parse(t), oracle.matrix_parse(t))
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.matrix_builtin("nosuch")
+
+
+def _bits(x):
+    return np.float64(x).view(np.uint64)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(symtype=1, matrix="BLOSUM62", gapopen=11, gapextend=1, qlen=375, db_seqcount=1013, db_symcount=340000),
+    dict(symtype=1, matrix="BLOSUM62", gapopen=11, gapextend=1, qlen=375, db_seqcount=10_000_000, db_symcount=3_250_000_000),
+    dict(symtype=1, matrix="BLOSUM50", gapopen=13, gapextend=2, qlen=29, db_seqcount=77, db_symcount=9000),
+    dict(symtype=1, matrix="PAM250", gapopen=14, gapextend=2, qlen=1000, db_seqcount=5, db_symcount=700, effdbsize=123456),
+    dict(symtype=0, match=1, mismatch=-3, gapopen=5, gapextend=2, qlen=1000, db_seqcount=310, db_symcount=100000),
+    dict(symtype=0, match=2, mismatch=-3, gapopen=5, gapextend=2, qlen=200, db_seqcount=50_000_000, db_symcount=15_000_000_000),
+    dict(symtype=1, matrix="BLOSUM62", gapopen=3, gapextend=3, qlen=100, db_seqcount=10, db_symcount=1000),
+])
+def test_statistics_bitwise_equal_to_oracle(kw):
+    st = swipe_amd.stats_init(expect=10.0, minexpect=1e-250, **kw)
+    h = oracle.HitList(symtype=kw["symtype"], matrix=kw.get("matrix", "BLOSUM62"), match=kw.get("match", 1),
+                       mismatch=kw.get("mismatch", -3), gapopen=kw["gapopen"], gapextend=kw["gapextend"],
+                       qlen=kw["qlen"], dbseqs=kw["db_seqcount"], dbsyms=kw["db_symcount"],
+                       effdbsize=kw.get("effdbsize", 0), expect=10.0, minexpect=1e-250).c
+    assert st.available == h.stats_available
+    if not st.available:
+        return
+    assert (st.lenadj, st.m, st.n) == (h.lenadj, h.m, h.n)
+    assert (st.scorethreshold, st.upperscorethreshold) == (h.scorethreshold, h.upperscorethreshold)
+    for a, b in [(st.Kmn, h.Kmn), (st.logK, h.logK), (st.lambda_d_log2, h.lambda_d_log2), (st.logK_d_log2, h.logK_d_log2)]:
+        assert _bits(a) == _bits(b)
+    hl = oracle.HitList(symtype=kw["symtype"], matrix=kw.get("matrix", "BLOSUM62"), match=kw.get("match", 1),
+                        mismatch=kw.get("mismatch", -3), gapopen=kw["gapopen"], gapextend=kw["gapextend"],
+                        qlen=kw["qlen"], dbseqs=kw["db_seqcount"], dbsyms=kw["db_symcount"],
+                        effdbsize=kw.get("effdbsize", 0))
+    for s in (1, 37, 50, 117, 1957, 65525):
+        assert _bits(st.evalue(s)) == _bits(hl.expect(s))
+        assert _bits(st.bits(s)) == _bits(hl.bits(s))
+
+
+def test_default_gaps():
+    for m in ["BLOSUM45", "BLOSUM50", "BLOSUM62", "BLOSUM80", "BLOSUM90", "PAM30", "PAM70", "PAM250"]:
+        assert swipe_amd.default_gaps(m) == oracle.default_gaps(m)
+
+
+def test_synth_cpp_equals_numpy():
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(1, 3000, query=q, threads=3)
+    ltab, rtab = synth.length_table(), synth.residue_table_protein()
+    for s in list(range(0, 3000, 97)) + [2999]:
+        assert np.array_equal(res[off[s]:off[s + 1]], synth.make_sequence(1, s, ltab, rtab, q))
+    for s in cases.PLANTED_IN_100K[:4]:            # planted homologs take the mutation path
+        r1, o1 = swipe_amd.synth_db(1, 1, first=s, query=q)
+        assert np.array_equal(r1, synth.make_sequence(1, s, ltab, rtab, q))
+    rn, on = swipe_amd.synth_db(2, 50, protein=False)
+    assert set(np.unique(rn)) <= {1, 2, 4, 8}
+    # shards concatenate to the whole
+    ra, oa = swipe_amd.synth_db(1, 1000, first=500, query=q)
+    assert np.array_equal(ra, res[off[500]:off[1500]])
+
+
+def test_merge_hits_is_the_reference_order():
+    a = [(9, 100), (3, 100), (5, 50)]
+    b = [(7, 100), (8, 60), (1, 50)]
+    assert swipe_amd.merge_hits([a, b], 4) == [(9, 100), (7, 100), (3, 100), (8, 60)]
+    h = oracle.HitList(descriptions=4, alignments=0, dbseqs=100, dbsyms=10000, qlen=10, expect=1e30)
+    for s, sc in b + a:
+        h.enter(s, sc)
+    assert [(x[0], x[1]) for x in h.hits()] == swipe_amd.merge_hits([a, b], 4)
+    assert swipe_amd.merge_hits([[], []], 5) == []
+
+
+def test_shard_bounds_balance_residues():
+    res, off = swipe_amd.synth_db(1, 5000)
+    for w in (1, 2, 3, 8):
+        b = parallel.shard_bounds(off, w)
+        assert b[0][0] == 0 and b[-1][1] == 5000
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [int(off[hi] - off[lo]) for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 2 * 35000
+    assert parallel.shard_bounds(np.zeros(1, np.int64), 4) == [(0, 0)] * 4

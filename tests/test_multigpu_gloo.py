@@ -1,0 +1,74 @@
+"""CPU, world_size 2 over gloo: the N>1 path - shard by residues, per-rank top-K, ONE all_gather,
+merge with the reference comparator - equals the single-list result.  Per-rank scores come from
+the oracle here (no GPU in this container); on the GPU box the same code path runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import cases
+import oracle
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, keep, q_out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import swipe_amd
+    from swipe_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q = cases.Q375
+        res, off = swipe_amd.synth_db(1, 3000, query=q)
+        seqs = [res[off[i]:off[i + 1]] for i in range(3000)] + cases.case_p1k().seqs[1000:]
+        r2, o2 = oracle.pack(seqs)
+        lo, hi = parallel.shard_bounds(o2, world)[rank]
+        M = oracle.matrix_builtin("BLOSUM62")
+        local = oracle.search_all63(r2[o2[lo]:o2[hi]], o2[lo:hi + 1] - o2[lo], q, M, 12, 1)
+        minscore = 40
+        mine = sorted(((int(s), lo + i) for i, s in enumerate(local) if s >= minscore), key=lambda t: (-t[0], -t[1]))[:keep]
+        hits, tot, obv = parallel.gather_topk([(i, s) for s, i in mine], keep, totalhits=int((local >= minscore).sum()))
+        if rank == 0:
+            q_out.put((hits, tot, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("keep", [5, 250])
+def test_sharded_topk_equals_single_list(keep):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, keep, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    hits, tot, bounds = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import swipe_amd
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(1, 3000, query=q)
+    seqs = [res[off[i]:off[i + 1]] for i in range(3000)] + cases.case_p1k().seqs[1000:]
+    r2, o2 = oracle.pack(seqs)
+    full = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=2)
+    h = oracle.HitList(descriptions=keep, alignments=0, minscore=40, expect=1e30, dbseqs=len(seqs), dbsyms=int(o2[-1]), qlen=375)
+    for i, s in enumerate(full):
+        h.enter(i, int(s))
+    assert hits == [(x[0], x[1]) for x in h.hits()]
+    assert tot == int((full >= 40).sum())
+    assert 0 < bounds[1] < len(seqs)

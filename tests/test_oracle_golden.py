@@ -1,0 +1,102 @@
+"""CPU: the oracle (oracle/sw_oracle.c) against the committed outputs of the compiled reference
+(tests/golden/*.json, produced by tests/golden/make_golden.py from oracle/_ref).  This is what
+pins the oracle - every later parity claim rests on it."""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from conftest import case_matrix, load_golden
+from swipe_amd import blastdb
+
+NAMES = [f.__name__[5:] for f in cases.ALL]
+
+
+def strands(case):
+    if case.protein:
+        return [case.query]
+    return [case.query, blastdb.revcomp_nt16(case.query)]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_case_regenerates_identically(name):
+    assert cases.get(name).checksum() == load_golden(name)["checksum"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_lane_kernels_match_reference_raw_outputs(name):
+    """7-bit (both builds), 16-bit + bestpos and 63-bit values of EVERY sequence, saturated ones included."""
+    case, g = cases.get(name), load_golden(name)
+    M = case_matrix(case, oracle)
+    lo, hi, l7, l16 = oracle.score_limits(M)
+    assert (l7, l16) == (g["scorelimit7"], g["scorelimit16"])
+    goe, ge = case.gapopen + case.gapextend, case.gapextend
+    qs = strands(case)
+    assert len(g["raw"]) == len(case.seqs) * len(qs)
+    for seqno, strand, length, s7a, s7b, s16, bp16, s63 in g["raw"]:
+        d, q = case.seqs[seqno], qs[strand]
+        assert len(d) == length
+        assert oracle.search7_lane(d, q, M, goe, ge) == s7a == s7b
+        assert oracle.search16_lane(d, q, M, goe, ge) == (s16, bp16)
+        assert oracle.fullsw(d, q, M, goe, ge) == s63
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_escalation_delivers_exact_scores(name):
+    """search_chunk's 7 -> 16 -> 63 ladder ends at the 63-bit score whenever a width saturates."""
+    case, g = cases.get(name), load_golden(name)
+    M = case_matrix(case, oracle)
+    res, off = oracle.pack(case.seqs)
+    goe, ge = case.gapopen + case.gapextend, case.gapextend
+    for strand, q in enumerate(strands(case)):
+        rows = [r for r in g["raw"] if r[1] == strand]
+        scores, (c7, c16, c63) = oracle.search_chunk(res, off, q, M, goe, ge)
+        assert list(scores) == [r[7] for r in rows]
+        assert c7 == len(rows)
+        assert c16 == sum(r[3] >= g["scorelimit7"] for r in rows)
+        assert c63 == sum(r[3] >= g["scorelimit7"] and r[5] >= g["scorelimit16"] for r in rows)
+        assert list(oracle.search_all63(res, off, q, M, goe, ge, threads=2)) == [r[7] for r in rows]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_hit_list_rank_evalue_bits_match_cli(name):
+    """hits_init thresholds + hits_enter order + E-value / bit-score strings of the reference CLI."""
+    case, g = cases.get(name), load_golden(name)
+    assert g["cli"]["1"] == g["cli"]["8"]          # thread count never changes the reference's answer
+    cli = g["cli"]["1"]
+    nsym = int(sum(len(s) for s in case.seqs))
+    kw = dict(descriptions=case.keep, alignments=0, symtype=1 if case.protein else 0, matrix=case.matrix,
+              match=case.match, mismatch=case.mismatch, gapopen=case.gapopen, gapextend=case.gapextend,
+              qlen=len(case.query), dbseqs=len(case.seqs), dbsyms=nsym)
+    h = oracle.HitList(**kw)
+    for seqno, strand, length, s7a, s7b, s16, bp16, s63 in g["raw"]:
+        h.enter(seqno, s63, 0, 0, strand, 0)       # nucleotide minus strand enters as dstrand 1 (swipe.cc:1470)
+    got = h.hits()
+    assert [x[0] for x in got] == cli["seqno"]
+    assert [x[1] for x in got] == cli["score"]
+    if cli["strand"]:
+        assert ["-" if x[3] else "+" for x in got] == cli["strand"]
+    if h.c.stats_available:
+        assert ["%.2g" % h.expect(x[1]) for x in got] == cli["evalue"]
+        assert ["%.1f" % h.bits(x[1]) for x in got] == cli["bits"]
+    else:
+        assert [str(x[1]) for x in got] == cli["bits"]      # no statistics: the TSV shows the raw score
+
+
+def test_known_answers_from_baseline_md():
+    """self hit 1957 = 758.4 bits; ties rank by descending sequence number."""
+    M = oracle.matrix_builtin("BLOSUM62")
+    assert oracle.fullsw(cases.Q375, cases.Q375, M, 12, 1) == 1957
+    h = oracle.HitList(qlen=375, dbseqs=1000, dbsyms=344448)
+    assert "%.1f" % h.bits(1957) == "758.4"
+    assert "%.2g" % h.expect(1957) == "3.9e-221"
+    for s in (5, 9, 7):
+        h.enter(s, 100)
+    assert [x[0] for x in h.hits()] == [9, 7, 5]
+
+
+def test_stats_tables():
+    assert oracle.default_gaps("BLOSUM62") == (11, 1)
+    assert oracle.stats_protein("BLOSUM62", 11, 1)[:2] == (0.267, 0.041)
+    assert oracle.stats_nucleotide(1, -3, 5, 2)[:2] == (1.374, 0.711)     # both >= maxima -> the (0,0) row
+    assert oracle.stats_protein("BLOSUM62", 3, 3) is None
