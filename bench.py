@@ -178,13 +178,15 @@ def main():
                        if world > 1 else "single shard"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "swa_narrow_kernel<24>", "kernel_ms": round(k_ms, 3),
+                         "kernel": ("swa_narrow_shifted_kernel<%d>" if c["narrow_shifted"] else "swa_narrow_kernel<%d>") % c["narrow_rows"],
+                         "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer DP at 375 cells per residue byte is VALU-issue-bound, not HBM-bound; "
                                  "see valu_roofline"},
             "valu_roofline": {"achieved_gcups_kernel": round(nsym * len(q) / (k_ms * 1e-3) / 1e9, 1),
-                              "peak_gcups": 9252.0,
-                              "model": "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per VOP3P wave64 op x 128 cells / 8.5 ops"},
+                              "peak_gcups": round(256 * 4 * 2.4e9 / 4 * 128 / (7.5 if c["narrow_shifted"] else 8.5) / 1e9, 1),
+                              "model": "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per VOP3P wave64 op x 128 cells / "
+                                       + ("7.5" if c["narrow_shifted"] else "8.5") + " ops per cell pair"},
             "search": {"totalhits": int(tot), "top_hit": list(hits[0]) if hits else None, "requeued_32bit": int(c["wide"]),
                        "requeued_64bit": int(c["full"])},
             "setup_s": {"generate": round(t_gen, 2), "load_format": round(t_load, 2)},

@@ -62,6 +62,8 @@ typedef struct {
   int64_t cells;         /* DP cells computed in the first pass (symcount * qlen) */
   double  kernel_ms;     /* device time of the first-pass kernel (HIP events) */
   double  total_ms;      /* device time of the whole search (HIP events) */
+  int32_t narrow_rows;   /* query rows per lane (K) of the first-pass kernel, 0 if it did not run */
+  int32_t narrow_shifted;/* 1: row-shifted form (7.5 ops per cell pair), 0: plain form (8.5) */
 } swa_counters_t;
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;

@@ -32,6 +32,11 @@ struct swa_narrow_params {
   int32_t* ovf_count;
   int32_t* ovf_list;
   uint32_t negQ, negR;         /* packed f16 pairs: -(gapopen+gapextend), -gapextend */
+  /* row-shifted form (swa_narrow_shifted_kernel) */
+  int32_t shifted;
+  float gapextend_f;           /* R, added to every profile entry */
+  uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
+  uint32_t rowc[66];           /* packed f16 pairs r*R for r = 0..K (+1) */
 };
 
 struct swa_wide_params {

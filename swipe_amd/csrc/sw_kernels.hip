@@ -95,7 +95,7 @@ swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restric
 // ------------------------------------------------------------------ profile tables in LDS
 // f16 table, 16-byte unit index = (d*C + c)*16 + l, unit holds rows l*K + c*8 + 0..7
 template <int K>
-__device__ __forceinline__ void build_profile_f16(unsigned char* lds, const swa_query* q)
+__device__ __forceinline__ void build_profile_f16(unsigned char* lds, const swa_query* q, float add)
 {
   constexpr int C = K / 8;
   unsigned short* t = (unsigned short*)lds;
@@ -105,7 +105,36 @@ __device__ __forceinline__ void build_profile_f16(unsigned char* lds, const swa_
     const int row = l * K + c * 8 + k;
     float v = -1.0f;                                   // padding rows / PAD residue: any value <= 0
     if (row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
-    t[e] = (unsigned short)float_to_half_bits(v);
+    t[e] = (unsigned short)float_to_half_bits(v + add);
+  }
+}
+
+// scores of the 8 sequences of a batch + overflow re-queue: ballot, one atomic per wave, compacted append
+__device__ __forceinline__ void narrow_write_scores(const swa_narrow_params& p, int b, int lane, h2 S)
+{
+  const bool writer = (lane & 15) == 15;
+  const int grp = lane >> 4;
+  int sA = -1, sB = -1, idA = -1, idB = -1;
+  if (writer) {
+    idA = p.slots[(int64_t)b * SWA_SLOTS + grp * 2];
+    idB = p.slots[(int64_t)b * SWA_SLOTS + grp * 2 + 1];
+    sA = (int)(float)S.x;
+    sB = (int)(float)S.y;
+    if (idA >= 0) p.scores[idA] = sA;
+    if (idB >= 0) p.scores[idB] = sB;
+  }
+  // overflow re-queue: ballot, one atomic per wave, compacted append
+  const bool oA = writer && idA >= 0 && sA >= p.limit;
+  const bool oB = writer && idB >= 0 && sB >= p.limit;
+  const u64 mA = __ballot(oA), mB = __ballot(oB);
+  const int nA = __popcll(mA), nB = __popcll(mB);
+  if (nA + nB) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(p.ovf_count, nA + nB);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const u64 below = (1ull << lane) - 1;
+    if (oA) p.ovf_list[base + __popcll(mA & below)] = idA;
+    if (oB) p.ovf_list[base + nA + __popcll(mB & below)] = idB;
   }
 }
 
@@ -117,7 +146,7 @@ swa_narrow_kernel(swa_narrow_params p)
   constexpr int C = K / 8;
   constexpr u32 CS = C * 256;                            // LDS bytes per residue
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  build_profile_f16<K>(lds, p.query);
+  build_profile_f16<K>(lds, p.query, 0.0f);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -190,30 +219,102 @@ swa_narrow_kernel(swa_narrow_params p)
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(8), 0xF, 0xF, true)));
-    const bool writer = (lane & 15) == 15;
-    const int grp = lane >> 4;
-    int sA = -1, sB = -1, idA = -1, idB = -1;
-    if (writer) {
-      idA = p.slots[(int64_t)b * SWA_SLOTS + grp * 2];
-      idB = p.slots[(int64_t)b * SWA_SLOTS + grp * 2 + 1];
-      sA = (int)(float)S.x;
-      sB = (int)(float)S.y;
-      if (idA >= 0) p.scores[idA] = sA;
-      if (idB >= 0) p.scores[idB] = sB;
+    narrow_write_scores(p, b, lane, S);
+  }
+}
+
+// ------------------------------------------------------------------ narrow kernel, row-shifted form
+// Same systolic scheme with every value of local row r stored as  x + r*R  (R = gap extension):
+//   H^[r] = H[r] + r R,  E^[r] = E[r] + r R,  F^ entering row r = F + r R.
+// Then the vertical gap update loses its subtraction,
+//   F^[r+1] = max(F[r] - R, H[r] - Q) + (r+1) R = max(F^[r], H^[r] - (Q - R)),
+// and the horizontal one keeps its two operations,
+//   E^new[r] = max(E^[r], H^[r] - (Q - R), (r+1) R) - R      (the third operand is the zero floor),
+// so a cell pair costs 7.5 VOP3P instructions instead of 8.5.  The substitution profile carries
+// the +R of the diagonal move (H^[r] = H^[r-1]' + R + P).  Values handed to the next lane are
+// brought back to its row 0 by subtracting K R.  The per-row maxima S^[r] are un-shifted once
+// per batch.  Exact while every value stays within 2048, i.e. for scores below 2048 - hi - K R.
+template <int K>
+__global__ void __launch_bounds__(256)
+swa_narrow_shifted_kernel(swa_narrow_params p)
+{
+  constexpr int C = K / 8;
+  constexpr u32 CS = C * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  build_profile_f16<K>(lds, p.query, p.gapextend_f);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const u32 l16 = (u32)(lane & 15) * 16;
+  const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR), negKR = as_h2(p.negKR);
+  const h2 zero = {0, 0};
+  const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
+
+  for (;;) {
+    int b = 0;
+    if (lane == 0) b = atomicAdd(p.counter, 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= p.nbatches) break;
+    const swa_batch bd = p.batches[b];
+    const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
+    const int nchunks = bd.nchunks;
+
+    h2 H[K], E[K], SR[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r]); E[r] = H[r]; SR[r] = H[r]; }   // 0 + r R
+    h2 diag = negR;                                       // H[-1][-1] in row 0's frame: 0 - R
+    h2 Fout = as_h2(p.rowc[K]);                           // F leaving row K-1 in the next lane's frame + K R
+    u32 cur = PADOFF;
+    u32 raw = nchunks > 0 ? (u32)s[lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
+
+    for (int m = 0; m <= nchunks; ++m) {
+      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
+
+#pragma unroll 2
+      for (int u = 0; u < 16; ++u) {
+        cur = row_shr1(cur, pl);
+        pl = row_shl1(pl);
+        // lane 0 of a row has no neighbour: the fills make hup = -R and F = 0 after the K R correction
+        const h2 hup = as_h2(row_shr1(as_u32(H[K - 1]), p.rowc[K - 1])) + negKR;
+        h2 F = as_h2(row_shr1(as_u32(Fout), p.rowc[K])) + negKR;
+        h2 hd = diag;
+        diag = hup;
+
+        const u32 aoff = (cur & 0xFFFF) | l16;
+        const u32 boff = (cur >> 16) | l16;
+        uint4 pa[C], pb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          pa[c] = *(const uint4*)(lds + aoff + c * 256);
+          pb[c] = *(const uint4*)(lds + boff + c * 256);
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          const int c = r >> 3, k = r & 7;
+          const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;
+          const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;
+          const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u));
+          const h2 h = pk_max3(hd + sc, E[r], F);
+          hd = H[r];
+          if (u & 1) SR[r] = pk_max3(SR[r], hd, h);      // two columns per update
+          H[r] = h;
+          const h2 t = h + negQR;
+          F = pk_max(F, t);
+          E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 1])) + negR;
+        }
+        Fout = F;
+      }
     }
-    // overflow re-queue: ballot, one atomic per wave, compacted append
-    const bool oA = writer && idA >= 0 && sA >= p.limit;
-    const bool oB = writer && idB >= 0 && sB >= p.limit;
-    const u64 mA = __ballot(oA), mB = __ballot(oB);
-    const int nA = __popcll(mA), nB = __popcll(mB);
-    if (nA + nB) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(p.ovf_count, nA + nB);
-      base = __builtin_amdgcn_readfirstlane(base);
-      const u64 below = (1ull << lane) - 1;
-      if (oA) p.ovf_list[base + __popcll(mA & below)] = idA;
-      if (oB) p.ovf_list[base + nA + __popcll(mB & below)] = idB;
-    }
+
+    h2 S = zero;
+#pragma unroll
+    for (int r = 0; r < K; ++r) S = pk_max(S, pk_max(SR[r], H[r]) - as_h2(p.rowc[r]));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(8), 0xF, 0xF, true)));
+    narrow_write_scores(p, b, lane, S);
   }
 }
 
@@ -396,6 +497,15 @@ static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStrea
   hipLaunchKernelGGL(swa_narrow_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
+template <int K>
+static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * (K / 8) * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(swa_narrow_shifted_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
 template <typename T, int K>
 static hipError_t launch_wide(const swa_wide_params& p, int blocks, hipStream_t st)
 {
@@ -421,6 +531,15 @@ extern "C" int swa_wide_rows_for(int qlen)
 
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
+  if (p->shifted) switch (K) {
+    case 8:  return launch_narrow_shifted<8>(*p, blocks, st);
+    case 16: return launch_narrow_shifted<16>(*p, blocks, st);
+    case 24: return launch_narrow_shifted<24>(*p, blocks, st);
+    case 32: return launch_narrow_shifted<32>(*p, blocks, st);
+    case 40: return launch_narrow_shifted<40>(*p, blocks, st);
+    case 48: return launch_narrow_shifted<48>(*p, blocks, st);
+    default: return hipErrorInvalidValue;
+  }
   switch (K) {
     case 8:  return launch_narrow<8>(*p, blocks, st);
     case 16: return launch_narrow<16>(*p, blocks, st);

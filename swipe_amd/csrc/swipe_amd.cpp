@@ -115,6 +115,7 @@ struct swa_db {
   int32_t h_matrix[1024];
   int64_t goe = 0, ge = 0, hi = 0, lo = 0;
   bool searched = false;
+  int narrow_variant = 0;                  // 0 auto, 1 plain, 2 row-shifted (SWA_NARROW_VARIANT, for A/B runs)
 
   ~swa_db()
   {
@@ -292,10 +293,24 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.limit = int32_t(2048 - db->hi);
     p.ovf_count = db->ctl.p + 1;
     p.ovf_list = db->ovf_list.p;
-    const uint32_t nq = f16_bits(-float(db->goe)), nr = f16_bits(-float(db->ge));
-    p.negQ = nq | nq << 16;
-    p.negR = nr | nr << 16;
-    HIP_TRY(swa_launch_narrow(swa_narrow_rows_for(int(qlen)), &p, persistent_blocks(db, p.nbatches), st));
+    const int K = swa_narrow_rows_for(int(qlen));
+    auto pair = [](float v) { const uint32_t b = f16_bits(v); return b | b << 16; };
+    p.negQ = pair(-float(db->goe));
+    p.negR = pair(-float(db->ge));
+    // row-shifted form: values carry up to K*R extra, so its exact range ends K*R earlier
+    const int64_t shifted_limit = 2048 - db->hi - int64_t(K) * db->ge;
+    p.shifted = (db->narrow_variant != 1 && K <= 48 && db->goe >= db->ge && shifted_limit >= 1024) ? 1 : 0;
+    if (db->narrow_variant == 2 && !p.shifted) return fail(SWA_EINVAL, "row-shifted kernel not applicable to this scoring");
+    if (p.shifted) {
+      p.limit = int32_t(shifted_limit);
+      p.gapextend_f = float(db->ge);
+      p.negQR = pair(-float(db->goe - db->ge));
+      p.negKR = pair(-float(int64_t(K) * db->ge));
+      for (int r = 0; r <= K; ++r) p.rowc[r] = pair(float(int64_t(r) * db->ge));
+    }
+    c.narrow_rows = K;
+    c.narrow_shifted = p.shifted;
+    HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
     HIP_TRY(hipEventRecord(db->ev[2], st));
     int32_t novf = 0;
     HIP_TRY(hipMemcpyAsync(&novf, db->ctl.p + 1, sizeof novf, hipMemcpyDeviceToHost, st));
@@ -391,6 +406,7 @@ extern "C" int swa_db_from_memory(const uint8_t* residues, const int64_t* offset
   if (!db) return fail(SWA_ENOMEM, "out of host memory");
   db->device = device;
   db->symtype = symtype;
+  if (const char* v = std::getenv("SWA_NARROW_VARIANT")) db->narrow_variant = std::atoi(v);
   db->first_seqno = first_seqno;
   const int rc = ingest(db, residues, offsets, nseq);
   if (rc != SWA_OK) { delete db; return rc; }

@@ -141,6 +141,24 @@ def test_every_rows_per_lane_variant(qlen):
     db.close()
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("gaps", [(11, 1), (5, 2), (0, 3), (14, 4)])
+def test_both_narrow_kernel_forms(monkeypatch, variant, gaps):
+    """plain (SWA_NARROW_VARIANT=1) and row-shifted (=2) packed-f16 kernels, several gap systems"""
+    monkeypatch.setenv("SWA_NARROW_VARIANT", variant)
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(9, 4000, query=q)
+    seqs = [res[off[i]:off[i + 1]] for i in range(4000)] + cases.case_p1k().seqs[1000:] + [q, q[:100], np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), *gaps)
+    scores, c = db.search(q)
+    want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), gaps[0] + gaps[1], gaps[1], threads=THREADS)
+    assert np.array_equal(scores, want)
+    assert c["narrow"] == len(seqs)
+    db.close()
+
+
 def test_empty_inputs_and_errors():
     M = swipe_amd.matrix_builtin("BLOSUM62")
     db = swipe_amd.Database.from_sequences([cases.Q375, np.zeros(0, np.uint8)])
