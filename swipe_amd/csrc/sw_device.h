@@ -11,7 +11,8 @@
 
 struct swa_batch {
   uint32_t offset;             /* start of the batch in the residue stream, in 128-byte chunks */
-  int32_t nchunks;             /* 16-column chunks = ceil(longest sequence of the batch / 16) */
+  int32_t steps;               /* DP columns the batch needs = longest sequence rounded up to 2;
+                                  the stream holds ceil(steps / 16) chunks of 16 columns */
 };
 
 struct swa_query {
@@ -33,10 +34,10 @@ struct swa_narrow_params {
   int32_t* ovf_list;
   uint32_t negQ, negR;         /* packed f16 pairs: -(gapopen+gapextend), -gapextend */
   /* row-shifted form (swa_narrow_shifted_kernel) */
-  int32_t shifted;
+  int32_t shifted;             /* 0 plain form, 1 row-shifted form */
   float gapextend_f;           /* R, added to every profile entry */
   uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
-  uint32_t rowc[66];           /* packed f16 pairs r*R for r = 0..K (+1) */
+  uint32_t rowc[68];           /* packed f16 pairs r*R for r = 0..K+1 */
 };
 
 struct swa_wide_params {

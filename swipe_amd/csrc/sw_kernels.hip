@@ -73,7 +73,7 @@ swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restric
   const swa_batch bd = batches[b];
   const int32_t* sl = slots + (int64_t)b * SWA_SLOTS;
   uint16_t* out = stream + (int64_t)bd.offset * 64;
-  const int total = bd.nchunks * 64;
+  const int total = ((bd.steps + 15) >> 4) * 64;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int chunk = e >> 6, lane = e & 63, grp = lane >> 4, l = lane & 15;
     const int64_t t = (int64_t)chunk * 16 + l;
@@ -162,7 +162,7 @@ swa_narrow_kernel(swa_narrow_params p)
     if (b >= p.nbatches) break;
     const swa_batch bd = p.batches[b];
     const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
-    const int nchunks = bd.nchunks;
+    const int nchunks = (bd.steps + 15) >> 4;
 
     h2 H[K], E[K];
 #pragma unroll
@@ -224,18 +224,24 @@ swa_narrow_kernel(swa_narrow_params p)
 }
 
 // ------------------------------------------------------------------ narrow kernel, row-shifted form
-// Same systolic scheme with every value of local row r stored as  x + r*R  (R = gap extension):
-//   H^[r] = H[r] + r R,  E^[r] = E[r] + r R,  F^ entering row r = F + r R.
+// Same systolic scheme with every value of local row r stored as  x + (r+1) R  (R = gap extension):
+//   H^[r] = H[r] + (r+1) R,  E^[r] = E[r] + (r+1) R,  F^ entering row r = F + (r+1) R.
 // Then the vertical gap update loses its subtraction,
-//   F^[r+1] = max(F[r] - R, H[r] - Q) + (r+1) R = max(F^[r], H^[r] - (Q - R)),
+//   F^[r+1] = max(F[r] - R, H[r] - Q) + (r+2) R = max(F^[r], H^[r] - (Q - R)),
 // and the horizontal one keeps its two operations,
-//   E^new[r] = max(E^[r], H^[r] - (Q - R), (r+1) R) - R      (the third operand is the zero floor),
+//   E^new[r] = max(E^[r], H^[r] - (Q - R), (r+2) R) - R      (the third operand is the zero floor),
 // so a cell pair costs 7.5 VOP3P instructions instead of 8.5.  The substitution profile carries
 // the +R of the diagonal move (H^[r] = H^[r-1]' + R + P).  Values handed to the next lane are
-// brought back to its row 0 by subtracting K R.  The per-row maxima S^[r] are un-shifted once
-// per batch.  Exact while every value stays within 2048, i.e. for scores below 2048 - hi - K R.
+// brought to its row -1 frame (offset 0) by the SENDER subtracting K R, so the DPP zero fill is the
+// correct boundary for lane 0 of a row (H[-1] = 0; F <= 0 is "no gap").  Per-row maxima S^[r] are
+// un-shifted once per batch.  Exact while every value stays within 2048, i.e. for scores below
+// 2048 - hi - (K+1) R.  The last chunk of a batch runs only as many steps as the batch needs
+// (+16 to drain the skew), rounded to 2 because S^ is updated every other column.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u4v* lds_u4_ptr;
+
 template <int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (K <= 24 ? 4 : K <= 32 ? 3 : 2))
 swa_narrow_shifted_kernel(swa_narrow_params p)
 {
   constexpr int C = K / 8;
@@ -245,10 +251,11 @@ swa_narrow_shifted_kernel(swa_narrow_params p)
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const u32 l16 = (u32)(lane & 15) * 16;
+  const u32 l16 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (u32)(lane & 15) * 16;
   const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR), negKR = as_h2(p.negKR);
   const h2 zero = {0, 0};
   const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
+  const u32 PADRAW = SWA_PAD | (SWA_PAD << 8);
 
   for (;;) {
     int b = 0;
@@ -257,59 +264,64 @@ swa_narrow_shifted_kernel(swa_narrow_params p)
     if (b >= p.nbatches) break;
     const swa_batch bd = p.batches[b];
     const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
-    const int nchunks = bd.nchunks;
+    const int nchunks = (bd.steps + 15) >> 4;
+    const int total = bd.steps + 16;                      // + drain of the 15-step skew, kept even
 
     h2 H[K], E[K], SR[K];
 #pragma unroll
-    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r]); E[r] = H[r]; SR[r] = H[r]; }   // 0 + r R
-    h2 diag = negR;                                       // H[-1][-1] in row 0's frame: 0 - R
-    h2 Fout = as_h2(p.rowc[K]);                           // F leaving row K-1 in the next lane's frame + K R
+    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r + 1]); E[r] = H[r]; SR[r] = H[r]; }   // 0 + (r+1) R
+    h2 diag = zero;                                       // H[-1][-1]
+    h2 hsend = zero, fsend = zero;                        // what the next lane reads: H[K-1] - K R, Fout - K R
     u32 cur = PADOFF;
-    u32 raw = nchunks > 0 ? (u32)s[lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
+    u32 raw = nchunks > 0 ? (u32)s[lane] : PADRAW;
 
-    for (int m = 0; m <= nchunks; ++m) {
+#define SWA_STEP(ODD)                                                                          \
+    {                                                                                          \
+      const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
+      cur = row_shr1(cur, pl);                                                                 \
+      pl = pl2;                                                                                \
+      const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+      h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+      h2 hd = diag;                                                                            \
+      diag = hup;                                                                              \
+      const u32 aoff = (cur & 0xFFFF) | l16;                                                   \
+      const u32 boff = (cur >> 16) | l16;                                                      \
+      u4v pa[C], pb[C];                                                                        \
+      _Pragma("unroll") for (int c = 0; c < C; ++c) {                                          \
+        pa[c] = *(lds_u4_ptr)(uintptr_t)(aoff + c * 256);                                      \
+        pb[c] = *(lds_u4_ptr)(uintptr_t)(boff + c * 256);                                      \
+      }                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < K; ++r) {                                          \
+        const int c = r >> 3, k = r & 7;                                                       \
+        const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;          \
+        const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;          \
+        const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u)); \
+        const h2 h = pk_max3(hd + sc, E[r], F);                                                \
+        hd = H[r];                                                                             \
+        if (ODD) SR[r] = pk_max3(SR[r], hd, h);           /* two columns per update */         \
+        H[r] = h;                                                                              \
+        const h2 t = h + negQR;                                                                \
+        F = pk_max(F, t);                                                                      \
+        E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2])) + negR;                                  \
+      }                                                                                        \
+      hsend = H[K - 1] + negKR;                                                                \
+      fsend = F + negKR;                                                                       \
+    }
+
+    for (int m = 0; m * 16 < total; ++m) {
       u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
-      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
-
-#pragma unroll 2
-      for (int u = 0; u < 16; ++u) {
-        cur = row_shr1(cur, pl);
-        pl = row_shl1(pl);
-        // lane 0 of a row has no neighbour: the fills make hup = -R and F = 0 after the K R correction
-        const h2 hup = as_h2(row_shr1(as_u32(H[K - 1]), p.rowc[K - 1])) + negKR;
-        h2 F = as_h2(row_shr1(as_u32(Fout), p.rowc[K])) + negKR;
-        h2 hd = diag;
-        diag = hup;
-
-        const u32 aoff = (cur & 0xFFFF) | l16;
-        const u32 boff = (cur >> 16) | l16;
-        uint4 pa[C], pb[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          pa[c] = *(const uint4*)(lds + aoff + c * 256);
-          pb[c] = *(const uint4*)(lds + boff + c * 256);
-        }
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-          const int c = r >> 3, k = r & 7;
-          const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;
-          const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;
-          const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u));
-          const h2 h = pk_max3(hd + sc, E[r], F);
-          hd = H[r];
-          if (u & 1) SR[r] = pk_max3(SR[r], hd, h);      // two columns per update
-          H[r] = h;
-          const h2 t = h + negQR;
-          F = pk_max(F, t);
-          E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 1])) + negR;
-        }
-        Fout = F;
+      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : PADRAW;
+      const int n = total - m * 16 < 16 ? total - m * 16 : 16;
+      for (int u = 0; u < n; u += 2) {
+        SWA_STEP(0)
+        SWA_STEP(1)
       }
     }
+#undef SWA_STEP
 
     h2 S = zero;
 #pragma unroll
-    for (int r = 0; r < K; ++r) S = pk_max(S, pk_max(SR[r], H[r]) - as_h2(p.rowc[r]));
+    for (int r = 0; r < K; ++r) S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
@@ -383,7 +395,7 @@ swa_wide_kernel(swa_wide_params p)
     if (b >= p.nbatches) break;
     const swa_batch bd = p.batches[b];
     const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
-    const int nchunks = bd.nchunks;
+    const int nchunks = (bd.steps + 15) >> 4;
 
     T H[K], E[K];
 #pragma unroll

@@ -154,10 +154,11 @@ int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchS
       const int64_t len = db->h_offsets[id + 1] - db->h_offsets[id];
       if (len > longest) longest = len;
     }
-    const int64_t nchunks = (longest + 15) / 16;
-    if (chunk_total > 0xffffffffull) return fail(SWA_EINVAL, "residue stream exceeds 2^32 chunks");
+    const int64_t steps = (longest + 1) & ~int64_t(1);
+    const int64_t nchunks = (steps + 15) / 16;
+    if (chunk_total > 0xffffffffull || steps > 0x7ffffff0) return fail(SWA_EINVAL, "residue stream exceeds 2^32 chunks");
     batches[size_t(b)].offset = uint32_t(chunk_total);
-    batches[size_t(b)].nchunks = int32_t(nchunks);
+    batches[size_t(b)].steps = int32_t(steps);
     chunk_total += uint64_t(nchunks);
   }
   HIP_TRY(bs.slots.reserve(slots.size()));
@@ -298,7 +299,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.negQ = pair(-float(db->goe));
     p.negR = pair(-float(db->ge));
     // row-shifted form: values carry up to K*R extra, so its exact range ends K*R earlier
-    const int64_t shifted_limit = 2048 - db->hi - int64_t(K) * db->ge;
+    const int64_t shifted_limit = 2048 - db->hi - int64_t(K + 1) * db->ge;
     p.shifted = (db->narrow_variant != 1 && K <= 48 && db->goe >= db->ge && shifted_limit >= 1024) ? 1 : 0;
     if (db->narrow_variant == 2 && !p.shifted) return fail(SWA_EINVAL, "row-shifted kernel not applicable to this scoring");
     if (p.shifted) {
@@ -306,11 +307,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
       p.gapextend_f = float(db->ge);
       p.negQR = pair(-float(db->goe - db->ge));
       p.negKR = pair(-float(int64_t(K) * db->ge));
-      for (int r = 0; r <= K; ++r) p.rowc[r] = pair(float(int64_t(r) * db->ge));
+      for (int r = 0; r <= K + 1; ++r) p.rowc[r] = pair(float(int64_t(r) * db->ge));
     }
+    int blocks = persistent_blocks(db, p.nbatches);
     c.narrow_rows = K;
     c.narrow_shifted = p.shifted;
-    HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
+    HIP_TRY(swa_launch_narrow(K, &p, blocks, st));
     HIP_TRY(hipEventRecord(db->ev[2], st));
     int32_t novf = 0;
     HIP_TRY(hipMemcpyAsync(&novf, db->ctl.p + 1, sizeof novf, hipMemcpyDeviceToHost, st));
