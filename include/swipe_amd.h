@@ -110,6 +110,18 @@ int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores,
 int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep,
                     int64_t minscore, int64_t maxscore, swa_hit_t* hits, int64_t* nhits,
                     int64_t* totalhits, int64_t* obvious, swa_counters_t* counters);
+/* Two queries of EQUAL length in one pass over the shard (both halves of the packed lanes see
+   the same database residue).  The nucleotide search of the reference is exactly this: the plus
+   strand and the reverse-complemented query against the same database (swipe.cc:1403-1411,
+   hits entered with dstrand = 1 for the second, swipe.cc:1470-1471). */
+int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
+                int64_t* scores1, int64_t* scores2, swa_counters_t* counters);
+/* hits of both queries in one list; which[i] = 0 / 1 tells the query (strand) of hits[i]; on equal
+   score and seqno the entry of query 1 comes first, as in the reference's insertion order */
+int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
+                     int64_t keep, int64_t minscore, int64_t maxscore, swa_hit_t* hits,
+                     int32_t* which, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
+                     swa_counters_t* counters);
 /* Merge per-shard top-K lists (each ordered) into the global top-K with the reference's
    comparator - what the MPI master does with tag_search_report (swipe.cc:1951-1974). */
 int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,

@@ -151,6 +151,35 @@ class Database:
         return ([(hits[i].seqno, hits[i].score) for i in range(n.value)], tot.value, obv.value,
                 {f: getattr(c, f) for f, _ in c._fields_})
 
+    def search2(self, query1: np.ndarray, query2: np.ndarray, *, want_scores: bool = True):
+        """Two equal-length queries in one pass (nucleotide: plus strand and its reverse complement)."""
+        q1 = np.ascontiguousarray(query1, dtype=np.uint8)
+        q2 = np.ascontiguousarray(query2, dtype=np.uint8)
+        if len(q1) != len(q2):
+            raise SwaError("search2 needs two queries of equal length")
+        c = _lib.Counters()
+        n = self.info()["seqcount"]
+        s1 = np.empty(n, dtype=np.int64) if want_scores else None
+        s2 = np.empty(n, dtype=np.int64) if want_scores else None
+        _check(_lib.load().swa_search2(self._h, q1.ctypes.data, q2.ctypes.data, len(q1),
+                                       s1.ctypes.data if want_scores else None,
+                                       s2.ctypes.data if want_scores else None, C.byref(c)))
+        return s1, s2, {f: getattr(c, f) for f, _ in c._fields_}
+
+    def search2_topk(self, query1, query2, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
+        q1 = np.ascontiguousarray(query1, dtype=np.uint8)
+        q2 = np.ascontiguousarray(query2, dtype=np.uint8)
+        if len(q1) != len(q2):
+            raise SwaError("search2_topk needs two queries of equal length")
+        c = _lib.Counters()
+        hits = (_lib.Hit * max(1, keep))()
+        which = (C.c_int32 * max(1, keep))()
+        n, tot, obv = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(_lib.load().swa_search2_topk(self._h, q1.ctypes.data, q2.ctypes.data, len(q1), keep, minscore, maxscore,
+                                            hits, which, C.byref(n), C.byref(tot), C.byref(obv), C.byref(c)))
+        return ([(hits[i].seqno, hits[i].score, which[i]) for i in range(n.value)], tot.value, obv.value,
+                {f: getattr(c, f) for f, _ in c._fields_})
+
     def close(self):
         if self._h:
             _lib.load().swa_db_close(self._h)

@@ -35,23 +35,36 @@ struct swa_narrow_params {
   uint32_t negQ, negR;         /* packed f16 pairs: -(gapopen+gapextend), -gapextend */
   /* row-shifted form (swa_narrow_shifted_kernel) */
   int32_t shifted;             /* 0 plain form, 1 row-shifted form */
+  int32_t waves;               /* tuning: waves per SIMD the kernel is compiled for (0 = default) */
   float gapextend_f;           /* R, added to every profile entry */
   uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
   uint32_t rowc[68];           /* packed f16 pairs r*R for r = 0..K+1 */
 };
 
-struct swa_wide_params {
-  const swa_query* query;
+/* generic multi-pass kernel (sw_mp_kernel.inc) */
+struct swa_mp_params {
+  const uint8_t* qseq;         /* query 1 */
+  const uint8_t* qseq2;        /* query 2 (dual mode), same length */
+  const int32_t* matrix;
+  int32_t qlen, npass, rows_per_lane;
   const uint16_t* stream;
   const swa_batch* batches;
   const int32_t* slots;
   int32_t nbatches;
-  int32_t* counter;
+  int32_t* counter;            /* super-batch queue head (one grab = one batch per wave of a block) */
   int32_t* scores;
+  int32_t* scores2;            /* dual mode: scores of query 2 */
   long long* scores64;
-  long long limit;             /* 2^31 - hi for the 32-bit kernel */
+  long long limit;
   int32_t* ovf_count;
   int32_t* ovf_list;
+  int32_t* ovf_count2;
+  int32_t* ovf_list2;
+  void* boundary;              /* per wave: boundary_cols x 4 rows x (H, F) */
+  int32_t boundary_cols;
   long long gapopenextend, gapextend;
+  float gapextend_f;
+  uint32_t negQR, negR, negKR;
+  uint32_t rowc[68];
 };
 #endif

@@ -240,8 +240,8 @@ swa_narrow_kernel(swa_narrow_params p)
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u4v* lds_u4_ptr;
 
-template <int K>
-__global__ void __launch_bounds__(256, (K <= 24 ? 4 : K <= 32 ? 3 : 2))
+template <int K, int W>
+__global__ void __launch_bounds__(256, W)
 swa_narrow_shifted_kernel(swa_narrow_params p)
 {
   constexpr int C = K / 8;
@@ -330,139 +330,7 @@ swa_narrow_shifted_kernel(swa_narrow_params p)
   }
 }
 
-// ------------------------------------------------------------------ wide kernels (i32 / i64)
-template <typename T>
-__device__ __forceinline__ T wide_row_shr1(T v)
-{
-  if constexpr (sizeof(T) == 4) {
-    return (T)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR1, 0xF, 0xF, true);
-  } else {
-    const u64 x = (u64)v;
-    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, DPP_ROW_SHR1, 0xF, 0xF, true);
-    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(x >> 32), DPP_ROW_SHR1, 0xF, 0xF, true);
-    return (T)(((u64)hi << 32) | lo);
-  }
-}
-template <typename T, int N>
-__device__ __forceinline__ T wide_row_shrn(T v)
-{
-  if constexpr (sizeof(T) == 4) {
-    return (T)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(N), 0xF, 0xF, true);
-  } else {
-    const u64 x = (u64)v;
-    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, DPP_ROW_SHR(N), 0xF, 0xF, true);
-    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(x >> 32), DPP_ROW_SHR(N), 0xF, 0xF, true);
-    return (T)(((u64)hi << 32) | lo);
-  }
-}
-template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
-
-// int32 profile table, 16-byte unit index = (d*C4 + c)*16 + l, unit holds rows l*K + c*4 + 0..3
-template <int K>
-__device__ __forceinline__ void build_profile_i32(unsigned char* lds, const swa_query* q)
-{
-  constexpr int C4 = K / 4;
-  int* t = (int*)lds;
-  const int total = 32 * C4 * 16 * 4;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int k = e & 3, l = (e >> 2) & 15, c = (e >> 6) % C4, d = (e >> 6) / C4;
-    const int row = l * K + c * 4 + k;
-    int v = -1;
-    if (row < q->qlen && d != SWA_PAD) v = q->matrix[(d << 5) + q->qseq[row]];
-    t[e] = v;
-  }
-}
-
-// One sequence per 16-lane row (slot A of each group), exact in T.  Same systolic scheme.
-template <typename T, int K>
-__global__ void __launch_bounds__(256)
-swa_wide_kernel(swa_wide_params p)
-{
-  constexpr int C4 = K / 4;
-  constexpr u32 CS = C4 * 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  build_profile_i32<K>(lds, p.query);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const u32 l16 = (u32)(lane & 15) * 16;
-  const T Q = (T)p.gapopenextend, R = (T)p.gapextend;
-
-  for (;;) {
-    int b = 0;
-    if (lane == 0) b = atomicAdd(p.counter, 1);
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= p.nbatches) break;
-    const swa_batch bd = p.batches[b];
-    const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
-    const int nchunks = (bd.steps + 15) >> 4;
-
-    T H[K], E[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) { H[r] = 0; E[r] = 0; }
-    T S = 0, diag = 0, Fout = 0;
-    u32 cur = SWA_PAD * CS;
-    u32 raw = nchunks > 0 ? (u32)s[lane] : (u32)SWA_PAD;
-
-    for (int m = 0; m <= nchunks; ++m) {
-      u32 pl = (raw & 0xFF) * CS;
-      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : (u32)SWA_PAD;
-#pragma unroll 1
-      for (int u = 0; u < 16; ++u) {
-        cur = row_shr1(cur, pl);
-        pl = row_shl1(pl);
-        const T hup = wide_row_shr1<T>(H[K - 1]);
-        T F = wide_row_shr1<T>(Fout);
-        T hd = diag;
-        diag = hup;
-        const u32 aoff = cur | l16;
-#pragma unroll
-        for (int c = 0; c < C4; ++c) {
-          const int4 pa = *(const int4*)(lds + aoff + c * 256);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int r = c * 4 + k;
-            const T sc = (T)(k == 0 ? pa.x : k == 1 ? pa.y : k == 2 ? pa.z : pa.w);
-            T h = hd + sc;
-            h = tmax(tmax(h, E[r]), F);                 // >= 0 because E >= 0
-            hd = H[r];
-            H[r] = h;
-            S = tmax(S, h);
-            const T t = h - Q;
-            E[r] = tmax(tmax(E[r] - R, t), (T)0);
-            F = tmax(F - R, t);
-          }
-        }
-        Fout = F;
-      }
-    }
-    S = tmax(S, wide_row_shrn<T, 1>(S));
-    S = tmax(S, wide_row_shrn<T, 2>(S));
-    S = tmax(S, wide_row_shrn<T, 4>(S));
-    S = tmax(S, wide_row_shrn<T, 8>(S));
-    const bool writer = (lane & 15) == 15;
-    const int grp = lane >> 4;
-    int id = -1;
-    if (writer) {
-      id = p.slots[(int64_t)b * SWA_SLOTS + grp * 2];
-      if (id >= 0) {
-        if constexpr (sizeof(T) == 4) p.scores[id] = (int)S;
-        else { p.scores64[id] = (long long)S; p.scores[id] = SWA_SCORE_IN_64; }
-      }
-    }
-    if constexpr (sizeof(T) == 4) {
-      const bool o = writer && id >= 0 && (long long)S >= p.limit;
-      const u64 mo = __ballot(o);
-      const int n = __popcll(mo);
-      if (n) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(p.ovf_count, n);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (o) p.ovf_list[base + __popcll(mo & ((1ull << lane) - 1))] = id;
-      }
-    }
-  }
-}
+#include "sw_mp_kernel.inc"
 
 // ------------------------------------------------------------------ hit filter
 // The hits_enter acceptance test (hits.cc:174-184) over all scores of the shard: counts
@@ -509,47 +377,30 @@ static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStrea
   hipLaunchKernelGGL(swa_narrow_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
-template <int K>
+template <int K, int W>
 static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
   const size_t lds = (size_t)32 * (K / 8) * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted_kernel<K, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(swa_narrow_shifted_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
-template <typename T, int K>
-static hipError_t launch_wide(const swa_wide_params& p, int blocks, hipStream_t st)
-{
-  const size_t lds = (size_t)32 * (K / 4) * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)swa_wide_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((swa_wide_kernel<T, K>), dim3(blocks), dim3(256), lds, st, p);
-  return hipGetLastError();
-}
-
 extern "C" int swa_narrow_rows_for(int qlen)
 {
   static const int ks[] = {8, 16, 24, 32, 40, 48, 64};
   for (int k : ks) if (qlen <= 16 * k) return k;
   return 0;
 }
-extern "C" int swa_wide_rows_for(int qlen)
-{
-  static const int ks[] = {8, 16, 24, 32, 48, 64};
-  for (int k : ks) if (qlen <= 16 * k) return k;
-  return 0;
-}
-
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
   if (p->shifted) switch (K) {
-    case 8:  return launch_narrow_shifted<8>(*p, blocks, st);
-    case 16: return launch_narrow_shifted<16>(*p, blocks, st);
-    case 24: return launch_narrow_shifted<24>(*p, blocks, st);
-    case 32: return launch_narrow_shifted<32>(*p, blocks, st);
-    case 40: return launch_narrow_shifted<40>(*p, blocks, st);
-    case 48: return launch_narrow_shifted<48>(*p, blocks, st);
+    case 8:  return launch_narrow_shifted<8, 8>(*p, blocks, st);
+    case 16: return launch_narrow_shifted<16, 4>(*p, blocks, st);
+    case 24: return p->waves == 3 ? launch_narrow_shifted<24, 3>(*p, blocks, st) : p->waves == 2 ? launch_narrow_shifted<24, 2>(*p, blocks, st) : launch_narrow_shifted<24, 4>(*p, blocks, st);
+    case 32: return launch_narrow_shifted<32, 3>(*p, blocks, st);
+    case 40: return launch_narrow_shifted<40, 2>(*p, blocks, st);
+    case 48: return launch_narrow_shifted<48, 2>(*p, blocks, st);
     default: return hipErrorInvalidValue;
   }
   switch (K) {
@@ -560,25 +411,6 @@ extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int b
     case 40: return launch_narrow<40>(*p, blocks, st);
     case 48: return launch_narrow<48>(*p, blocks, st);
     case 64: return launch_narrow<64>(*p, blocks, st);
-  }
-  return hipErrorInvalidValue;
-}
-extern "C" hipError_t swa_launch_wide(int K, int bits, const swa_wide_params* p, int blocks, hipStream_t st)
-{
-  if (bits == 32) switch (K) {
-    case 8:  return launch_wide<int, 8>(*p, blocks, st);
-    case 16: return launch_wide<int, 16>(*p, blocks, st);
-    case 24: return launch_wide<int, 24>(*p, blocks, st);
-    case 32: return launch_wide<int, 32>(*p, blocks, st);
-    case 48: return launch_wide<int, 48>(*p, blocks, st);
-    case 64: return launch_wide<int, 64>(*p, blocks, st);
-  } else switch (K) {
-    case 8:  return launch_wide<long long, 8>(*p, blocks, st);
-    case 16: return launch_wide<long long, 16>(*p, blocks, st);
-    case 24: return launch_wide<long long, 24>(*p, blocks, st);
-    case 32: return launch_wide<long long, 32>(*p, blocks, st);
-    case 48: return launch_wide<long long, 48>(*p, blocks, st);
-    case 64: return launch_wide<long long, 64>(*p, blocks, st);
   }
   return hipErrorInvalidValue;
 }

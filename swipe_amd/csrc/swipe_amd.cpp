@@ -23,9 +23,8 @@
 
 extern "C" {
 int swa_narrow_rows_for(int qlen);
-int swa_wide_rows_for(int qlen);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
-hipError_t swa_launch_wide(int K, int bits, const swa_wide_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
 hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, long long minscore,
@@ -100,10 +99,16 @@ struct swa_db {
   DevBuf<int64_t> offsets;
   BatchSet main;                           // all sequences, two per DPP row
   BatchSet scratch;                        // re-queued sequences, one per DPP row
+  BatchSet single;                         // all sequences, one per DPP row (built on first use)
+  bool single_built = false;
   DevBuf<int32_t> scores;
   DevBuf<long long> scores64;
   DevBuf<int32_t> ovf_list;
-  DevBuf<int32_t> ctl;                     // [0] work counter, [1] overflow count, [2] candidate count
+  DevBuf<int32_t> ovf_list2;
+  DevBuf<int32_t> scores2;                 // second query of a dual search
+  DevBuf<uint8_t> qseq2;
+  DevBuf<unsigned char> boundary;          // per-wave pass hand-over columns of the multi-pass kernel
+  DevBuf<int32_t> ctl;                     // [0] work counter, [1] overflow count, [2] candidate count, [3] overflow count of query 2
   DevBuf<unsigned long long> tallies;      // totalhits, obvious
   DevBuf<int32_t> cand_idx;
   DevBuf<long long> cand_score;
@@ -114,7 +119,6 @@ struct swa_db {
   bool scoring_set = false;
   int32_t h_matrix[1024];
   int64_t goe = 0, ge = 0, hi = 0, lo = 0;
-  bool searched = false;
   int narrow_variant = 0;                  // 0 auto, 1 plain, 2 row-shifted (SWA_NARROW_VARIANT, for A/B runs)
 
   ~swa_db()
@@ -125,7 +129,8 @@ struct swa_db {
   size_t hbm_bytes() const
   {
     return residues.bytes() + offsets.bytes() + main.slots.bytes() + main.batches.bytes() + main.stream.bytes() +
-           scratch.slots.bytes() + scratch.batches.bytes() + scratch.stream.bytes() + scores.bytes() +
+           scratch.slots.bytes() + scratch.batches.bytes() + scratch.stream.bytes() + single.slots.bytes() +
+           single.batches.bytes() + single.stream.bytes() + scores2.bytes() + boundary.bytes() + scores.bytes() +
            scores64.bytes() + ovf_list.bytes() + cand_idx.bytes() + cand_score.bytes();
   }
 };
@@ -245,45 +250,224 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   return build_batches(db, db->h_order.data(), nseq, 2, db->main);
 }
 
-struct SearchTimes { float narrow_ms = 0, total_ms = 0; };
+uint32_t f16_pair(float v)
+{
+  const uint32_t b = f16_bits(v);
+  return b | b << 16;
+}
+
+// all sequences, one per DPP row (dual-query kernel, and the 32-bit kernel when f16 does not apply)
+int ensure_single(swa_db* db)
+{
+  if (db->single_built) return SWA_OK;
+  const int rc = build_batches(db, db->h_order.data(), db->nseq, 1, db->single);
+  if (rc == SWA_OK) db->single_built = true;
+  return rc;
+}
+
+struct MpRun {
+  int mode = 0;                 // 0 f16 pair, 1 f16 dual, 2 int32, 3 int64
+  const BatchSet* set = nullptr;
+  const uint8_t* q1 = nullptr;  // device pointers
+  const uint8_t* q2 = nullptr;
+  int32_t* scores = nullptr;
+  int32_t* scores2 = nullptr;
+  int32_t* ovf_count = nullptr;
+  int32_t* ovf_list = nullptr;
+  int32_t* ovf_count2 = nullptr;
+  int32_t* ovf_list2 = nullptr;
+};
+
+int mp_rows_for(int mode, int64_t qlen)
+{
+  if (mode == 0) return qlen <= 16 * 24 ? 24 : 32;
+  if (mode == 1) return qlen <= 128 ? 8 : qlen <= 256 ? 16 : qlen <= 384 ? 24 : 32;
+  if (mode == 2) return qlen <= 128 ? 8 : qlen <= 256 ? 16 : 32;
+  return qlen <= 128 ? 8 : 16;
+}
+
+// limit below which the f16 forms are exact for K rows per lane
+int64_t f16_limit(const swa_db* db, int K) { return 2048 - db->hi - int64_t(K + 1) * db->ge; }
+
+int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
+{
+  const int K = mp_rows_for(r.mode, qlen);
+  swa_mp_params p{};
+  p.qseq = r.q1;
+  p.qseq2 = r.q2;
+  p.matrix = db->matrix.p;
+  p.qlen = int32_t(qlen);
+  p.rows_per_lane = K;
+  p.npass = int32_t((qlen + 16 * K - 1) / (16 * K));
+  p.stream = r.set->stream.p;
+  p.batches = r.set->batches.p;
+  p.slots = r.set->slots.p;
+  p.nbatches = r.set->nbatches;
+  p.counter = db->ctl.p + 0;
+  p.scores = r.scores;
+  p.scores2 = r.scores2;
+  p.scores64 = db->scores64.p;
+  p.limit = r.mode <= 1 ? f16_limit(db, K) : (1ll << 31) - db->hi - int64_t(K + 1) * db->ge;
+  p.ovf_count = r.ovf_count;
+  p.ovf_list = r.ovf_list;
+  p.ovf_count2 = r.ovf_count2;
+  p.ovf_list2 = r.ovf_list2;
+  p.gapopenextend = db->goe;
+  p.gapextend = db->ge;
+  p.gapextend_f = float(db->ge);
+  p.negQR = f16_pair(-float(db->goe - db->ge));
+  p.negR = f16_pair(-float(db->ge));
+  p.negKR = f16_pair(-float(int64_t(K) * db->ge));
+  for (int i = 0; i <= K + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
+
+  const size_t lds = size_t(32) * (K / (r.mode == 0 ? 8 : 4)) * 256;
+  const int threads = lds >= 48 * 1024 ? 512 : 256;
+  const int nw = threads / 64;
+  const int per_cu = std::max(1, std::min<int>(int(160 * 1024 / lds), 12 / nw));
+  const int supers = (p.nbatches + nw - 1) / nw;
+  const int blocks = std::max(1, std::min(supers, db->cus * per_cu));
+  if (p.npass > 1) {
+    const size_t vbytes = r.mode == 3 ? 8 : 4;
+    p.boundary_cols = int32_t(((db->longest + 1) & ~int64_t(1)) + 48);
+    HIP_TRY(db->boundary.reserve(size_t(blocks) * nw * size_t(p.boundary_cols) * 8 * vbytes));
+    p.boundary = db->boundary.p;
+  }
+  HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
+  HIP_TRY(swa_launch_mp(r.mode, K, &p, blocks, threads, st));
+  return SWA_OK;
+}
+
+int read_requeue(swa_db* db, int ctl_index, const int32_t* list, std::vector<int32_t>& out, hipStream_t st)
+{
+  int32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, db->ctl.p + ctl_index, sizeof n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  out.clear();
+  if (n > 0) {
+    out.resize(size_t(n));
+    HIP_TRY(hipMemcpy(out.data(), list, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::sort(out.begin(), out.end());                 // deterministic whatever the wave timing was
+  }
+  return SWA_OK;
+}
+
+// 32-bit then 64-bit kernels over a re-queue list, one query; results land in `scores`
+// (64-bit values in db->scores64 with the sentinel in `scores`).
+int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int64_t qlen, int32_t* scores,
+             int64_t* n32, int64_t* n64, hipStream_t st)
+{
+  for (int bits = 32; !requeue.empty() && bits <= 64; bits += 32) {
+    const BatchSet* set = &db->scratch;
+    if (int64_t(requeue.size()) == db->nseq) {
+      const int rc = ensure_single(db);
+      if (rc != SWA_OK) return rc;
+      set = &db->single;
+    } else {
+      std::vector<int32_t> ordered;
+      order_by_length(db->h_offsets, requeue.data(), int64_t(requeue.size()), ordered);
+      const int rc = build_batches(db, ordered.data(), int64_t(ordered.size()), 1, db->scratch);
+      if (rc != SWA_OK) return rc;
+    }
+    if (bits == 64) HIP_TRY(db->scores64.reserve(size_t(db->nseq)));
+    HIP_TRY(hipMemsetAsync(db->ctl.p + 1, 0, sizeof(int32_t), st));
+    MpRun r;
+    r.mode = bits == 32 ? 2 : 3;
+    r.set = set;
+    r.q1 = qdev;
+    r.scores = scores;
+    r.ovf_count = db->ctl.p + 1;
+    r.ovf_list = db->ovf_list.p;
+    const int rc = launch_mp_run(db, r, qlen, st);
+    if (rc != SWA_OK) return rc;
+    *(bits == 32 ? n32 : n64) += int64_t(requeue.size());
+    requeue.clear();
+    if (bits == 32) {
+      const int rc2 = read_requeue(db, 1, db->ovf_list.p, requeue, st);
+      if (rc2 != SWA_OK) return rc2;
+    }
+  }
+  return SWA_OK;
+}
+
+int check_query(const swa_db* db, const uint8_t* q, int64_t qlen)
+{
+  if (!db) return fail(SWA_EINVAL, "null database handle");
+  if (!db->scoring_set) return fail(SWA_ESTATE, "swa_set_scoring must be called before searching");
+  if (qlen < 0 || (qlen > 0 && !q)) return fail(SWA_EINVAL, "bad query");
+  if (qlen > (1 << 20)) return fail(SWA_EINVAL, "query longer than 2^20 residues");
+  for (int64_t i = 0; i < qlen; ++i)
+    if (q[i] >= 32) return fail(SWA_EINVAL, "query symbol code out of range (must be < 32)");
+  return SWA_OK;
+}
+
+bool f16_applicable(const swa_db* db)
+{
+  // f16 pairs are exact while every value stays within +-2048: needs modest scores and penalties
+  return db->hi >= 0 && db->hi < 512 && db->lo > -1024 && db->goe >= db->ge && db->goe <= 1024 && db->ge >= 0 &&
+         db->ge <= 16;
+}
+
+int finish_empty(swa_db* db, swa_counters_t& c, swa_counters_t* counters, bool two, hipStream_t st)
+{
+  if (db->nseq) {
+    HIP_TRY(hipMemsetAsync(db->scores.p, 0, size_t(db->nseq) * sizeof(int32_t), st));
+    if (two) {
+      HIP_TRY(db->scores2.reserve(size_t(db->nseq)));
+      HIP_TRY(hipMemsetAsync(db->scores2.p, 0, size_t(db->nseq) * sizeof(int32_t), st));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (counters) *counters = c;
+  return SWA_OK;
+}
 
 // the escalation loop: packed f16 -> 32 bit -> 64 bit.  Scores end up in db->scores / scores64.
 int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* counters)
 {
-  if (!db) return fail(SWA_EINVAL, "null database handle");
-  if (!db->scoring_set) return fail(SWA_ESTATE, "swa_set_scoring must be called before searching");
-  if (qlen < 0 || (qlen > 0 && !query)) return fail(SWA_EINVAL, "bad query");
-  if (qlen > 1024) return fail(SWA_EINVAL, "queries longer than 1024 residues are not supported yet");
-  for (int64_t i = 0; i < qlen; ++i)
-    if (query[i] >= 32) return fail(SWA_EINVAL, "query symbol code out of range (must be < 32)");
+  int rc = check_query(db, query, qlen);
+  if (rc != SWA_OK) return rc;
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
   swa_counters_t c{};
   c.cells = db->nsym * qlen;
+  if (qlen == 0 || db->nseq == 0) return finish_empty(db, c, counters, false, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
-  if (qlen == 0 || db->nseq == 0) {
-    if (db->nseq) HIP_TRY(hipMemsetAsync(db->scores.p, 0, size_t(db->nseq) * sizeof(int32_t), st));
-    HIP_TRY(hipEventRecord(db->ev[1], st));
-    HIP_TRY(hipEventRecord(db->ev[2], st));
-    HIP_TRY(hipEventRecord(db->ev[3], st));
-    HIP_TRY(hipStreamSynchronize(st));
-    db->searched = true;
-    if (counters) *counters = c;
-    return SWA_OK;
-  }
   HIP_TRY(db->qseq.reserve(size_t(qlen)));
   HIP_TRY(hipMemcpyAsync(db->qseq.p, query, size_t(qlen), hipMemcpyHostToDevice, st));
   swa_query hq{db->qseq.p, db->matrix.p, int32_t(qlen)};
   HIP_TRY(hipMemcpyAsync(db->query.p, &hq, sizeof hq, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, 8 * sizeof(int32_t), st));
 
-  // f16 pairs are exact while every value stays within +-2048: needs modest scores and penalties
-  const bool narrow_ok = db->hi >= 0 && db->hi < 1024 && db->lo > -1024 && db->goe >= 0 && db->goe <= 1024 &&
-                         db->ge >= 0 && db->ge <= 1024 && swa_narrow_rows_for(int(qlen)) > 0;
   std::vector<int32_t> requeue;
+  const bool f16 = f16_applicable(db);
+  const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
+  const bool single_pass = qlen <= 16 * 48 && K > 0;
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  if (narrow_ok) {
+  if (f16 && single_pass && f16_limit(db, K) >= 1024 && db->narrow_variant != 1) {
     swa_narrow_params p{};
+    p.query = db->query.p;
+    p.stream = db->main.stream.p;
+    p.batches = db->main.batches.p;
+    p.slots = db->main.slots.p;
+    p.nbatches = db->main.nbatches;
+    p.counter = db->ctl.p + 0;
+    p.scores = db->scores.p;
+    p.ovf_count = db->ctl.p + 1;
+    p.ovf_list = db->ovf_list.p;
+    p.negQ = f16_pair(-float(db->goe));
+    p.negR = f16_pair(-float(db->ge));
+    p.shifted = 1;                                     // row-shifted form, 7.5 ops per cell pair
+    p.limit = int32_t(f16_limit(db, K));
+    p.gapextend_f = float(db->ge);
+    p.negQR = f16_pair(-float(db->goe - db->ge));
+    p.negKR = f16_pair(-float(int64_t(K) * db->ge));
+    for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
+    c.narrow_rows = K;
+    c.narrow_shifted = 1;
+    HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
+    c.narrow = db->nseq;
+  } else if (f16 && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
+    swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
     p.query = db->query.p;
     p.stream = db->main.stream.p;
     p.batches = db->main.batches.p;
@@ -294,77 +478,34 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.limit = int32_t(2048 - db->hi);
     p.ovf_count = db->ctl.p + 1;
     p.ovf_list = db->ovf_list.p;
-    const int K = swa_narrow_rows_for(int(qlen));
-    auto pair = [](float v) { const uint32_t b = f16_bits(v); return b | b << 16; };
-    p.negQ = pair(-float(db->goe));
-    p.negR = pair(-float(db->ge));
-    // row-shifted form: values carry up to K*R extra, so its exact range ends K*R earlier
-    const int64_t shifted_limit = 2048 - db->hi - int64_t(K + 1) * db->ge;
-    p.shifted = (db->narrow_variant != 1 && K <= 48 && db->goe >= db->ge && shifted_limit >= 1024) ? 1 : 0;
-    if (db->narrow_variant == 2 && !p.shifted) return fail(SWA_EINVAL, "row-shifted kernel not applicable to this scoring");
-    if (p.shifted) {
-      p.limit = int32_t(shifted_limit);
-      p.gapextend_f = float(db->ge);
-      p.negQR = pair(-float(db->goe - db->ge));
-      p.negKR = pair(-float(int64_t(K) * db->ge));
-      for (int r = 0; r <= K + 1; ++r) p.rowc[r] = pair(float(int64_t(r) * db->ge));
-    }
-    int blocks = persistent_blocks(db, p.nbatches);
+    p.negQ = f16_pair(-float(db->goe));
+    p.negR = f16_pair(-float(db->ge));
     c.narrow_rows = K;
-    c.narrow_shifted = p.shifted;
-    HIP_TRY(swa_launch_narrow(K, &p, blocks, st));
-    HIP_TRY(hipEventRecord(db->ev[2], st));
-    int32_t novf = 0;
-    HIP_TRY(hipMemcpyAsync(&novf, db->ctl.p + 1, sizeof novf, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
     c.narrow = db->nseq;
-    if (novf > 0) {
-      requeue.resize(size_t(novf));
-      HIP_TRY(hipMemcpy(requeue.data(), db->ovf_list.p, size_t(novf) * sizeof(int32_t), hipMemcpyDeviceToHost));
-      std::sort(requeue.begin(), requeue.end());       // deterministic order whatever the wave timing was
-    }
+  } else if (f16 && f16_limit(db, mp_rows_for(0, qlen)) >= 1024) {
+    MpRun r;                                           // long query: multi-pass pair kernel
+    r.mode = 0;
+    r.set = &db->main;
+    r.q1 = db->qseq.p;
+    r.scores = db->scores.p;
+    r.ovf_count = db->ctl.p + 1;
+    r.ovf_list = db->ovf_list.p;
+    rc = launch_mp_run(db, r, qlen, st);
+    if (rc != SWA_OK) return rc;
+    c.narrow_rows = mp_rows_for(0, qlen);
+    c.narrow_shifted = 1;
+    c.narrow = db->nseq;
+  }
+  HIP_TRY(hipEventRecord(db->ev[2], st));
+  if (c.narrow) {
+    rc = read_requeue(db, 1, db->ovf_list.p, requeue, st);
+    if (rc != SWA_OK) return rc;
   } else {
-    HIP_TRY(hipEventRecord(db->ev[2], st));
     requeue.assign(db->h_order.begin(), db->h_order.end());
   }
-
-  for (int bits = 32; !requeue.empty() && bits <= 64; bits += 32) {
-    std::vector<int32_t> ordered;
-    order_by_length(db->h_offsets, requeue.data(), int64_t(requeue.size()), ordered);
-    int rc = build_batches(db, ordered.data(), int64_t(ordered.size()), 1, db->scratch);
-    if (rc != SWA_OK) return rc;
-    if (bits == 64) HIP_TRY(db->scores64.reserve(size_t(db->nseq)));
-    HIP_TRY(hipMemsetAsync(db->ctl.p, 0, 2 * sizeof(int32_t), st));
-    swa_wide_params p{};
-    p.query = db->query.p;
-    p.stream = db->scratch.stream.p;
-    p.batches = db->scratch.batches.p;
-    p.slots = db->scratch.slots.p;
-    p.nbatches = db->scratch.nbatches;
-    p.counter = db->ctl.p + 0;
-    p.scores = db->scores.p;
-    p.scores64 = db->scores64.p;
-    p.limit = (1ll << 31) - db->hi;
-    p.ovf_count = db->ctl.p + 1;
-    p.ovf_list = db->ovf_list.p;
-    p.gapopenextend = db->goe;
-    p.gapextend = db->ge;
-    const int K = swa_wide_rows_for(int(qlen));
-    if (!K) return fail(SWA_EINVAL, "query too long for the wide kernel");
-    HIP_TRY(swa_launch_wide(K, bits, &p, persistent_blocks(db, p.nbatches), st));
-    (bits == 32 ? c.wide : c.full) = int64_t(requeue.size());
-    requeue.clear();
-    if (bits == 32) {
-      int32_t novf = 0;
-      HIP_TRY(hipMemcpyAsync(&novf, db->ctl.p + 1, sizeof novf, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      if (novf > 0) {
-        requeue.resize(size_t(novf));
-        HIP_TRY(hipMemcpy(requeue.data(), db->ovf_list.p, size_t(novf) * sizeof(int32_t), hipMemcpyDeviceToHost));
-        std::sort(requeue.begin(), requeue.end());
-      }
-    }
-  }
+  rc = run_wide(db, requeue, db->qseq.p, qlen, db->scores.p, &c.wide, &c.full, st);
+  if (rc != SWA_OK) return rc;
   HIP_TRY(hipEventRecord(db->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));
   float ms = 0;
@@ -372,7 +513,73 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   c.kernel_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, db->ev[0], db->ev[3]));
   c.total_ms = ms;
-  db->searched = true;
+  if (counters) *counters = c;
+  return SWA_OK;
+}
+
+// Two queries of equal length against every sequence in one pass (nucleotide plus/minus strand).
+// Scores of query 1 end up in db->scores, of query 2 in db->scores2 (64-bit values in scores64
+// would collide between the two, so the 64-bit hop is only taken for query 1 - see below).
+int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, swa_counters_t* counters)
+{
+  int rc = check_query(db, q1, qlen);
+  if (rc == SWA_OK) rc = check_query(db, q2, qlen);
+  if (rc != SWA_OK) return rc;
+  HIP_TRY(hipSetDevice(db->device));
+  hipStream_t st = db->stream;
+  swa_counters_t c{};
+  c.cells = 2 * db->nsym * qlen;
+  if (qlen == 0 || db->nseq == 0) return finish_empty(db, c, counters, true, st);
+  HIP_TRY(hipEventRecord(db->ev[0], st));
+  HIP_TRY(db->qseq.reserve(size_t(qlen)));
+  HIP_TRY(db->qseq2.reserve(size_t(qlen)));
+  HIP_TRY(db->scores2.reserve(size_t(db->nseq)));
+  HIP_TRY(db->ovf_list2.reserve(size_t(db->nseq)));
+  HIP_TRY(hipMemcpyAsync(db->qseq.p, q1, size_t(qlen), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(db->qseq2.p, q2, size_t(qlen), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(db->ctl.p, 0, 8 * sizeof(int32_t), st));
+  rc = ensure_single(db);
+  if (rc != SWA_OK) return rc;
+  std::vector<int32_t> rq1, rq2;
+  HIP_TRY(hipEventRecord(db->ev[1], st));
+  if (f16_applicable(db) && f16_limit(db, mp_rows_for(1, qlen)) >= 1024) {
+    MpRun r;
+    r.mode = 1;
+    r.set = &db->single;
+    r.q1 = db->qseq.p;
+    r.q2 = db->qseq2.p;
+    r.scores = db->scores.p;
+    r.scores2 = db->scores2.p;
+    r.ovf_count = db->ctl.p + 1;
+    r.ovf_list = db->ovf_list.p;
+    r.ovf_count2 = db->ctl.p + 3;
+    r.ovf_list2 = db->ovf_list2.p;
+    rc = launch_mp_run(db, r, qlen, st);
+    if (rc != SWA_OK) return rc;
+    c.narrow_rows = mp_rows_for(1, qlen);
+    c.narrow_shifted = 1;
+    c.narrow = db->nseq;
+    HIP_TRY(hipEventRecord(db->ev[2], st));
+    rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
+    if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
+    if (rc != SWA_OK) return rc;
+  } else {
+    HIP_TRY(hipEventRecord(db->ev[2], st));
+    rq1.assign(db->h_order.begin(), db->h_order.end());
+    rq2 = rq1;
+  }
+  int64_t full2 = 0;
+  rc = run_wide(db, rq1, db->qseq.p, qlen, db->scores.p, &c.wide, &c.full, st);
+  if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2.p, qlen, db->scores2.p, &c.wide, &full2, st);
+  if (rc != SWA_OK) return rc;
+  if (full2) return fail(SWA_EINVAL, "second query needs the 64-bit kernel; search the two queries separately");
+  HIP_TRY(hipEventRecord(db->ev[3], st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, db->ev[1], db->ev[2]));
+  c.kernel_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, db->ev[0], db->ev[3]));
+  c.total_ms = ms;
   if (counters) *counters = c;
   return SWA_OK;
 }
@@ -495,54 +702,30 @@ extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapope
   return SWA_OK;
 }
 
-extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters)
-{
-  const int rc = run_search(db, query, qlen, counters);
-  if (rc != SWA_OK || !scores || db->nseq == 0) return rc;
-  std::vector<int32_t> s32(size_t(db->nseq));
-  HIP_TRY(hipMemcpy(s32.data(), db->scores.p, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  std::vector<long long> s64;
-  for (int64_t i = 0; i < db->nseq; ++i) {
-    if (s32[size_t(i)] == SWA_SCORE_IN_64) {
-      if (s64.empty()) {
-        s64.resize(size_t(db->nseq));
-        HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      }
-      scores[i] = s64[size_t(i)];
-    } else {
-      scores[i] = s32[size_t(i)];
-    }
-  }
-  return SWA_OK;
-}
+extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters);
 
-extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore,
-                               int64_t maxscore, swa_hit_t* hits, int64_t* nhits, int64_t* totalhits,
-                               int64_t* obvious, swa_counters_t* counters)
+namespace {
+struct Cand { int64_t seqno, score; int32_t which; };
+
+// hits_enter acceptance test over one score array on the device; appends the survivors
+int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t keep, int64_t minscore,
+                       int64_t maxscore, std::vector<Cand>& cand, int64_t* totalhits, int64_t* obvious)
 {
-  if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
-  const int rc = run_search(db, query, qlen, counters);
-  if (rc != SWA_OK) return rc;
-  *nhits = 0;
-  if (totalhits) *totalhits = 0;
-  if (obvious) *obvious = 0;
-  if (db->nseq == 0) return SWA_OK;
   hipStream_t st = db->stream;
   const int cap = int(std::min<int64_t>(db->nseq, std::max<int64_t>(1 << 20, 8 * keep)));
   HIP_TRY(db->cand_idx.reserve(size_t(cap)));
   HIP_TRY(db->cand_score.reserve(size_t(cap)));
   HIP_TRY(hipMemsetAsync(db->ctl.p + 2, 0, sizeof(int32_t), st));
   HIP_TRY(hipMemsetAsync(db->tallies.p, 0, 2 * sizeof(unsigned long long), st));
-  HIP_TRY(swa_launch_filter(db->scores.p, db->scores64.p, int(db->nseq), minscore, maxscore, db->ctl.p + 2, cap,
+  HIP_TRY(swa_launch_filter(scores, db->scores64.p, int(db->nseq), minscore, maxscore, db->ctl.p + 2, cap,
                             db->cand_idx.p, db->cand_score.p, db->tallies.p, st));
   int32_t ncand = 0;
   unsigned long long tl[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(&ncand, db->ctl.p + 2, sizeof ncand, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(tl, db->tallies.p, sizeof tl, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (totalhits) *totalhits = int64_t(tl[0]);
-  if (obvious) *obvious = int64_t(tl[1]);
-  std::vector<swa_hit_t> cand;
+  *totalhits += int64_t(tl[0]);
+  *obvious += int64_t(tl[1]);
   if (ncand <= cap) {
     std::vector<int32_t> idx((size_t(ncand)));
     std::vector<long long> sc((size_t(ncand)));
@@ -550,29 +733,116 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
       HIP_TRY(hipMemcpy(idx.data(), db->cand_idx.p, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(sc.data(), db->cand_score.p, sc.size() * sizeof(long long), hipMemcpyDeviceToHost));
     }
-    cand.resize(size_t(ncand));
-    for (int i = 0; i < ncand; ++i) cand[size_t(i)] = {db->first_seqno + idx[size_t(i)], sc[size_t(i)]};
-  } else {
-    // more candidates than the compaction buffer: take every score to the host instead
-    std::vector<int64_t> all(size_t(db->nseq));
-    std::vector<int32_t> s32(size_t(db->nseq));
-    HIP_TRY(hipMemcpy(s32.data(), db->scores.p, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    std::vector<long long> s64;
-    for (int64_t i = 0; i < db->nseq; ++i) {
-      int64_t v = s32[size_t(i)];
-      if (v == SWA_SCORE_IN_64) {
-        if (s64.empty()) {
-          s64.resize(size_t(db->nseq));
-          HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        }
-        v = s64[size_t(i)];
+    for (int i = 0; i < ncand; ++i) cand.push_back({db->first_seqno + idx[size_t(i)], sc[size_t(i)], which});
+    return SWA_OK;
+  }
+  // more candidates than the compaction buffer: take every score to the host instead
+  std::vector<int32_t> s32(size_t(db->nseq));
+  HIP_TRY(hipMemcpy(s32.data(), scores, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<long long> s64;
+  for (int64_t i = 0; i < db->nseq; ++i) {
+    int64_t v = s32[size_t(i)];
+    if (v == SWA_SCORE_IN_64) {
+      if (s64.empty()) {
+        s64.resize(size_t(db->nseq));
+        HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
       }
-      if (v >= minscore && v <= maxscore) cand.push_back({db->first_seqno + i, v});
+      v = s64[size_t(i)];
+    }
+    if (v >= minscore && v <= maxscore) cand.push_back({db->first_seqno + i, v, which});
+  }
+  return SWA_OK;
+}
+
+// hits.cc:188-190 (score desc, seqno desc); entries of query 1 were entered before those of
+// query 2 (swipe.cc:1403 loops the strands in that order), so they win remaining ties
+bool cand_before(const Cand& a, const Cand& b)
+{
+  if (a.score != b.score) return a.score > b.score;
+  if (a.seqno != b.seqno) return a.seqno > b.seqno;
+  return a.which < b.which;
+}
+
+int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
+{
+  std::vector<int32_t> s32(size_t(db->nseq));
+  HIP_TRY(hipMemcpy(s32.data(), dev, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<long long> s64;
+  for (int64_t i = 0; i < db->nseq; ++i) {
+    if (s32[size_t(i)] == SWA_SCORE_IN_64) {
+      if (s64.empty()) {
+        s64.resize(size_t(db->nseq));
+        HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      }
+      out[i] = s64[size_t(i)];
+    } else {
+      out[i] = s32[size_t(i)];
     }
   }
+  return SWA_OK;
+}
+}  // namespace
+
+extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters)
+{
+  const int rc = run_search(db, query, qlen, counters);
+  if (rc != SWA_OK || !scores || db->nseq == 0) return rc;
+  return download_scores(db, db->scores.p, scores);
+}
+
+extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore,
+                               int64_t maxscore, swa_hit_t* hits, int64_t* nhits, int64_t* totalhits,
+                               int64_t* obvious, swa_counters_t* counters)
+{
+  if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
+  int rc = run_search(db, query, qlen, counters);
+  if (rc != SWA_OK) return rc;
+  *nhits = 0;
+  int64_t tot = 0, obv = 0;
+  std::vector<Cand> cand;
+  if (db->nseq) {
+    rc = collect_candidates(db, db->scores.p, 0, keep, minscore, maxscore, cand, &tot, &obv);
+    if (rc != SWA_OK) return rc;
+  }
+  if (totalhits) *totalhits = tot;
+  if (obvious) *obvious = obv;
   const size_t k = std::min<size_t>(size_t(keep), cand.size());
-  std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), hit_before);
-  for (size_t i = 0; i < k; ++i) hits[i] = cand[i];
+  std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), cand_before);
+  for (size_t i = 0; i < k; ++i) hits[i] = {cand[i].seqno, cand[i].score};
+  *nhits = int64_t(k);
+  return SWA_OK;
+}
+
+extern "C" int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
+                           int64_t* scores1, int64_t* scores2, swa_counters_t* counters)
+{
+  int rc = run_search2(db, query1, query2, qlen, counters);
+  if (rc != SWA_OK || db->nseq == 0) return rc;
+  if (scores1) rc = download_scores(db, db->scores.p, scores1);
+  if (rc == SWA_OK && scores2) rc = download_scores(db, db->scores2.p, scores2);
+  return rc;
+}
+
+extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen, int64_t keep,
+                                int64_t minscore, int64_t maxscore, swa_hit_t* hits, int32_t* which, int64_t* nhits,
+                                int64_t* totalhits, int64_t* obvious, swa_counters_t* counters)
+{
+  if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
+  int rc = run_search2(db, query1, query2, qlen, counters);
+  if (rc != SWA_OK) return rc;
+  *nhits = 0;
+  int64_t tot = 0, obv = 0;
+  std::vector<Cand> cand;
+  if (db->nseq) {
+    rc = collect_candidates(db, db->scores.p, 0, keep, minscore, maxscore, cand, &tot, &obv);
+    if (rc == SWA_OK) rc = collect_candidates(db, db->scores2.p, 1, keep, minscore, maxscore, cand, &tot, &obv);
+    if (rc != SWA_OK) return rc;
+  }
+  if (totalhits) *totalhits = tot;
+  if (obvious) *obvious = obv;
+  const size_t k = std::min<size_t>(size_t(keep), cand.size());
+  std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), cand_before);
+  for (size_t i = 0; i < k; ++i) { hits[i] = {cand[i].seqno, cand[i].score}; which[i] = cand[i].which; }
   *nhits = int64_t(k);
   return SWA_OK;
 }

@@ -125,7 +125,8 @@ def test_width_escalation_16_to_32_to_64():
     db.close()
 
 
-@pytest.mark.parametrize("qlen", [1, 2, 15, 16, 17, 127, 128, 129, 255, 375, 384, 385, 511, 640, 767, 1000, 1024])
+@pytest.mark.parametrize("qlen", [1, 2, 15, 16, 17, 127, 128, 129, 255, 375, 384, 385, 511, 640, 767, 768, 769, 1000,
+                                  1024, 1025, 1536, 2100, 5000])
 def test_every_rows_per_lane_variant(qlen):
     """query lengths around every 16*K boundary of the kernel templates"""
     rtab = synth.residue_table_protein()
@@ -170,8 +171,6 @@ def test_empty_inputs_and_errors():
     assert list(db.search(cases.Q375)[0]) == [1957, 0]
     with pytest.raises(swipe_amd.SwaError):
         db.search(np.full(5, 40, np.uint8))
-    with pytest.raises(swipe_amd.SwaError):
-        db.search(np.ones(1025, np.uint8))
     db.close()
     empty = swipe_amd.Database.from_sequences([])
     empty.set_scoring(M, 11, 1)
@@ -215,6 +214,48 @@ def test_properties_at_scale():
     hits, tot, obv, _ = db.search_topk(q, keep=250, minscore=50)
     order = sorted(((int(s), i) for i, s in enumerate(s1) if s >= 50), key=lambda t: (-t[0], -t[1]))
     assert hits == [(i, s) for s, i in order[:250]] and tot == len(order) and obv == 0
+    db.close()
+
+
+@pytest.mark.parametrize("qlen", [1, 100, 128, 129, 300, 384, 385, 512, 513, 1000, 1024, 1025, 3000])
+def test_dual_query_kernel_both_strands(qlen):
+    """search2: plus strand and reverse complement in the two halves of one pass (single and multi pass)"""
+    rtab = synth.residue_table_nucleotide()
+    q = synth._random_residues(31 + qlen, 1, qlen, rtab)
+    qm = blastdb.revcomp_nt16(q)
+    res, off = swipe_amd.synth_db(4, 1500, protein=False)
+    mut = q.copy()
+    mut[::11] = rtab[(np.arange(len(mut[::11])) * 613) % 4096]
+    seqs = [res[off[i]:off[i + 1]] for i in range(1500)] + [q, qm, mut, blastdb.revcomp_nt16(mut)[: max(1, qlen // 2)],
+                                                            np.zeros(0, np.uint8), q[:1]]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2, symtype=0)
+    db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+    Mo = oracle.matrix_nucleotide(1, -3)
+    s1, s2, c = db.search2(q, qm)
+    assert np.array_equal(s1, oracle.search_all63(r2, o2, q, Mo, 7, 2, threads=THREADS))
+    assert np.array_equal(s2, oracle.search_all63(r2, o2, qm, Mo, 7, 2, threads=THREADS))
+    if qlen >= 2048:
+        assert c["wide"] > 0           # the self hits leave the f16 range and are re-queued
+    hits, tot, obv, _ = db.search2_topk(q, qm, keep=20, minscore=15)
+    want = sorted([(int(s), i, 0) for i, s in enumerate(s1) if s >= 15] + [(int(s), i, 1) for i, s in enumerate(s2) if s >= 15],
+                  key=lambda t: (-t[0], -t[1], t[2]))[:20]
+    assert hits == [(i, s, w) for s, i, w in want]
+    db.close()
+
+
+def test_dual_query_protein_and_custom_matrix():
+    """the dual kernel is not nucleotide specific: two protein queries of equal length"""
+    q1 = cases.Q375
+    q2 = cases.Q375[::-1].copy()
+    res, off = swipe_amd.synth_db(6, 3000, query=q1)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    s1, s2, _ = db.search2(q1, q2)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    assert np.array_equal(s1, oracle.search_all63(res, off, q1, Mo, 12, 1, threads=THREADS))
+    assert np.array_equal(s2, oracle.search_all63(res, off, q2, Mo, 12, 1, threads=THREADS))
+    assert np.array_equal(db.search(q1)[0], s1)
     db.close()
 
 
