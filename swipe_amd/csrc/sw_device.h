@@ -47,6 +47,7 @@ struct swa_mp_params {
   const uint8_t* qseq2;        /* query 2 (dual mode), same length */
   const int32_t* matrix;
   int32_t qlen, npass, rows_per_lane;
+  int32_t tune_w;              /* tuning override of the waves-per-SIMD build (0 = default) */
   const uint16_t* stream;
   const swa_batch* batches;
   const int32_t* slots;

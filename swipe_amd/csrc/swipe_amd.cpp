@@ -24,6 +24,7 @@
 extern "C" {
 int swa_narrow_rows_for(int qlen);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
@@ -280,10 +281,11 @@ struct MpRun {
 
 int mp_rows_for(int mode, int64_t qlen)
 {
-  if (mode == 0) return qlen <= 16 * 24 ? 24 : 32;
-  if (mode == 1) return qlen <= 128 ? 8 : qlen <= 256 ? 16 : qlen <= 384 ? 24 : 32;
-  if (mode == 2) return qlen <= 128 ? 8 : qlen <= 256 ? 16 : 32;
-  return qlen <= 128 ? 8 : 16;
+  if (mode == 0) return 16;
+  // measured on MI355X (tools/gpu_nt_knobs.py): 16 rows per lane at 4 waves/SIMD beats 24 or 32 rows at
+  // 3 or 2 waves even though it needs more passes
+  if (mode == 1 || mode == 2) return qlen <= 128 ? 8 : 16;
+  return 8;
 }
 
 // limit below which the f16 forms are exact for K rows per lane
@@ -291,7 +293,8 @@ int64_t f16_limit(const swa_db* db, int K) { return 2048 - db->hi - int64_t(K + 
 
 int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
 {
-  const int K = mp_rows_for(r.mode, qlen);
+  int K = mp_rows_for(r.mode, qlen);
+  if (const char* e = std::getenv("SWA_MP_K")) if (r.mode <= 1) K = std::atoi(e);
   swa_mp_params p{};
   p.qseq = r.q1;
   p.qseq2 = r.q2;
@@ -321,9 +324,15 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   for (int i = 0; i <= K + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
 
   const size_t lds = size_t(32) * (K / (r.mode == 0 ? 8 : 4)) * 256;
-  const int threads = lds >= 48 * 1024 ? 512 : 256;
-  const int nw = threads / 64;
-  const int per_cu = std::max(1, std::min<int>(int(160 * 1024 / lds), 12 / nw));
+  // resident waves per SIMD the kernel's VGPR count allows (-Rpass-analysis=kernel-resource-usage)
+  int wps = swa_mp_waves(r.mode, K);
+  if (const char* e = std::getenv("SWA_MP_W")) { p.tune_w = std::atoi(e); if (r.mode == 1 && K == 32) wps = p.tune_w; }
+  const int waves_cu = 4 * wps;
+  const int by_lds = std::max(1, int(160 * 1024 / lds));
+  int nw = 4;
+  while (nw < 8 && (waves_cu + nw - 1) / nw > by_lds) nw += 2;     // fewer, larger blocks when LDS is the limit
+  const int threads = nw * 64;
+  const int per_cu = std::max(1, std::min(by_lds, waves_cu / nw));
   const int supers = (p.nbatches + nw - 1) / nw;
   const int blocks = std::max(1, std::min(supers, db->cus * per_cu));
   if (p.npass > 1) {
@@ -441,7 +450,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   std::vector<int32_t> requeue;
   const bool f16 = f16_applicable(db);
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
-  const bool single_pass = qlen <= 16 * 48 && K > 0;
+  const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
+  const bool single_pass = qlen <= 16 * 48 && K > 0 && !force_mp;
   HIP_TRY(hipEventRecord(db->ev[1], st));
   if (f16 && single_pass && f16_limit(db, K) >= 1024 && db->narrow_variant != 1) {
     swa_narrow_params p{};
@@ -466,7 +476,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     c.narrow_shifted = 1;
     HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
     c.narrow = db->nseq;
-  } else if (f16 && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
+  } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
     p.query = db->query.p;
     p.stream = db->main.stream.p;

@@ -244,6 +244,23 @@ def test_dual_query_kernel_both_strands(qlen):
     db.close()
 
 
+@pytest.mark.parametrize("K", ["16", "24", "32"])
+def test_multipass_pair_kernel_rows_per_lane(monkeypatch, K):
+    """every rows-per-lane build of the multi-pass pair kernel (SWA_MP_K override) on a long protein query"""
+    monkeypatch.setenv("SWA_MP_K", K)
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(77, 1, 1300, rtab)
+    res, off = swipe_amd.synth_db(8, 2500, query=q)
+    seqs = [res[off[i]:off[i + 1]] for i in range(2500)] + [q, q[200:900], np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    scores, c = db.search(q)
+    assert np.array_equal(scores, oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS))
+    assert c["wide"] > 0
+    db.close()
+
+
 def test_dual_query_protein_and_custom_matrix():
     """the dual kernel is not nucleotide specific: two protein queries of equal length"""
     q1 = cases.Q375
