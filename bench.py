@@ -99,7 +99,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device per rank (swipe_amd has no CPU path)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SWA_BENCH_FORCE_DIST") == "1"     # the latter: exercise RCCL with one rank
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -115,22 +116,22 @@ def main():
     t_load = time.time() - t0
     nsym = int(off[-1])
     tot_sym = nsym
-    if world > 1:
+    if use_dist:
         t = torch.tensor([nsym], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         tot_sym = int(t.item())
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     st = swipe_amd.stats_init(qlen=len(q), db_seqcount=world * a.nseq, db_symcount=tot_sym)
-    dev = torch.device("cuda", local) if world > 1 else None
+    dev = torch.device("cuda", local) if use_dist else None
 
     def step():
         hits, tot, obv, c = db.search_topk(q, keep=KEEP, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
-        if world > 1:
+        if use_dist:
             hits, tot, obv = parallel.gather_topk(hits, KEEP, tot, obv, device=dev)
         return hits, tot, c
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +145,7 @@ def main():
         kernel_ms.append(c["kernel_ms"])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -199,7 +200,7 @@ def main():
                                        "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     db.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

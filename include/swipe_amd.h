@@ -92,6 +92,10 @@ int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int
                      uint8_t** residues, int64_t** offsets, int64_t* nseq,
                      int64_t* total_seqcount, int64_t* total_symcount, int64_t* longest);
 void swa_free(void* p);
+/* Host-only: first definition line of sequence `seqno` rendered as the reference's db_showheader does
+   for hit lists ("lcl|id title", asnparse.cc:753-887) and the sequence's length. */
+int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
+                        int64_t* seqlen);
 void swa_db_close(swa_db* db);
 
 /* ---- scoring ------------------------------------------------------------------------------ */

@@ -35,7 +35,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
-    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_hits_merge",
+    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_hits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
     "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
@@ -59,6 +59,7 @@ def load():
     L.swa_db_from_memory.argtypes = [vp, vp, i64, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp)]
     L.swa_db_info.argtypes = [vp, C.POINTER(DbInfo)]
     L.swa_blastdb_read.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(vp), C.POINTER(vp), i64p, i64p, i64p, i64p]
+    L.swa_blastdb_defline.argtypes = [C.c_char_p, C.c_int, i64, C.c_char_p, i64, i64p]
     L.swa_free.argtypes = [vp]
     L.swa_free.restype = None
     L.swa_db_close.argtypes = [vp]

@@ -43,7 +43,8 @@ inline uint64_t be64(const uint8_t* p) { return uint64_t(be32(p)) << 32 | be32(p
 
 struct Volume {
   std::string base;
-  Mapped index, seq;
+  Mapped index, seq, hdr;
+  const uint8_t* hdr_off = nullptr;    // big-endian u32 [nseq + 1]
   int64_t nseq = 0, nsym = 0, longest = 0;
   const uint8_t* seq_off = nullptr;    // big-endian u32 [nseq + 1]
   const uint8_t* amb_off = nullptr;    // nucleotide only
@@ -72,6 +73,7 @@ bool open_volume(const std::string& base, bool protein, Volume& v, std::string& 
   v.longest = be32(p + o); o += 4;
   const size_t tab = size_t(v.nseq + 1) * 4;
   if (p + o + tab * (protein ? 2 : 3) > end) { err = "Truncated database index."; return false; }
+  v.hdr_off = p + o;
   v.seq_off = p + o + tab;
   v.amb_off = protein ? nullptr : p + o + 2 * tab;
   return true;
@@ -193,6 +195,186 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
       out.offsets.push_back(int64_t(out.residues.size()));
     }
     vbase += v.nseq;
+  }
+  return SWA_OK;
+}
+
+// ---- definition lines -----------------------------------------------------------------------
+// Minimal BER walker for Blast-def-line-set (reference asnparse.cc:652-887): renders the first
+// def-line of an entry as "<seqids joined by |> <title>".  Seq-id choices follow the tag table at
+// asnparse.cc:657-658.
+namespace {
+struct Ber {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool eoc() const { return p + 1 < end && p[0] == 0 && p[1] == 0; }
+  // reads tag + length; returns content length or -1 for the indefinite form
+  bool head(int& tag, long& len)
+  {
+    if (p >= end) return false;
+    tag = *p++;
+    if (p >= end) return false;
+    int l = *p++;
+    if (l == 0x80) { len = -1; return true; }
+    if (l & 0x80) {
+      int n = l & 0x7f;
+      len = 0;
+      while (n-- && p < end) len = (len << 8) | *p++;
+    } else {
+      len = l;
+    }
+    return true;
+  }
+  // skips one complete element
+  void skip()
+  {
+    int tag; long len;
+    if (!head(tag, len)) { p = end; return; }
+    if (len >= 0) { p += len; return; }
+    while (p < end && !eoc()) skip();
+    p += 2;
+  }
+  std::string str(long len) { std::string s(reinterpret_cast<const char*>(p), size_t(len)); p += len; return s; }
+  long integer(long len) { long v = 0; for (long i = 0; i < len && p < end; ++i) v = (v << 8) | *p++; return v; }
+  void close(long len) { if (len < 0 && eoc()) p += 2; }
+};
+
+std::string object_id(Ber& b)                       // CHOICE { id [0] INTEGER, str [1] VisibleString }
+{
+  int tag; long len;
+  std::string out;
+  if (!b.head(tag, len)) return out;
+  int t2; long l2;
+  if (b.head(t2, l2)) out = (tag == 0xA0) ? std::to_string(b.integer(l2)) : b.str(l2);
+  b.close(len);
+  return out;
+}
+
+std::string seq_id(Ber& b)
+{
+  static const char* const names[] = {"lcl", "bbs", "bbm", "gim", "gb", "emb", "pir", "sp", "pat", "ref",
+                                      "gnl", "gi", "dbj", "prf", "pdb", "tpg", "tpe", "tpd", "gpp", "nat"};
+  int tag; long len;
+  if (!b.head(tag, len)) return std::string();
+  const int choice = tag - 0xA0;
+  const std::string db = (choice >= 0 && choice < 20) ? names[choice] : "unk";
+  std::string out;
+  const uint8_t* stop = len >= 0 ? b.p + len : nullptr;
+  if (choice == 0) {
+    out = db + "|" + object_id(b);
+  } else if (choice == 11 || choice == 1 || choice == 2 || choice == 3) {
+    int t; long l;
+    if (b.head(t, l)) out = db + "|" + std::to_string(b.integer(l));
+  } else if (choice == 10) {                        // Dbtag { db VisibleString, tag Object-id }
+    int t; long l;
+    if (b.head(t, l)) {                             // SEQUENCE
+      int t1; long l1, l1b; int t1b;
+      std::string dbname, tagv;
+      if (b.head(t1, l1)) { if (b.head(t1b, l1b)) dbname = b.str(l1b); b.close(l1); }
+      if (b.head(t1, l1)) { tagv = object_id(b); b.close(l1); }
+      b.close(l);
+      out = db + "|" + dbname + "|" + tagv;
+    }
+  } else {                                          // Textseq-id { name, accession, release, version }
+    int t; long l;
+    std::string name, acc;
+    long version = 0;
+    if (b.head(t, l)) {
+      const uint8_t* sstop = l >= 0 ? b.p + l : nullptr;
+      while (b.p < b.end && (sstop ? b.p < sstop : !b.eoc())) {
+        int ft; long fl;
+        if (!b.head(ft, fl)) break;
+        int it; long il;
+        if (!b.head(it, il)) break;
+        if (ft == 0xA0) name = b.str(il);
+        else if (ft == 0xA1) acc = b.str(il);
+        else if (ft == 0xA3) version = b.integer(il);
+        else b.p += il;
+        b.close(fl);
+      }
+      b.close(l);
+    }
+    out = db + "|" + acc + (version ? "." + std::to_string(version) : std::string()) + "|" + name;
+  }
+  if (stop) b.p = stop; else { while (b.p < b.end && !b.eoc()) b.skip(); b.p += 2; }
+  return out;
+}
+
+std::string first_defline(const uint8_t* p, size_t n)
+{
+  Ber b{p, p + n};
+  int tag; long len;
+  std::string title, ids;
+  if (!b.head(tag, len) || tag != 0x30) return std::string();         // Blast-def-line-set
+  int t2; long l2;
+  if (!b.head(t2, l2) || t2 != 0x30) return std::string();            // first Blast-def-line
+  const uint8_t* stop = l2 >= 0 ? b.p + l2 : nullptr;
+  while (b.p < b.end && (stop ? b.p < stop : !b.eoc())) {
+    int ft; long fl;
+    if (!b.head(ft, fl)) break;
+    if (ft == 0xA0) {                                                  // title
+      int it; long il;
+      if (b.head(it, il)) title = b.str(il);
+      b.close(fl);
+    } else if (ft == 0xA1) {                                           // seqid SEQUENCE OF Seq-id
+      int st; long sl;
+      if (b.head(st, sl)) {
+        const uint8_t* sstop = sl >= 0 ? b.p + sl : nullptr;
+        while (b.p < b.end && (sstop ? b.p < sstop : !b.eoc())) {
+          const std::string id = seq_id(b);
+          if (!ids.empty()) ids += "|";
+          ids += id;
+        }
+        b.close(sl);
+      }
+      b.close(fl);
+    } else {
+      if (fl >= 0) b.p += fl; else { while (b.p < b.end && !b.eoc()) b.skip(); b.p += 2; }
+    }
+  }
+  return ids + (title.empty() ? "" : " " + title);
+}
+}  // namespace
+
+int swa::read_blast_deflines(const char* basename, int symtype, const std::vector<int64_t>& seqnos,
+                             std::vector<std::string>& deflines, std::vector<int64_t>& lengths)
+{
+  const bool protein = symtype == SWA_SYMTYPE_PROTEIN;
+  const std::string base(basename);
+  std::vector<std::string> vols;
+  const std::vector<std::string> top = read_alias(base, protein, nullptr);
+  if (top.empty()) vols.push_back(base);
+  else {
+    const std::string dir = dir_of(base);
+    for (const std::string& n : top) {
+      const std::vector<std::string> nested = read_alias(dir + n, protein, nullptr);
+      if (nested.empty()) vols.push_back(dir + n);
+      else for (const std::string& m : nested) vols.push_back(dir + m);
+    }
+  }
+  std::vector<Volume> V(vols.size());
+  std::string err;
+  for (size_t i = 0; i < vols.size(); ++i) {
+    if (!open_volume(vols[i], protein, V[i], err)) return fail(SWA_EIO, err);
+    if (!V[i].hdr.open(vols[i] + (protein ? ".phr" : ".nhr"))) return fail(SWA_EIO, "Unable to open file " + vols[i] + (protein ? ".phr." : ".nhr."));
+  }
+  deflines.clear();
+  lengths.clear();
+  for (int64_t s : seqnos) {
+    int64_t local = s;
+    const Volume* v = nullptr;
+    for (const Volume& x : V) { if (local < x.nseq) { v = &x; break; } local -= x.nseq; }
+    if (!v || local < 0) return fail(SWA_EINVAL, "Cant find database volume.");
+    const uint64_t h1 = be32(v->hdr_off + 4 * local), h2 = be32(v->hdr_off + 4 * (local + 1));
+    if (h2 < h1 || h2 > v->hdr.n) return fail(SWA_EIO, "corrupt header offsets in " + v->base);
+    deflines.push_back(first_defline(v->hdr.p + h1, size_t(h2 - h1)));
+    const uint64_t o1 = be32(v->seq_off + 4 * local), o2 = be32(v->seq_off + 4 * (local + 1));
+    if (protein) lengths.push_back(o2 > o1 ? int64_t(o2 - o1 - 1) : 0);
+    else {
+      const uint64_t o3 = be32(v->amb_off + 4 * local);
+      const size_t packed = size_t(o3 - o1);
+      lengths.push_back(int64_t(4 * (packed - 1) + (v->seq.p[o1 + packed - 1] & 3)));
+    }
   }
   return SWA_OK;
 }

@@ -1,0 +1,312 @@
+// swipe_amd: command-line driver with SWIPE's options for the searches this library covers
+// (protein -p 1 / blastp and nucleotide -p 0 / blastn), on one MI355X.
+//
+// Mirrors the control flow of the reference's main()/work() (swipe.cc:2436-2611): open the
+// database once, then for every query of the FASTA file: hits_init thresholds, search, hit list,
+// output.  Output formats: -m 7 (the reference's simple XML, reproduced byte for byte when no
+// alignments are requested) and -m 0 (banner, parameter block and the "Sequences producing
+// significant alignments" list).  The traceback/alignment phase (align.cc) is outside this
+// library's scope, so -b is accepted and ignored.  Errors follow the reference: message on
+// stderr, exit(1) (swipe.cc:158-170).
+#include "../../include/swipe_amd.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <getopt.h>
+#include <string>
+#include <vector>
+
+namespace {
+[[noreturn]] void fatal(const std::string& msg)
+{
+  if (!msg.empty()) std::fprintf(stderr, "%s\n", msg.c_str());
+  std::exit(1);
+}
+void check(int rc) { if (rc != SWA_OK) fatal(std::string("swipe_amd: ") + swa_last_error()); }
+
+int aa_code(int c)
+{
+  static const char a[] = "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ";       // query.cc:51-69
+  const char* p = c ? std::strchr(a, std::toupper(c)) : nullptr;
+  return p ? int(p - a) : -1;
+}
+int nt_code(int c)
+{
+  static const char a[] = "-ACMGRSVTWYHKDBN";                   // query.cc:91-109
+  c = std::toupper(c);
+  if (c == 'U') c = 'T';
+  const char* p = (c && c != '-') ? std::strchr(a, c) : nullptr;
+  return p ? int(p - a) : -1;
+}
+
+struct Query { std::string description; std::vector<uint8_t> seq; };
+
+// query_read (query.cc:265-366): '>' line = description, every mapped letter of the following
+// lines is a residue, anything else is skipped
+bool read_query(FILE* f, std::string& pending, bool protein, Query& q)
+{
+  char line[4096];
+  if (pending.empty()) {
+    if (!std::fgets(line, sizeof line, f)) return false;
+    pending = line;
+  }
+  q.description.clear();
+  q.seq.clear();
+  std::string cur = pending;
+  pending.clear();
+  while (!cur.empty() && (cur.back() == '\n' || cur.back() == '\r')) cur.pop_back();
+  bool have = true;
+  if (!cur.empty() && cur[0] == '>') {
+    q.description = cur.substr(1);
+    have = std::fgets(line, sizeof line, f) != nullptr;
+    cur = have ? line : "";
+  }
+  while (have && (cur.empty() || cur[0] != '>')) {
+    for (char c : cur) {
+      const int m = protein ? aa_code((unsigned char)c) : nt_code((unsigned char)c);
+      if (m >= 0) q.seq.push_back(uint8_t(m));
+    }
+    have = std::fgets(line, sizeof line, f) != nullptr;
+    cur = have ? line : "";
+  }
+  if (have) pending = cur;
+  return true;
+}
+
+void show_expect(FILE* out, double e)                        // hits.cc:1177-1197
+{
+  char temp[16];
+  if (e < 1e-180) std::fprintf(out, "0.0  ");
+  else if (e < 9.5e-100) { std::snprintf(temp, sizeof temp, "%-6.0e", e); std::fputs(temp + 1, out); }
+  else if (e < 0.00095) std::fprintf(out, "%-5.0e", e);
+  else if (e < 0.0995) std::fprintf(out, "%-5.3f", e);
+  else if (e < 0.95) std::fprintf(out, "%-5.2f", e);
+  else if (e < 9.5) std::fprintf(out, "%-5.1f", e);
+  else std::fprintf(out, "%5.0f", e);
+}
+
+void usage(const char* prog)
+{
+  std::printf("Usage: %s [OPTIONS]\n", prog);
+  std::printf("  -d, --db=FILE              sequence database base name (required)\n");
+  std::printf("  -i, --query=FILE           query sequence filename (stdin)\n");
+  std::printf("  -M, --matrix=NAME/FILE     score matrix name or filename (BLOSUM62)\n");
+  std::printf("  -q, --penalty=NUM          penalty for nucleotide mismatch (-3)\n");
+  std::printf("  -r, --reward=NUM           reward for nucleotide match (1)\n");
+  std::printf("  -G, --gapopen=NUM          gap open penalty (11)\n");
+  std::printf("  -E, --gapextend=NUM        gap extension penalty (1)\n");
+  std::printf("  -v, --num_descriptions=NUM sequence descriptions to show (250)\n");
+  std::printf("  -b, --num_alignments=NUM   accepted, alignments are not produced (0)\n");
+  std::printf("  -e, --evalue=REAL          maximum expect value of sequences to show (10.0)\n");
+  std::printf("  -k, --minevalue=REAL       minimum expect value of sequences to show (0.0)\n");
+  std::printf("  -c, --min_score=NUM        minimum score of sequences to show (1)\n");
+  std::printf("  -u, --max_score=NUM        maximum score of sequences to show (inf.)\n");
+  std::printf("  -a, --num_threads=NUM      accepted and ignored (one GPU)\n");
+  std::printf("  -m, --outfmt=NUM           output format [0,7=plain,xml] (0)\n");
+  std::printf("  -p, --symtype=NAME/NUM     symbol type [0-1, blastn, blastp] (1)\n");
+  std::printf("  -S, --strand=NAME/NUM      query strands to search [1-3] (3)\n");
+  std::printf("  -o, --out=FILE             output file (stdout)\n");
+  std::printf("  -z, --dbsize=NUM           set effective database size (0)\n");
+  std::printf("  -g, --gpu=NUM              HIP device (0)\n");
+}
+}  // namespace
+
+int main(int argc, char** argv)
+{
+  std::string dbname, queryname = "-", matrixname, outfile;
+  long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
+  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0;
+  double expect = 10.0, minexpect = 0.0;
+  static const option longopts[] = {
+      {"db", 1, 0, 'd'}, {"query", 1, 0, 'i'}, {"matrix", 1, 0, 'M'}, {"penalty", 1, 0, 'q'}, {"reward", 1, 0, 'r'},
+      {"gapopen", 1, 0, 'G'}, {"gapextend", 1, 0, 'E'}, {"num_descriptions", 1, 0, 'v'}, {"num_alignments", 1, 0, 'b'},
+      {"evalue", 1, 0, 'e'}, {"minevalue", 1, 0, 'k'}, {"min_score", 1, 0, 'c'}, {"max_score", 1, 0, 'u'},
+      {"num_threads", 1, 0, 'a'}, {"outfmt", 1, 0, 'm'}, {"symtype", 1, 0, 'p'}, {"strand", 1, 0, 'S'}, {"out", 1, 0, 'o'},
+      {"dbsize", 1, 0, 'z'}, {"gpu", 1, 0, 'g'}, {"help", 0, 0, 'h'}, {0, 0, 0, 0}};
+  int c;
+  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:h", longopts, nullptr)) != -1) {
+    switch (c) {
+      case 'd': dbname = optarg; break;
+      case 'i': queryname = optarg; break;
+      case 'M': matrixname = optarg; break;
+      case 'q': mismatch = std::atol(optarg); break;
+      case 'r': match = std::atol(optarg); break;
+      case 'G': gapopen = std::atol(optarg); break;
+      case 'E': gapextend = std::atol(optarg); break;
+      case 'v': maxmatches = std::atol(optarg); break;
+      case 'b': break;
+      case 'a': break;
+      case 'e': expect = std::atof(optarg); break;
+      case 'k': minexpect = std::atof(optarg); break;
+      case 'c': minscore = std::atol(optarg); break;
+      case 'u': maxscore = std::atol(optarg); break;
+      case 'm': view = std::atol(optarg); break;
+      case 'o': outfile = optarg; break;
+      case 'z': effdbsize = std::atol(optarg); break;
+      case 'g': device = std::atol(optarg); break;
+      case 'S':
+        strands = !std::strcmp(optarg, "plus") ? 1 : !std::strcmp(optarg, "minus") ? 2 : !std::strcmp(optarg, "both") ? 3 : std::atol(optarg);
+        break;
+      case 'p':
+        symtype = !std::strcmp(optarg, "blastn") ? 0 : !std::strcmp(optarg, "blastp") ? 1 : std::atol(optarg);
+        break;
+      default: usage(argv[0]); std::exit(1);
+    }
+  }
+  FILE* out = stdout;
+  if (!outfile.empty() && !(out = std::fopen(outfile.c_str(), "w"))) fatal("Unable to open output file for writing.");
+  // argument rules of args_init (swipe.cc:1088-1161)
+  if (symtype != 0 && symtype != 1) fatal("Illegal symbol type.");   // translated searches: out of scope
+  const bool protein = symtype == 1;
+  if (!protein) {
+    if (gapopen == 0) gapopen = 5;
+    if (gapextend == 0) gapextend = 2;
+  } else {
+    if (matrixname.empty()) matrixname = "BLOSUM62";
+    int64_t go = 0, ge = 0;
+    if (swa_default_gaps(matrixname.c_str(), &go, &ge) == SWA_OK) {
+      if (gapopen == 0) gapopen = long(go);
+      if (gapextend == 0) gapextend = long(ge);
+    } else if (gapopen == 0 && gapextend == 0) {
+      fatal("Unknown score matrix. Gap penalties must be specified (-G and -E).");
+    }
+  }
+  if (effdbsize < 0) fatal("Illegal effective db size specified");
+  if (dbname.empty()) fatal("No database specified.");
+  if (view != 0 && view != 7) fatal("Illegal view type.");
+  if (gapopen < 0 || gapextend < 0 || gapopen + gapextend < 1) fatal("Illegal gap penalties.");
+  if (strands < 1 || strands > 3) fatal("Illegal query strands specified.");
+  if (strands == 2 && protein) fatal("Illegal strand specified for protein query.");
+
+  int64_t M[1024];
+  if (!protein) check(swa_matrix_nucleotide(match, mismatch, M));
+  else if (swa_matrix_builtin(matrixname.c_str(), M) != SWA_OK) {
+    FILE* mf = std::fopen(matrixname.c_str(), "r");
+    if (!mf) fatal("Cannot open score matrix file.");
+    std::string text;
+    char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, mf)) > 0) text.append(buf, n);
+    std::fclose(mf);
+    check(swa_matrix_parse(text.c_str(), M));
+  }
+
+  swa_db* db = nullptr;
+  check(swa_db_open(dbname.c_str(), int(symtype), int(device), 0, -1, &db));
+  swa_db_info_t info;
+  check(swa_db_info(db, &info));
+  check(swa_set_scoring(db, M, gapopen + gapextend, gapextend));
+
+  FILE* qf = queryname == "-" ? stdin : std::fopen(queryname.c_str(), "r");
+  if (!qf) fatal("Cannot open query file.");
+  if (view == 0)
+    std::fprintf(out, "swipe_amd (MI355X) - SWIPE-compatible Smith-Waterman database search\n\n");
+  else
+    std::fprintf(out, "<?xml version=\"1.0\"?>\n");
+
+  std::string pending;
+  Query q;
+  while (read_query(qf, pending, protein, q)) {
+    const int64_t qlen = int64_t(q.seq.size());
+    int64_t keep = maxmatches;                                         // hits.cc:287-315
+    int64_t maxhits = info.seqcount * ((!protein && strands == 3) ? 2 : 1);
+    if (keep > maxhits) keep = maxhits;
+    swa_stats_t st;
+    check(swa_stats_init(int(symtype), matrixname.c_str(), match, mismatch, gapopen, gapextend, qlen,
+                         info.total_seqcount, info.total_symcount, effdbsize, minscore, maxscore, minexpect, expect, &st));
+    std::vector<swa_hit_t> hits(size_t(keep > 0 ? keep : 1));
+    std::vector<int32_t> which(size_t(keep > 0 ? keep : 1), 0);
+    int64_t nhits = 0, total = 0, obvious = 0;
+    swa_counters_t cnt;
+    std::vector<uint8_t> rc;
+    if (!protein) {
+      static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // query.cc:112
+      rc.resize(q.seq.size());
+      for (size_t i = 0; i < q.seq.size(); ++i) rc[i] = compl4[q.seq[q.seq.size() - 1 - i]];
+    }
+    if (protein || strands == 1) {
+      check(swa_search_topk(db, q.seq.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(), &nhits, &total, &obvious, &cnt));
+    } else if (strands == 2) {
+      check(swa_search_topk(db, rc.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(), &nhits, &total, &obvious, &cnt));
+      std::fill(which.begin(), which.end(), 1);
+    } else {
+      check(swa_search2_topk(db, q.seq.data(), rc.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(),
+                             which.data(), &nhits, &total, &obvious, &cnt));
+    }
+    std::vector<int64_t> seqnos;
+    for (int64_t i = 0; i < nhits; ++i) seqnos.push_back(hits[size_t(i)].seqno);
+    std::vector<std::string> deflines;
+    std::vector<int64_t> lengths;
+    for (int64_t s : seqnos) {
+      char buf[4096];
+      int64_t len = 0;
+      check(swa_blastdb_defline(dbname.c_str(), int(symtype), s, buf, sizeof buf, &len));
+      deflines.push_back(buf);
+      lengths.push_back(len);
+    }
+
+    std::string qid = q.description.substr(0, q.description.find(' '));
+    if (view == 7) {                                                  // hits_show_xml, hits.cc:1660-1727
+      std::fprintf(out, "<result>\n  <general>\n    <hitcount>%d</hitcount>\n  </general>\n  <hits>\n", int(nhits));
+      for (int64_t i = 0; i < nhits; ++i) {
+        std::fprintf(out, "    <hit>\n      <hitno>%ld</hitno>\n      <track>%ld</track>\n", long(i + 1), long(hits[size_t(i)].seqno));
+        std::fprintf(out, "      <query>%s</query>\n      <name>%s</name>\n", qid.c_str(), deflines[size_t(i)].c_str());
+        std::fprintf(out, "      <len>%ld</len>\n      <score>%ld</score>\n    </hit>\n", long(lengths[size_t(i)]), long(hits[size_t(i)].score));
+      }
+      std::fprintf(out, "  </hits>\n</result>\n");
+    } else {                                                          // args_show + hits_show_plain
+      std::fprintf(out, "Database file:     %s\n", dbname.c_str());
+      std::fprintf(out, "Database size:     %ld residues in %ld sequences\n", long(info.total_symcount), long(info.total_seqcount));
+      std::fprintf(out, "Longest db seq:    %ld residues\n", long(info.longest));
+      std::fprintf(out, "Query file name:   %s\n", queryname.c_str());
+      std::fprintf(out, "Query length:      %ld residues\n", long(qlen));
+      std::fprintf(out, "Query description: %s\n", q.description.c_str());
+      if (protein) std::fprintf(out, "Score matrix:      %s\n", matrixname.c_str());
+      else std::fprintf(out, "Score matrix:      %ld/%ld\n", match, mismatch);
+      std::fprintf(out, "Gap penalty:       %ld+%ldk\n", gapopen, gapextend);
+      std::fprintf(out, "Max expect shown:  %-g\n", expect);
+      std::fprintf(out, "Min score shown:   %ld\n", minscore);
+      std::fprintf(out, "Max matches shown: %ld\n", maxmatches);
+      std::fprintf(out, "Symbol type:       %s\n\n", protein ? "Amino acid" : "Nucleotide");
+      std::fprintf(out, "Elapsed:           %.4fs (device)\n", cnt.total_ms * 1e-3);
+      std::fprintf(out, "Speed:             %.3f GCUPS\n\n", cnt.total_ms > 0 ? double(cnt.cells) / (cnt.total_ms * 1e-3) / 1e9 : 0.0);
+      if (nhits == 0) {
+        std::fprintf(out, "\nNo hits.\n");
+      } else {
+        if (st.available) {
+          std::fprintf(out, "                                                                 Score    E\n");
+          std::fprintf(out, "Sequences producing significant alignments:                      (bits) Value\n\n");
+        } else {
+          std::fprintf(out, "Sequences producing significant alignments:                         Score\n\n");
+        }
+        const size_t width = protein ? 67 : 65;                       // hits.cc:1815-1822
+        for (int64_t i = 0; i < nhits; ++i) {
+          std::string d = deflines[size_t(i)];
+          if (d.size() > width) { d.resize(width); if (width >= 3) d.replace(width - 3, 3, "..."); }   // asnparse.cc:897-906
+          d.resize(width, ' ');
+          std::fputs(d.c_str(), out);
+          const long score = long(hits[size_t(i)].score);
+          if (!protein) std::fprintf(out, " %c", which[size_t(i)] ? '-' : '+');
+          if (st.available) {
+            const long bits = long(std::floor(st.lambda_d_log2 * score - st.logK_d_log2 + 0.5));   // hits.cc:1848
+            std::fprintf(out, " %5ld", bits);
+            std::fprintf(out, "   ");
+            show_expect(out, swa_evalue(&st, score));
+          } else {
+            std::fprintf(out, " %5ld", score);
+          }
+          std::fputc('\n', out);
+        }
+      }
+      std::fprintf(out, "\n");
+    }
+  }
+  if (qf != stdin) std::fclose(qf);
+  swa_db_close(db);
+  if (out != stdout) std::fclose(out);
+  return 0;
+}

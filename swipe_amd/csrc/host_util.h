@@ -21,5 +21,8 @@ struct HostDb {
 // Mirrors db_open (alias + volumes, database.cc:775-925) and db_getsequence
 // (database.cc:1237-1401) for symtype 0 and 1.  Returns SWA_OK or records an error.
 int read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out);
+// Definition lines ("lcl|id title" style, first defline of each entry) of the given sequences
+int read_blast_deflines(const char* basename, int symtype, const std::vector<int64_t>& seqnos,
+                        std::vector<std::string>& deflines, std::vector<int64_t>& lengths);
 }  // namespace swa
 #endif

@@ -669,6 +669,18 @@ extern "C" int swa_blastdb_read(const char* basename, int symtype, int64_t first
 
 extern "C" void swa_free(void* p) { std::free(p); }
 
+extern "C" int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen, int64_t* seqlen)
+{
+  if (!basename || !buf || buflen < 1) return fail(SWA_EINVAL, "bad argument");
+  std::vector<std::string> d;
+  std::vector<int64_t> len;
+  const int rc = swa::read_blast_deflines(basename, symtype, std::vector<int64_t>{seqno}, d, len);
+  if (rc != SWA_OK) return rc;
+  std::snprintf(buf, size_t(buflen), "%s", d[0].c_str());
+  if (seqlen) *seqlen = len[0];
+  return SWA_OK;
+}
+
 extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
 {
   if (!db || !info) return fail(SWA_EINVAL, "null argument");

@@ -49,6 +49,8 @@ def run(case):
         common += ["-r", str(case.match), "-q", str(case.mismatch)]
     for threads in (1, 8):
         x = subprocess.run(common + ["-a", str(threads), "-m", "7", "-b", "0"], capture_output=True, text=True, check=True)
+        if threads == 1:
+            out["xml"] = x.stdout
         tracks = list(map(int, re.findall(r"<track>(\d+)</track>", x.stdout)))
         scores = list(map(int, re.findall(r"<score>(-?\d+)</score>", x.stdout)))
         t = subprocess.run(common + ["-a", str(threads), "-m", "8", "-b", str(case.keep)], capture_output=True, text=True, check=True)
@@ -61,6 +63,10 @@ def run(case):
                 ev.append(None); bits.append(f[10])
         p = subprocess.run(common + ["-a", str(threads), "-m", "0", "-b", "0"], capture_output=True, text=True, check=True)
         strands = re.findall(r"^lcl\|\S+.*? ([+-]) +\d+ +\S+\s*$", p.stdout, re.M) if not case.protein else []
+        if threads == 1:
+            lines = p.stdout.splitlines()
+            k = next(i for i, l in enumerate(lines) if l.startswith("Sequences producing")) if any(l.startswith("Sequences producing") for l in lines) else None
+            out["plain_hits"] = [l for l in lines[k + 2:] if l.strip()] if k is not None else []
         out["cli"][str(threads)] = {"seqno": tracks, "score": scores, "evalue": ev, "bits": bits, "strand": strands}
     return out
 

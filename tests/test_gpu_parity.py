@@ -290,3 +290,46 @@ def test_nucleotide_scale_both_strands():
         want = oracle.search_all63(r2, o2, qs, Mo, 7, 2, threads=THREADS)
         assert np.array_equal(scores, want)
     db.close()
+
+
+@pytest.mark.parametrize("name", ["p1k", "multivol", "nt", "asym", "edges"])
+def test_cli_output_equals_reference_cli(tmp_path, name):
+    """swipe_amd_cli -m 7 / -m 0 against the reference's own output for the same command line
+    (XML identical except <len>, which the reference leaves unset without alignments; the plain hit
+    list - names, bit scores, E-values, strands - identical line by line)."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    case, g = cases.get(name), load_golden(name)
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    alpha = blastdb.NCBISTDAA if case.protein else blastdb.NCBI4NA
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    args = [exe, "-d", base, "-i", qf, "-p", "1" if case.protein else "0", "-G", str(case.gapopen), "-E", str(case.gapextend),
+            "-v", str(case.keep), "-e", "10", "-b", "0"]
+    if case.protein:
+        mat = case.matrix
+        if mat == "@text":
+            mat = str(tmp_path / "matrix.txt")
+            open(mat, "w").write(case.matrix_text)
+        args += ["-M", mat]
+    else:
+        args += ["-r", str(case.match), "-q", str(case.mismatch)]
+    xml = subprocess.run(args + ["-m", "7"], capture_output=True, text=True, check=True).stdout
+    strip = lambda t: re.sub(r"\s*<len>\d+</len>", "", t)
+    assert strip(xml) == strip(g["xml"])
+    plain = subprocess.run(args + ["-m", "0"], capture_output=True, text=True, check=True).stdout.splitlines()
+    k = next(i for i, l in enumerate(plain) if l.startswith("Sequences producing"))
+    assert [l for l in plain[k + 2:] if l.strip()] == g["plain_hits"]
+
+
+def test_cli_errors_like_the_reference(tmp_path):
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "No database specified." in r.stderr
+    r = subprocess.run([exe, "-d", str(tmp_path / "nosuch"), "-i", "/dev/null"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unable to open file" in r.stderr

@@ -104,10 +104,11 @@ def _bits(x):
 ])
 def test_statistics_bitwise_equal_to_oracle(kw):
     st = swipe_amd.stats_init(expect=10.0, minexpect=1e-250, **kw)
-    h = oracle.HitList(symtype=kw["symtype"], matrix=kw.get("matrix", "BLOSUM62"), match=kw.get("match", 1),
-                       mismatch=kw.get("mismatch", -3), gapopen=kw["gapopen"], gapextend=kw["gapextend"],
-                       qlen=kw["qlen"], dbseqs=kw["db_seqcount"], dbsyms=kw["db_symcount"],
-                       effdbsize=kw.get("effdbsize", 0), expect=10.0, minexpect=1e-250).c
+    keepalive = oracle.HitList(symtype=kw["symtype"], matrix=kw.get("matrix", "BLOSUM62"), match=kw.get("match", 1),
+                               mismatch=kw.get("mismatch", -3), gapopen=kw["gapopen"], gapextend=kw["gapextend"],
+                               qlen=kw["qlen"], dbseqs=kw["db_seqcount"], dbsyms=kw["db_symcount"],
+                               effdbsize=kw.get("effdbsize", 0), expect=10.0, minexpect=1e-250)
+    h = keepalive.c                                    # (the struct is freed with its owner)
     assert st.available == h.stats_available
     if not st.available:
         return
