@@ -15,6 +15,7 @@
      search7 + search16 + fullsw under search_chunk
                         (swipe.h:200-258, swipe.cc:1416-1592)  swa_search
      hits_enter loop + top-K list (hits.cc:163-222)     swa_search_topk / swa_hits_*
+     search16s end points (swipe.h:237-249)             swa_search_endpoints
      hits_init thresholds, E-values (hits.cc:283-511,
                         1777-1779; stats.cc)            swa_stats_init / swa_evalue / swa_bits
 
@@ -126,6 +127,13 @@ int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, i
                      int64_t keep, int64_t minscore, int64_t maxscore, swa_hit_t* hits,
                      int32_t* which, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                      swa_counters_t* counters);
+/* Alignment-phase end points (search16s, swipe.h:237-249; called from align_chunk, swipe.cc:381): for
+   each listed sequence the exact score, the 0-based database column where the final maximum is first
+   reached and the smallest query row holding it in that column (search16s.cc:391-405).  Values equal
+   the reference's whenever its 16-bit lanes do not saturate (score < SCORELIMIT_16, the only case in
+   which it uses them, swipe.cc:404). */
+int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
+                         int64_t* scores, int64_t* bestpos, int64_t* bestq);
 /* Merge per-shard top-K lists (each ordered) into the global top-K with the reference's
    comparator - what the MPI master does with tag_search_report (swipe.cc:1951-1974). */
 int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,

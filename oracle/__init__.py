@@ -38,6 +38,8 @@ def lib():
             f.restype = C.c_long
         L.swo_search16_lane.argtypes = [u8p, C.c_long, u8p, C.c_long, lp, C.c_ushort, C.c_ushort, lp]
         L.swo_search16_lane.restype = C.c_long
+        L.swo_search16s_lane.argtypes = [u8p, C.c_long, u8p, C.c_long, lp, C.c_ushort, C.c_ushort, lp, lp]
+        L.swo_search16s_lane.restype = C.c_long
         L.swo_search_chunk.argtypes = [u8p, i64p, C.c_long, u8p, C.c_long, lp, C.c_long, C.c_long, lp, C.c_void_p]
         L.swo_search_all63.argtypes = [u8p, i64p, C.c_long, u8p, C.c_long, lp, C.c_long, C.c_long, lp, C.c_int]
         L.swo_length_adjustment.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_int)]
@@ -134,6 +136,14 @@ def search16_lane(d, q, M, goe, ge):
     bp = C.c_long()
     s = lib().swo_search16_lane(dp, len(d), qp, len(q), _lp(M), goe & 0xFFFF, ge & 0xFFFF, C.byref(bp))
     return s, bp.value
+
+
+def search16s_lane(d, q, M, goe, ge):
+    d, dp = _u8(d)
+    q, qp = _u8(q)
+    bp, bq = C.c_long(), C.c_long()
+    s = lib().swo_search16s_lane(dp, len(d), qp, len(q), _lp(M), goe & 0xFFFF, ge & 0xFFFF, C.byref(bp), C.byref(bq))
+    return s, bp.value, bq.value
 
 
 def pack(seqs):

@@ -7,14 +7,15 @@
    restatement in sw_oracle.c and to generate tests/golden/*.raw.tsv.
 
    It re-creates only the argument plumbing of the reference's search_init
-   (swipe.cc:1183-1251: dprofile, hearray, qtable[i] = dprofile + 64*qsym) and calls
+   (swipe.cc:1183-1251: dprofile, hearray, qtable[i] = dprofile + 64*qsym; 16*qsym for
+   search16s as in align_init, swipe.cc:202-240) and calls
    search7 / search7_ssse3 / search16 / fullsw exactly as search_chunk does
    (swipe.cc:1432-1585).  Nothing here is shipped or timed.
 
    usage: ref_harness <db> <query.fasta> <symtype 0|1> <matrix|-> <gapopen> <gapextend>
                       [match mismatch]
    output (one line per db sequence and query strand):
-     seqno strand len s7_ssse3 s7_sse2 s16 bestpos16 s63
+     seqno strand len s7_ssse3 s7_sse2 s16 bestpos16 s63 s16s bestpos16s bestq16s
 */
 #include "swipe.h"   /* found via -I/root/reference */
 
@@ -42,6 +43,8 @@ int main(int argc, char** argv)
   if (!query_read()) { fprintf(stderr, "no query\n"); return 1; }
 
   struct db_thread_s* dbt = db_thread_create();
+  struct db_thread_s* dbta[8];
+  for (int i = 0; i < 8; i++) dbta[i] = db_thread_create();
   BYTE* dprofile = (BYTE*) xmalloc(4 * 16 * 32);
 
   int nstrands = symtype == 0 ? 2 : 1;
@@ -58,6 +61,9 @@ int main(int argc, char** argv)
     long* s7b = (long*) xmalloc(n * sizeof(long));
     long* s16 = (long*) xmalloc(n * sizeof(long));
     long* bp16 = (long*) xmalloc(n * sizeof(long));
+    long* s16s = (long*) xmalloc(n * sizeof(long));
+    long* bp16s = (long*) xmalloc(n * sizeof(long));
+    long* bq16s = (long*) xmalloc(n * sizeof(long));
     for (long i = 0; i < n; i++) seqnos[i] = (seqbase + i) << 3;
 
     for (int s = 0; s < nstrands; s++) {
@@ -74,6 +80,14 @@ int main(int argc, char** argv)
       search16((WORD**) qtable, gapopenextend, gapextend, (WORD*) score_matrix_16, (WORD*) dprofile,
                (WORD*) hearray, dbt, n, seqnos, s16, bp16, qlen);
 
+      /* alignment phase layout: one column per block, qtable stride 16 (align_init, swipe.cc:220-240) */
+      BYTE** qtable_s = (BYTE**) xmalloc((qlen > 0 ? qlen : 1) * sizeof(BYTE*));
+      for (long i = 0; i < qlen; i++) qtable_s[i] = dprofile + 16 * q[i];
+      search16s((WORD**) qtable_s, gapopenextend, gapextend, (WORD*) score_matrix_16, (WORD*) dprofile,
+                (WORD*) hearray, dbta, n, seqnos, s16s, bp16s, bq16s, qlen);
+      free(qtable_s);
+      db_mapsequences(dbt, seqbase, seqbase + n - 1);
+
       for (long i = 0; i < n; i++) {
         char* address; long length, ntlen;
         db_getsequence(dbt, seqbase + i, 0, 0, &address, &length, &ntlen, 0);
@@ -81,13 +95,13 @@ int main(int argc, char** argv)
         long s63 = fullsw(address, address + length - 1, q, q + qlen, he63, score_matrix_63,
                           gapopenextend, gapextend);
         free(he63);
-        printf("%ld\t%d\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\n", seqbase + i, s, length - 1,
-               s7a[i], s7b[i], s16[i], bp16[i], s63);
+        printf("%ld\t%d\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\n", seqbase + i, s, length - 1,
+               s7a[i], s7b[i], s16[i], bp16[i], s63, s16s[i], bp16s[i], bq16s[i]);
       }
       free(qtable);
       free(hearray);
     }
-    free(seqnos); free(s7a); free(s7b); free(s16); free(bp16);
+    free(seqnos); free(s7a); free(s7b); free(s16); free(bp16); free(s16s); free(bp16s); free(bq16s);
     seqbase += n;
   }
   return 0;

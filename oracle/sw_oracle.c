@@ -267,6 +267,54 @@ long swo_search16_lane(const unsigned char* dseq, long dlen, const unsigned char
   return (long)(S ^ 0x8000);                           /* search16.cc:462 */
 }
 
+long swo_search16s_lane(const unsigned char* dseq, long dlen, const unsigned char* qseq, long qlen,
+                        const long* M, unsigned short gapopenextend, unsigned short gapextend,
+                        long* bestpos, long* bestq)
+{
+  /* search16s.cc: CDEPTH 1 (line 31), so every column starts with H0 = F0 = Z (INITIALIZE) and the
+     best-cell bookkeeping of 391-405 runs after each column. */
+  const uint16_t Z = 0x8000;
+  const uint16_t Q = gapopenextend, R = gapextend;
+  size_t n = (size_t)(qlen > 0 ? qlen : 1);
+  uint16_t* H = (uint16_t*)malloc(n * sizeof(uint16_t));
+  uint16_t* E = (uint16_t*)malloc(n * sizeof(uint16_t));
+  for (size_t i = 0; i < n; i++) H[i] = E[i] = Z;
+  uint16_t S = Z, SL = Z;
+  long bp = 0, bq = -1;
+  long cols = dlen > 0 ? dlen : 1;                     /* an empty sequence still runs one padded column */
+  for (long j = 0; j < cols; j++) {
+    const unsigned char d = j < dlen ? dseq[j] : 0;
+    uint16_t hd = Z, f = Z;
+    for (long i = 0; i < qlen; i++) {
+      uint16_t n0 = H[i], e = E[i];
+      uint16_t p = (uint16_t)(short)M[((long)d << 5) + qseq[i]];
+      uint16_t h = adds16(hd, p);
+      h = maxs16(h, f);
+      h = maxs16(h, e);
+      S = maxs16(S, h);
+      f = subs16(f, R);
+      e = subs16(e, R);
+      H[i] = h;
+      h = subs16(h, Q);
+      e = maxs16(e, h);
+      f = maxs16(f, h);
+      E[i] = e;
+      hd = n0;
+    }
+    if ((int16_t)S > (int16_t)SL) {
+      bp = j;                                          /* d_best = d_pos - 1 (S cannot rise on the padded column of an empty sequence) */
+      for (long i = qlen - 1; i >= 0; i--)
+        if (H[i] == S) bq = i;
+    }
+    SL = S;
+  }
+  free(H);
+  free(E);
+  if (bestpos) *bestpos = bp;
+  if (bestq) *bestq = bq;
+  return (long)(S ^ 0x8000);
+}
+
 /* ------------------------------------------------------------------ escalation -------- */
 
 void swo_search_chunk(const unsigned char* residues, const int64_t* offsets, long nseq,

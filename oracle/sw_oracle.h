@@ -41,6 +41,13 @@ long swo_search16_lane(const unsigned char* dseq, long dlen, const unsigned char
                        const long* M, unsigned short gapopenextend, unsigned short gapextend,
                        long* bestpos);
 
+/* One lane of search16s (search16s.cc:106-548): as search16 with ONE column per block; *bestpos =
+   0-based column where the final maximum was first reached, *bestq = smallest row holding it in
+   that column (search16s.cc:391-405); (0, -1) if the score never rose above zero. */
+long swo_search16s_lane(const unsigned char* dseq, long dlen, const unsigned char* qseq, long qlen,
+                        const long* M, unsigned short gapopenextend, unsigned short gapextend,
+                        long* bestpos, long* bestq);
+
 /* ---- the per-chunk escalation loop (swipe.cc:1416-1592) ---------------------------- */
 typedef struct {
   long compute7, compute16, compute63;   /* swipe.cc:1426, 1495, 1553 */

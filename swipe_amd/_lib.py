@@ -35,7 +35,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
-    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_hits_merge",
+    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_hits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
     "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
@@ -70,6 +70,7 @@ def load():
     L.swa_search2.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(Counters)]
     L.swa_search2_topk.argtypes = [vp, vp, vp, i64, i64, i64, i64, C.POINTER(Hit), C.POINTER(C.c_int32), i64p, i64p, i64p,
                                    C.POINTER(Counters)]
+    L.swa_search_endpoints.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp]
     L.swa_hits_merge.argtypes = [C.POINTER(Hit), i64p, C.c_int, i64, i64, C.POINTER(Hit), i64p]
     L.swa_stats_init.argtypes = [C.c_int, C.c_char_p, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                                  C.c_double, C.c_double, C.POINTER(Stats)]

@@ -180,6 +180,15 @@ class Database:
         return ([(hits[i].seqno, hits[i].score, which[i]) for i in range(n.value)], tot.value, obv.value,
                 {f: getattr(c, f) for f, _ in c._fields_})
 
+    def search_endpoints(self, query: np.ndarray, seqnos):
+        """(score, bestpos, bestq) per listed sequence - the reference's search16s for the alignment phase."""
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        ids = _i64(seqnos)
+        out = [np.empty(len(ids), dtype=np.int64) for _ in range(3)]
+        _check(_lib.load().swa_search_endpoints(self._h, q.ctypes.data, len(q), ids.ctypes.data, len(ids),
+                                                out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+        return out
+
     def close(self):
         if self._h:
             _lib.load().swa_db_close(self._h)

@@ -367,6 +367,48 @@ swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ sc
   if (lane == 0) { if (total) atomicAdd(&tallies[0], total); if (obvious) atomicAdd(&tallies[1], obvious); }
 }
 
+// ------------------------------------------------------------------ alignment end points
+// search16s (search16s.cc:297-548) for the few sequences of the alignment phase: exact score, the
+// 0-based column where the final maximum is first reached and the smallest row holding it there.
+// One thread per sequence, H/E columns in global scratch ([row][thread], coalesced); at most a few
+// hundred sequences per query, so throughput is irrelevant here.
+extern "C" __global__ void __launch_bounds__(64)
+swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
+                     const int32_t* __restrict__ ids, int n, const uint8_t* __restrict__ qseq, int qlen,
+                     const int32_t* __restrict__ matrix, long long Q, long long R,
+                     long long* __restrict__ Hs, long long* __restrict__ Es,
+                     long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int stride = gridDim.x * blockDim.x;
+  const int64_t o = offsets[ids[t]], len = offsets[ids[t] + 1] - o;
+  for (int i = 0; i < qlen; ++i) { Hs[(int64_t)i * stride + t] = 0; Es[(int64_t)i * stride + t] = 0; }
+  long long S = 0, bp = 0, bq = -1;                       // d_best = d_begin, q_best = -1 (search16s.cc:483-486)
+  for (int64_t j = 0; j < len; ++j) {
+    const int32_t* row = matrix + ((int)residues[o + j] << 5);
+    long long hd = 0, f = 0, cm = 0, cq = -1;
+    for (int i = 0; i < qlen; ++i) {
+      const int64_t a = (int64_t)i * stride + t;
+      const long long n0 = Hs[a];
+      long long e = Es[a];
+      long long h = hd + row[qseq[i]];
+      if (f > h) h = f;
+      if (e > h) h = e;
+      if (h < 0) h = 0;
+      if (h > cm) { cm = h; cq = i; }
+      Hs[a] = h;
+      const long long tt = h - Q;
+      e -= R; if (tt > e) e = tt;
+      f -= R; if (tt > f) f = tt;
+      Es[a] = e;
+      hd = n0;
+    }
+    if (cm > S) { S = cm; bp = j; bq = cq; }
+  }
+  out_score[t] = S; out_pos[t] = bp; out_q[t] = bq;
+}
+
 // ------------------------------------------------------------------ launchers
 template <int K>
 static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStream_t st)
@@ -419,6 +461,16 @@ extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* 
 {
   if (nbatches <= 0) return hipSuccess;
   hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids, int n,
+                                           const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
+                                           long long* Hs, long long* Es, long long* out, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  const int blocks = (n + 63) / 64;
+  hipLaunchKernelGGL(swa_endpoints_kernel, dim3(blocks), dim3(64), 0, st, residues, offsets, ids, n, qseq, qlen, matrix, Q, R,
+                     Hs, Es, out, out + n, out + 2 * (size_t)n);
   return hipGetLastError();
 }
 extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, long long minscore,

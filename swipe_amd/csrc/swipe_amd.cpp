@@ -25,6 +25,9 @@ extern "C" {
 int swa_narrow_rows_for(int qlen);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
+hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids, int n,
+                                const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
+                                long long* Hs, long long* Es, long long* out, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
@@ -866,6 +869,45 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
   std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), cand_before);
   for (size_t i = 0; i < k; ++i) { hits[i] = {cand[i].seqno, cand[i].score}; which[i] = cand[i].which; }
   *nhits = int64_t(k);
+  return SWA_OK;
+}
+
+extern "C" int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
+                                    int64_t* scores, int64_t* bestpos, int64_t* bestq)
+{
+  int rc = check_query(db, query, qlen);
+  if (rc != SWA_OK) return rc;
+  if (n < 0 || (n > 0 && (!seqnos || !scores || !bestpos || !bestq))) return fail(SWA_EINVAL, "bad argument");
+  if (n == 0) return SWA_OK;
+  if (n > (1 << 20)) return fail(SWA_EINVAL, "too many sequences for the alignment phase");
+  std::vector<int32_t> ids((size_t(n)));
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t local = seqnos[i] - db->first_seqno;
+    if (local < 0 || local >= db->nseq) return fail(SWA_EINVAL, "sequence number outside this shard");
+    ids[size_t(i)] = int32_t(local);
+  }
+  HIP_TRY(hipSetDevice(db->device));
+  hipStream_t st = db->stream;
+  const size_t threads = size_t((n + 63) / 64) * 64;
+  DevBuf<int32_t> d_ids;
+  DevBuf<long long> d_h, d_e, d_out;
+  HIP_TRY(d_ids.reserve(size_t(n)));
+  HIP_TRY(d_h.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
+  HIP_TRY(d_e.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
+  HIP_TRY(d_out.reserve(3 * size_t(n)));
+  HIP_TRY(db->qseq.reserve(size_t(qlen > 0 ? qlen : 1)));
+  if (qlen) HIP_TRY(hipMemcpyAsync(db->qseq.p, query, size_t(qlen), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_ids.p, ids.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(swa_launch_endpoints(db->residues.p, db->offsets.p, d_ids.p, int(n), db->qseq.p, int(qlen), db->matrix.p,
+                               db->goe, db->ge, d_h.p, d_e.p, d_out.p, st));
+  std::vector<long long> out(3 * size_t(n));
+  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < n; ++i) {
+    scores[i] = out[size_t(i)];
+    bestpos[i] = out[size_t(n + i)];
+    bestq[i] = out[size_t(2 * n + i)];
+  }
   return SWA_OK;
 }
 

@@ -39,7 +39,7 @@ def run(case):
     raw = [list(map(int, l.split())) for l in lines[1:]]
     out = {"name": case.name, "checksum": case.checksum(), "nseq": len(case.seqs),
            "scorelimit7": int(m.group(1)), "scorelimit16": int(m.group(2)),
-           "raw_columns": ["seqno", "strand", "len", "s7_ssse3", "s7_sse2", "s16", "bestpos16", "s63"],
+           "raw_columns": ["seqno", "strand", "len", "s7_ssse3", "s7_sse2", "s16", "bestpos16", "s63", "s16s", "bestpos16s", "bestq16s"],
            "raw": raw, "cli": {}}
     common = [os.path.join(REF, "swipe"), "-d", base, "-i", qf, "-p", sym, "-G", str(case.gapopen), "-E", str(case.gapextend),
               "-v", str(case.keep), "-e", "10"]

@@ -160,6 +160,21 @@ def test_both_narrow_kernel_forms(monkeypatch, variant, gaps):
     db.close()
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_alignment_end_points_equal_search16s(name):
+    """swa_search_endpoints against the reference's search16s for every sequence it does not saturate on"""
+    case, g = cases.get(name), load_golden(name)
+    db = open_case(case)
+    for strand, q in enumerate(strands(case)):
+        rows = [r for r in g["raw"] if r[1] == strand]
+        sc, bp, bq = db.search_endpoints(q, [r[0] for r in rows])
+        for r, a, b, c in zip(rows, sc, bp, bq):
+            assert a == r[7]
+            if r[8] < g["scorelimit16"]:
+                assert (a, b, c) == (r[8], r[9], r[10])
+    db.close()
+
+
 def test_empty_inputs_and_errors():
     M = swipe_amd.matrix_builtin("BLOSUM62")
     db = swipe_amd.Database.from_sequences([cases.Q375, np.zeros(0, np.uint8)])

@@ -33,11 +33,12 @@ def test_lane_kernels_match_reference_raw_outputs(name):
     goe, ge = case.gapopen + case.gapextend, case.gapextend
     qs = strands(case)
     assert len(g["raw"]) == len(case.seqs) * len(qs)
-    for seqno, strand, length, s7a, s7b, s16, bp16, s63 in g["raw"]:
+    for seqno, strand, length, s7a, s7b, s16, bp16, s63, s16s, bp16s, bq16s in g["raw"]:
         d, q = case.seqs[seqno], qs[strand]
         assert len(d) == length
         assert oracle.search7_lane(d, q, M, goe, ge) == s7a == s7b
         assert oracle.search16_lane(d, q, M, goe, ge) == (s16, bp16)
+        assert oracle.search16s_lane(d, q, M, goe, ge) == (s16s, bp16s, bq16s)
         assert oracle.fullsw(d, q, M, goe, ge) == s63
 
 
@@ -69,7 +70,8 @@ def test_hit_list_rank_evalue_bits_match_cli(name):
               match=case.match, mismatch=case.mismatch, gapopen=case.gapopen, gapextend=case.gapextend,
               qlen=len(case.query), dbseqs=len(case.seqs), dbsyms=nsym)
     h = oracle.HitList(**kw)
-    for seqno, strand, length, s7a, s7b, s16, bp16, s63 in g["raw"]:
+    for row in g["raw"]:
+        seqno, strand, s63 = row[0], row[1], row[7]
         h.enter(seqno, s63, 0, 0, strand, 0)       # nucleotide minus strand enters as dstrand 1 (swipe.cc:1470)
     got = h.hits()
     assert [x[0] for x in got] == cli["seqno"]
