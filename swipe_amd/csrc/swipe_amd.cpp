@@ -163,7 +163,7 @@ int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchS
       const int64_t len = db->h_offsets[id + 1] - db->h_offsets[id];
       if (len > longest) longest = len;
     }
-    const int64_t steps = (longest + 1) & ~int64_t(1);
+    const int64_t steps = std::max<int64_t>(16, (longest + 1) & ~int64_t(1));   // even, and at least one full chunk
     const int64_t nchunks = (steps + 15) / 16;
     if (chunk_total > 0xffffffffull || steps > 0x7ffffff0) return fail(SWA_EINVAL, "residue stream exceeds 2^32 chunks");
     batches[size_t(b)].offset = uint32_t(chunk_total);
@@ -477,7 +477,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
     c.narrow_shifted = 1;
-    HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
+    int blocks = persistent_blocks(db, p.nbatches);
+    if (const char* w = std::getenv("SWA_WAVES")) p.waves = std::atoi(w);
+    if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((p.nbatches + 3) / 4, db->cus * std::atoi(w)));
+    HIP_TRY(swa_launch_narrow(K, &p, blocks, st));
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
