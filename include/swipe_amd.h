@@ -29,6 +29,9 @@
 #ifndef SWIPE_AMD_H
 #define SWIPE_AMD_H
 #include <stdint.h>
+#ifndef SWA_API
+#define SWA_API __attribute__((visibility("default")))
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -69,61 +72,61 @@ typedef struct {
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;
 
-const char* swa_last_error(void);
-int swa_device_count(void);
+SWA_API const char* swa_last_error(void);
+SWA_API int swa_device_count(void);
 
 /* ---- database --------------------------------------------------------------------------- */
 /* Opens BLAST v4 volume(s) `basename` (.pin/.psq or .nin/.nsq, or a .pal/.nal alias) and loads
    the sequences [first_seqno, last_seqno] (last_seqno < 0: to the end) onto `device`,
    re-formatted for the kernels.  Mirrors db_open + db_mapsequences. */
-int swa_db_open(const char* basename, int symtype, int device,
+SWA_API int swa_db_open(const char* basename, int symtype, int device,
                 int64_t first_seqno, int64_t last_seqno, swa_db** out);
 /* Same from host arrays: sequence s = residues[offsets[s] .. offsets[s+1]) in reference symbol
    codes.  total_* describe the whole database when this is one shard of it (pass 0 to use
    the shard's own counts). */
-int swa_db_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq,
+SWA_API int swa_db_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq,
                        int symtype, int device, int64_t first_seqno,
                        int64_t total_seqcount, int64_t total_symcount, swa_db** out);
-int swa_db_info(const swa_db* db, swa_db_info_t* info);
+SWA_API int swa_db_info(const swa_db* db, swa_db_info_t* info);
 /* Host-only: read sequences [first_seqno, last_seqno] of a BLAST v4 database into malloc'ed
    arrays in reference symbol codes (what db_getsequence returns, database.cc:1237-1401:
    protein = NCBIstdaa bytes; nucleotide = 4-bit base masks with ambiguities applied).
    Release both arrays with swa_free.  Needs no GPU. */
-int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
+SWA_API int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
                      uint8_t** residues, int64_t** offsets, int64_t* nseq,
                      int64_t* total_seqcount, int64_t* total_symcount, int64_t* longest);
-void swa_free(void* p);
+SWA_API void swa_free(void* p);
 /* Host-only: first definition line of sequence `seqno` rendered as the reference's db_showheader does
    for hit lists ("lcl|id title", asnparse.cc:753-887) and the sequence's length. */
-int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
+SWA_API int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
                         int64_t* seqlen);
-void swa_db_close(swa_db* db);
+SWA_API void swa_db_close(swa_db* db);
 
 /* ---- scoring ------------------------------------------------------------------------------ */
 /* matrix: 32*32 scores, index (db_symbol << 5) | query_symbol, as score_matrix_63
    (matrices.cc:583-590); gapopenextend = gapopen + gapextend (swipe.cc:1126). */
-int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapopenextend, int64_t gapextend);
+SWA_API int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapopenextend, int64_t gapextend);
 
 /* ---- search --------------------------------------------------------------------------------- */
 /* Exact Smith-Waterman score of `query` (reference symbol codes) against every sequence of the
    shard: scores[s - first_seqno].  `scores` may be NULL (bench: results stay on device). */
-int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores,
+SWA_API int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores,
                swa_counters_t* counters);
 /* The hits_enter loop on device: keeps the `keep` best (score desc, seqno desc) among
    minscore <= score <= maxscore; *totalhits counts scores >= minscore, *obvious counts scores
    > maxscore (hits.cc:174-178).  hits[] receives *nhits entries, already ordered. */
-int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep,
+SWA_API int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep,
                     int64_t minscore, int64_t maxscore, swa_hit_t* hits, int64_t* nhits,
                     int64_t* totalhits, int64_t* obvious, swa_counters_t* counters);
 /* Two queries of EQUAL length in one pass over the shard (both halves of the packed lanes see
    the same database residue).  The nucleotide search of the reference is exactly this: the plus
    strand and the reverse-complemented query against the same database (swipe.cc:1403-1411,
    hits entered with dstrand = 1 for the second, swipe.cc:1470-1471). */
-int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
+SWA_API int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
                 int64_t* scores1, int64_t* scores2, swa_counters_t* counters);
 /* hits of both queries in one list; which[i] = 0 / 1 tells the query (strand) of hits[i]; on equal
    score and seqno the entry of query 1 comes first, as in the reference's insertion order */
-int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
+SWA_API int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
                      int64_t keep, int64_t minscore, int64_t maxscore, swa_hit_t* hits,
                      int32_t* which, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                      swa_counters_t* counters);
@@ -132,11 +135,11 @@ int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, i
    reached and the smallest query row holding it in that column (search16s.cc:391-405).  Values equal
    the reference's whenever its 16-bit lanes do not saturate (score < SCORELIMIT_16, the only case in
    which it uses them, swipe.cc:404). */
-int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
+SWA_API int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
                          int64_t* scores, int64_t* bestpos, int64_t* bestq);
 /* Merge per-shard top-K lists (each ordered) into the global top-K with the reference's
    comparator - what the MPI master does with tag_search_report (swipe.cc:1951-1974). */
-int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
+SWA_API int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
                    int64_t keep, swa_hit_t* out, int64_t* nout);
 
 /* ---- statistics (host arithmetic, bit-exact with hits.cc/stats.cc) ------------------------- */
@@ -147,18 +150,18 @@ typedef struct {
   int64_t lenadj, m, n;
   int64_t scorethreshold, upperscorethreshold;   /* after the E-value cut, hits.cc:486-508 */
 } swa_stats_t;
-int swa_stats_init(int symtype, const char* matrixname, int64_t match, int64_t mismatch,
+SWA_API int swa_stats_init(int symtype, const char* matrixname, int64_t match, int64_t mismatch,
                    int64_t gapopen, int64_t gapextend, int64_t qlen,
                    int64_t db_seqcount, int64_t db_symcount, int64_t effdbsize,
                    int64_t minscore, int64_t maxscore, double minexpect, double expect,
                    swa_stats_t* out);
-double swa_evalue(const swa_stats_t* st, int64_t score);   /* hits.cc:1777 */
-double swa_bits(const swa_stats_t* st, int64_t score);     /* hits.cc:1779 */
+SWA_API double swa_evalue(const swa_stats_t* st, int64_t score);   /* hits.cc:1777 */
+SWA_API double swa_bits(const swa_stats_t* st, int64_t score);     /* hits.cc:1779 */
 /* Built-in matrices by name (matrices.cc:540-559); returns SWA_EINVAL for unknown names. */
-int swa_matrix_builtin(const char* name, int64_t* matrix);
-int swa_matrix_nucleotide(int64_t match, int64_t mismatch, int64_t* matrix);
-int swa_matrix_parse(const char* text, int64_t* matrix);
-int swa_default_gaps(const char* matrixname, int64_t* gapopen, int64_t* gapextend);
+SWA_API int swa_matrix_builtin(const char* name, int64_t* matrix);
+SWA_API int swa_matrix_nucleotide(int64_t match, int64_t mismatch, int64_t* matrix);
+SWA_API int swa_matrix_parse(const char* text, int64_t* matrix);
+SWA_API int swa_default_gaps(const char* matrixname, int64_t* gapopen, int64_t* gapextend);
 
 #ifdef __cplusplus
 }
