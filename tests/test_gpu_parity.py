@@ -143,7 +143,7 @@ def test_every_rows_per_lane_variant(qlen):
 
 
 @pytest.mark.parametrize("variant", ["1", "2"])
-@pytest.mark.parametrize("gaps", [(11, 1), (5, 2), (0, 3), (14, 4)])
+@pytest.mark.parametrize("gaps", [(11, 1), (5, 2), (0, 3), (14, 4), (30, 20)])
 def test_both_narrow_kernel_forms(monkeypatch, variant, gaps):
     """plain (SWA_NARROW_VARIANT=1) and row-shifted (=2) packed-f16 kernels, several gap systems"""
     monkeypatch.setenv("SWA_NARROW_VARIANT", variant)
