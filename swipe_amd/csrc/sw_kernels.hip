@@ -97,14 +97,15 @@ swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restric
 template <int K>
 __device__ __forceinline__ void build_profile_f16(unsigned char* lds, const swa_query* q, float add)
 {
-  constexpr int C = K / 8;
+  constexpr int C = (K + 7) / 8;                       // 16-byte units per (residue, lane); the last may be half used
   unsigned short* t = (unsigned short*)lds;
   const int total = 32 * C * 16 * 8;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int k = e & 7, l = (e >> 3) & 15, c = (e >> 7) % C, d = (e >> 7) / C;
-    const int row = l * K + c * 8 + k;
+    const int local = c * 8 + k;
+    const int row = l * K + local;
     float v = -1.0f;                                   // padding rows / PAD residue: any value <= 0
-    if (row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
+    if (local < K && row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
     t[e] = (unsigned short)float_to_half_bits(v + add);
   }
 }
@@ -143,7 +144,7 @@ template <int K>
 __global__ void __launch_bounds__(256)
 swa_narrow_kernel(swa_narrow_params p)
 {
-  constexpr int C = K / 8;
+  constexpr int C = (K + 7) / 8;
   constexpr u32 CS = C * 256;                            // LDS bytes per residue
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   build_profile_f16<K>(lds, p.query, 0.0f);
@@ -244,7 +245,7 @@ template <int K, int W>
 __global__ void __launch_bounds__(256, W)
 swa_narrow_shifted_kernel(swa_narrow_params p)
 {
-  constexpr int C = K / 8;
+  constexpr int C = (K + 7) / 8;
   constexpr u32 CS = C * 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   build_profile_f16<K>(lds, p.query, p.gapextend_f);
@@ -413,7 +414,7 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
 template <int K>
 static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
-  const size_t lds = (size_t)32 * (K / 8) * 256;
+  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
   hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(swa_narrow_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
@@ -422,7 +423,7 @@ static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStrea
 template <int K, int W>
 static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
-  const size_t lds = (size_t)32 * (K / 8) * 256;
+  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
   hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted_kernel<K, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
@@ -430,27 +431,41 @@ static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, 
 }
 extern "C" int swa_narrow_rows_for(int qlen)
 {
-  static const int ks[] = {8, 16, 24, 32, 40, 48, 64};
-  for (int k : ks) if (qlen <= 16 * k) return k;
-  return 0;
+  // rows per lane: multiples of 4 up to 48 for the row-shifted kernel (16 K rows per pass), 64 for the plain one
+  const int k = 4 * ((qlen + 63) / 64);
+  if (k <= 0) return 4;
+  if (k <= 48) return k;
+  return qlen <= 1024 ? 64 : 0;
 }
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
   if (p->shifted) switch (K) {
+    case 4:  return launch_narrow_shifted<4, 8>(*p, blocks, st);
     case 8:  return launch_narrow_shifted<8, 8>(*p, blocks, st);
+    case 12: return launch_narrow_shifted<12, 6>(*p, blocks, st);
     case 16: return launch_narrow_shifted<16, 4>(*p, blocks, st);
-    case 24: return p->waves == 3 ? launch_narrow_shifted<24, 3>(*p, blocks, st) : p->waves == 2 ? launch_narrow_shifted<24, 2>(*p, blocks, st) : launch_narrow_shifted<24, 4>(*p, blocks, st);
+    case 20: return launch_narrow_shifted<20, 4>(*p, blocks, st);
+    case 24: return p->waves == 4 ? launch_narrow_shifted<24, 4>(*p, blocks, st) : launch_narrow_shifted<24, 3>(*p, blocks, st);
+    case 28: return launch_narrow_shifted<28, 3>(*p, blocks, st);
     case 32: return launch_narrow_shifted<32, 3>(*p, blocks, st);
+    case 36: return launch_narrow_shifted<36, 2>(*p, blocks, st);
     case 40: return launch_narrow_shifted<40, 2>(*p, blocks, st);
+    case 44: return launch_narrow_shifted<44, 2>(*p, blocks, st);
     case 48: return launch_narrow_shifted<48, 2>(*p, blocks, st);
     default: return hipErrorInvalidValue;
   }
   switch (K) {
+    case 4:  return launch_narrow<4>(*p, blocks, st);
     case 8:  return launch_narrow<8>(*p, blocks, st);
+    case 12: return launch_narrow<12>(*p, blocks, st);
     case 16: return launch_narrow<16>(*p, blocks, st);
+    case 20: return launch_narrow<20>(*p, blocks, st);
     case 24: return launch_narrow<24>(*p, blocks, st);
+    case 28: return launch_narrow<28>(*p, blocks, st);
     case 32: return launch_narrow<32>(*p, blocks, st);
+    case 36: return launch_narrow<36>(*p, blocks, st);
     case 40: return launch_narrow<40>(*p, blocks, st);
+    case 44: return launch_narrow<44>(*p, blocks, st);
     case 48: return launch_narrow<48>(*p, blocks, st);
     case 64: return launch_narrow<64>(*p, blocks, st);
   }

@@ -156,7 +156,7 @@ def test_both_narrow_kernel_forms(monkeypatch, variant, gaps):
     scores, c = db.search(q)
     want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), gaps[0] + gaps[1], gaps[1], threads=THREADS)
     assert np.array_equal(scores, want)
-    assert c["narrow"] == len(seqs)
+    assert c["narrow"] == (len(seqs) if gaps[1] <= 16 else 0)      # extension 20: f16 range too small, 32 bit throughout
     db.close()
 
 

@@ -6,13 +6,13 @@ import swipe_amd
 from swipe_amd import synth
 nseq = 1_000_000
 rtab = synth.residue_table_protein()
-for qlen in (100, 128, 200, 256, 375, 384, 450, 512, 640, 768):
+for qlen in (50, 64, 100, 128, 200, 256, 300, 375, 450, 512, 600, 700, 768):
     q = synth._random_residues(7, 1, qlen, rtab)
     res, off = swipe_amd.synth_db(1, nseq, query=q)
     db = swipe_amd.Database.from_arrays(res, off)
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     out = []
-    for force in ("0", "1"):
+    for force in ("0",):
         os.environ["SWA_FORCE_MP"] = force
         best = 1e9
         for _ in range(2):
