@@ -59,6 +59,9 @@ def lib():
         L.swo_hits_bits.argtypes = [C.POINTER(Hits), C.c_long]
         L.swo_hits_bits.restype = C.c_double
         L.swo_hits_free.argtypes = [C.POINTER(Hits)]
+        L.swo_align.argtypes = [u8p, C.c_long, u8p, C.c_long, lp, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long,
+                                C.c_void_p, C.c_char_p, C.c_long]
+        L.swo_align.restype = C.c_long
         _LIB = L
     return _LIB
 
@@ -144,6 +147,21 @@ def search16s_lane(d, q, M, goe, ge):
     bp, bq = C.c_long(), C.c_long()
     s = lib().swo_search16s_lane(dp, len(d), qp, len(q), _lp(M), goe & 0xFFFF, ge & 0xFFFF, C.byref(bp), C.byref(bq))
     return s, bp.value, bq.value
+
+
+def align(q, d, M, gapopen, gapextend, hint=None):
+    """align() of the reference as hits_align calls it; hint = (score, q_end, d_end) or None.
+    Returns (score, q_start, d_start, q_end, d_end, cigar) or None for the internal-error case."""
+    d, dp = _u8(d)
+    q, qp = _u8(q)
+    res = (C.c_long * 5)()
+    room = 16 * (len(q) + len(d)) + 64
+    buf = C.create_string_buffer(room)
+    hs, hq, hd = hint if hint else (0, 0, 0)
+    n = lib().swo_align(qp, len(q), dp, len(d), _lp(M), gapopen, gapextend, hs, hq, hd, C.addressof(res), buf, room)
+    if n < 0:
+        return None
+    return res[4], res[0], res[1], res[2], res[3], buf.value.decode()
 
 
 def pack(seqs):

@@ -13,9 +13,14 @@
    (swipe.cc:1432-1585).  Nothing here is shipped or timed.
 
    usage: ref_harness <db> <query.fasta> <symtype 0|1> <matrix|-> <gapopen> <gapextend>
-                      [match mismatch]
+                      [match mismatch [align]]
    output (one line per db sequence and query strand):
      seqno strand len s7_ssse3 s7_sse2 s16 bestpos16 s63 s16s bestpos16s bestq16s
+   with the trailing word "align", additionally one line per (sequence, database strand) whose
+   score is positive, from the reference's alignment phase run as align_chunk/hits_align do
+   (swipe.cc:339-414, hits.cc:546-618): search16s end points of the PLUS query against the
+   (reverse-complemented for strand 1) database sequence, then align() without and with them:
+     A seqno dstrand s16s bestpos bestq | score qstart dstart qend dend cigar | same with hints or "-"
 */
 #include "swipe.h"   /* found via -I/root/reference */
 
@@ -99,6 +104,41 @@ int main(int argc, char** argv)
                s7a[i], s7b[i], s16[i], bp16[i], s63, s16s[i], bp16s[i], bq16s[i]);
       }
       free(qtable);
+      free(hearray);
+    }
+    if (argc > 9 && !strcmp(argv[9], "align")) {
+      char* q = symtype == 0 ? query.nt[0].seq : query.aa[0].seq;
+      long qlen = symtype == 0 ? query.nt[0].len : query.aa[0].len;
+      BYTE** qtable_s = (BYTE**) xmalloc((qlen > 0 ? qlen : 1) * sizeof(BYTE*));
+      for (long i = 0; i < qlen; i++) qtable_s[i] = dprofile + 16 * q[i];
+      BYTE* hearray = (BYTE*) xmalloc((qlen > 0 ? qlen : 1) * 32);
+      for (int ds = 0; ds < nstrands; ds++) {
+        for (long i = 0; i < n; i++) seqnos[i] = ((seqbase + i) << 3) | (ds << 2);
+        search16s((WORD**) qtable_s, gapopenextend, gapextend, (WORD*) score_matrix_16, (WORD*) dprofile,
+                  (WORD*) hearray, dbta, n, seqnos, s16s, bp16s, bq16s, qlen);
+        db_mapsequences(dbt, seqbase, seqbase + n - 1);
+        for (long i = 0; i < n; i++) {
+          char* address; long length, ntlen;
+          db_getsequence(dbt, seqbase + i, ds, 0, &address, &length, &ntlen, 0);
+          long dlen = length - 1;
+          if (s16s[i] <= 0 || qlen == 0 || dlen == 0) continue;
+          long qs = 0, dst = 0, qe = 0, de = 0, sc = 0;
+          char* aln = 0;
+          align(q, address, qlen, dlen, score_matrix_63, gapopen, gapextend, &qs, &dst, &qe, &de, &aln, &sc);
+          printf("A\t%ld\t%d\t%ld\t%ld\t%ld\t|\t%ld\t%ld\t%ld\t%ld\t%ld\t%s\t|", seqbase + i, ds, s16s[i], bp16s[i], bq16s[i],
+                 sc, qs, dst, qe, de, aln);
+          free(aln);
+          if (s16s[i] < SCORELIMIT_16 && bq16s[i] > 0 && bp16s[i] != 0) {      /* hits.cc:587 */
+            qs = dst = 0; qe = bq16s[i]; de = bp16s[i]; sc = s16s[i];
+            align(q, address, qlen, dlen, score_matrix_63, gapopen, gapextend, &qs, &dst, &qe, &de, &aln, &sc);
+            printf("\t%ld\t%ld\t%ld\t%ld\t%ld\t%s\n", sc, qs, dst, qe, de, aln);
+            free(aln);
+          } else {
+            printf("\t-\n");
+          }
+        }
+      }
+      free(qtable_s);
       free(hearray);
     }
     free(seqnos); free(s7a); free(s7b); free(s16); free(bp16); free(s16s); free(bp16s); free(bq16s);

@@ -547,3 +547,185 @@ void swo_hits_free(swo_hits* h)
 {
   if (h) { free(h->list); free(h); }
 }
+
+/* ===== alignment phase: end points -> start points -> edit script =====================
+   Restates align.cc (region 38-164, diff 236-467, align 469-519): the local alignment is
+   delimited by a forward pass (or by the search16s hint) and a backward pass, then spelled
+   out by the linear-space divide-and-conquer of Myers & Miller with the reference's tie rules.
+   q = gap open, r = gap extend (a gap of k symbols costs q + k*r), M index (d << 5) + qsym. */
+typedef struct { char* text; long used, room; char kind; long run; } script_t;
+
+static void script_flush(script_t* s)                       /* push(), align.cc:184-207 */
+{
+  if (s->run <= 0) return;
+  if (s->room - s->used < 32) {
+    s->room = 2 * s->room + 64;
+    s->text = (char*) realloc(s->text, (size_t) s->room);
+  }
+  s->used += sprintf(s->text + s->used, "%c%ld", s->kind, s->run);
+}
+static void script_add(script_t* s, char kind, long n)      /* newop(), align.cc:209-219 */
+{
+  if (s->kind == kind) { s->run += n; return; }
+  script_flush(s);
+  s->kind = kind;
+  s->run = n;
+}
+
+typedef struct {
+  const unsigned char *a, *b;    /* a = query, b = database sequence */
+  const long* M;
+  long q, r;
+  script_t* out;
+} mm_ctx;
+
+static inline long mm_sub(const mm_ctx* c, long ai, long bj) { return c->M[((long) c->b[bj] << 5) + c->a[ai]]; }
+static inline long max2(long x, long y) { return x > y ? x : y; }
+
+/* One sweep of `rows` query rows over `n` database columns with a global (no zero floor) affine
+   recurrence whose first-column gap was opened at cost `edge` (align.cc:341-373 forward,
+   381-414 reverse).  dir = +1 walks a0+0.., b0+0..; dir = -1 walks from the far ends back.
+   best[j] = best score ending anywhere, gapd[j] = best score ending in a gap in the query rows. */
+static void mm_sweep(const mm_ctx* c, long a0, long b0, long rows_total, long n, long rows, int dir, long edge,
+                     long* best, long* gapd)
+{
+  long t = -c->q;
+  best[0] = 0;
+  for (long j = 1; j <= n; j++) { t -= c->r; best[j] = t; gapd[j] = t - c->q; }
+  t = -edge;
+  for (long i = 1; i <= rows; i++) {
+    long diag = best[0];
+    t -= c->r;
+    long h = t, f = t - c->q;
+    best[0] = t;
+    const long ai = dir > 0 ? a0 + i - 1 : a0 + rows_total - i;
+    for (long j = 1; j <= n; j++) {
+      const long bj = dir > 0 ? b0 + j - 1 : b0 + n - j;
+      f = max2(f, h - c->q) - c->r;
+      gapd[j] = max2(gapd[j], best[j] - c->q) - c->r;
+      h = diag + mm_sub(c, ai, bj);
+      if (f > h) h = f;
+      if (gapd[j] > h) h = gapd[j];
+      diag = best[j];
+      best[j] = h;
+    }
+  }
+  gapd[0] = best[0];
+}
+
+/* diff(), align.cc:236-467.  m query symbols from a0 against n database symbols from b0; lead /
+   trail = what opening a query-side gap costs at the left / right edge (0 when one is already open) */
+static void mm_solve(const mm_ctx* c, long a0, long b0, long m, long n, long lead, long trail)
+{
+  if (n == 0) { if (m > 0) script_add(c->out, 'D', m); return; }
+  if (m == 0) { script_add(c->out, 'I', n); return; }
+  if (m == 1) {                                              /* align.cc:260-328 */
+    long top, at;
+    if (lead <= trail) { top = -lead - (1 + n) * c->r - c->q; at = -1; }
+    else               { top = -c->q - (1 + n) * c->r - trail; at = n; }
+    for (long j = 0; j < n; j++) {
+      long v = mm_sub(c, a0, b0 + j) - c->r * (n - 1);
+      if (j > 0) v -= c->q;
+      if (j < n - 1) v -= c->q;
+      if (v > top) { top = v; at = j; }
+    }
+    if (at == -1) { script_add(c->out, 'D', 1); script_add(c->out, 'I', n); }
+    else if (at == n) { script_add(c->out, 'I', n); script_add(c->out, 'D', 1); }
+    else {
+      if (at > 0) script_add(c->out, 'I', at);
+      script_add(c->out, 'M', 1);
+      if (at < n - 1) script_add(c->out, 'I', n - 1 - at);
+    }
+    return;
+  }
+  const long half = m / 2;
+  long* buf = (long*) malloc((size_t) (4 * (n + 1)) * sizeof(long));
+  long *fh = buf, *fe = buf + (n + 1), *rh = buf + 2 * (n + 1), *re = buf + 3 * (n + 1);
+  mm_sweep(c, a0, b0, m, n, half, +1, lead, fh, fe);
+  mm_sweep(c, a0, b0, m, n, m - half, -1, trail, rh, re);
+  long top = 0, cut = -1;
+  int through_gap = -1;
+  for (long j = 0; j <= n; j++) {                            /* align.cc:419-432: first strict maximum */
+    const long v = fh[j] + rh[n - j];
+    if (through_gap < 0 || v > top) { top = v; cut = j; through_gap = 0; }
+  }
+  for (long j = 0; j <= n; j++) {                            /* align.cc:437-446: last >= wins */
+    const long v = fe[j] + re[n - j] + c->q;
+    if (v >= top) { top = v; cut = j; through_gap = 1; }
+  }
+  free(buf);
+  if (!through_gap) {
+    mm_solve(c, a0, b0, half, cut, lead, c->q);
+    mm_solve(c, a0 + half, b0 + cut, m - half, n - cut, c->q, trail);
+  } else {
+    mm_solve(c, a0, b0, half - 1, cut, lead, 0);
+    script_add(c->out, 'D', 2);
+    mm_solve(c, a0 + half + 1, b0 + cut, m - half - 1, n - cut, 0, trail);
+  }
+}
+
+long swo_align(const unsigned char* qseq, long qlen, const unsigned char* dseq, long dlen, const long* M,
+               long gapopen, long gapextend, long hint_score, long hint_q_end, long hint_d_end,
+               swo_alignment* res, char* cigar, long cigar_room)
+{
+  const long q = gapopen, r = gapextend;
+  long score = 0, qe = hint_q_end, de = hint_d_end;
+  long* hh = (long*) malloc((size_t) (dlen > 0 ? dlen : 1) * sizeof(long));
+  long* ee = (long*) malloc((size_t) (dlen > 0 ? dlen : 1) * sizeof(long));
+  if (hint_score) {
+    score = hint_score;                                      /* align.cc:62-65 */
+  } else {                                                   /* align.cc:70-106 */
+    for (long j = 0; j < dlen; j++) { hh[j] = 0; ee[j] = -q; }
+    for (long i = 0; i < qlen; i++) {
+      long h = 0, diag = 0, f = -q;
+      for (long j = 0; j < dlen; j++) {
+        f = max2(f, h - q) - r;
+        ee[j] = max2(ee[j], hh[j] - q) - r;
+        h = diag + M[((long) dseq[j] << 5) + qseq[i]];
+        if (h < 0) h = 0;
+        if (f > h) h = f;
+        if (ee[j] > h) h = ee[j];
+        diag = hh[j];
+        hh[j] = h;
+        if (h > score) { score = h; qe = i; de = j; }
+      }
+    }
+  }
+  /* backward pass from the end cell until the score is recovered, align.cc:111-154 */
+  long qs = -1, ds = -1, found = 0, cost = 0;
+  if (qe < qlen && de < dlen) {
+    for (long j = de; j >= 0; j--) hh[j] = ee[j] = -1;
+    for (long i = qe; i >= 0 && !found; i--) {
+      long h = -1, f = -1, diag = (i == qe) ? 0 : -1;
+      for (long j = de; j >= 0; j--) {
+        f = max2(f, h - q) - r;
+        ee[j] = max2(ee[j], hh[j] - q) - r;
+        h = diag + M[((long) dseq[j] << 5) + qseq[i]];
+        if (f > h) h = f;
+        if (ee[j] > h) h = ee[j];
+        diag = hh[j];
+        hh[j] = h;
+        if (h > cost) {
+          cost = h; qs = i; ds = j;
+          if (cost >= score) { found = 1; break; }
+        }
+      }
+    }
+  }
+  free(hh);
+  free(ee);
+  if (!found) return -1;                                     /* "Internal error in align function." */
+  script_t s = {0, 0, 0, 0, 0};
+  mm_ctx c = {qseq, dseq, M, q, r, &s};
+  mm_solve(&c, qs, ds, qe - qs + 1, de - ds + 1, q, q);      /* align.cc:502-513 */
+  script_flush(&s);
+  res->q_start = qs; res->d_start = ds; res->q_end = qe; res->d_end = de; res->score = score;
+  long n = s.used;
+  if (cigar && cigar_room > 0) {
+    long k = n < cigar_room - 1 ? n : cigar_room - 1;
+    if (s.text) memcpy(cigar, s.text, (size_t) k);
+    cigar[k] = 0;
+  }
+  free(s.text);
+  return n;
+}

@@ -90,6 +90,18 @@ double swo_hits_expect(const swo_hits* h, long score);   /* Kmn * exp(-lambda*sc
 double swo_hits_bits(const swo_hits* h, long score);     /* lambda/ln2*score - lnK/ln2 */
 void swo_hits_free(swo_hits* h);
 
+/* ---- alignment phase (align.cc:38-519 as called from hits_align, hits.cc:546-618) ---------- */
+typedef struct { long q_start, d_start, q_end, d_end, score; } swo_alignment;
+/* gapopen/gapextend as passed by hits_align (NOT open+extend).  hint_score != 0: trust
+   (hint_q_end, hint_d_end) as the end cell (the search16s result, hits.cc:587-596); otherwise the
+   forward pass finds score and end (first strict maximum in query-row-major order).  Writes the
+   edit script ("M12D2I1...", D = query symbol against a gap, I = database symbol against a gap)
+   NUL-terminated into cigar; returns its full length, or -1 where the reference would stop with
+   "Internal error in align function." */
+long swo_align(const unsigned char* qseq, long qlen, const unsigned char* dseq, long dlen, const long* M,
+               long gapopen, long gapextend, long hint_score, long hint_q_end, long hint_d_end,
+               swo_alignment* res, char* cigar, long cigar_room);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,15 +32,26 @@ def run(case):
         open(mat, "w").write(case.matrix_text)
     sym = "1" if case.protein else "0"
     h = subprocess.run([os.path.join(REF, "ref_harness"), base, qf, sym, mat if case.protein else "-",
-                        str(case.gapopen), str(case.gapextend), str(case.match), str(case.mismatch)],
+                        str(case.gapopen), str(case.gapextend), str(case.match), str(case.mismatch), "align"],
                        capture_output=True, text=True, check=True)
     lines = h.stdout.splitlines()
     m = re.match(r"# SCORELIMIT_7=(-?\d+) SCORELIMIT_16=(-?\d+)", lines[0])
-    raw = [list(map(int, l.split())) for l in lines[1:]]
+    raw = [list(map(int, l.split())) for l in lines[1:] if not l.startswith("A\t")]
+    align = []
+    for l in lines[1:]:
+        if not l.startswith("A\t"):
+            continue
+        f = l.split("\t")
+        row = [int(x) for x in f[1:6]] + [int(x) for x in f[7:12]] + [f[12]]
+        row.append(None if f[14] == "-" else [int(x) for x in f[14:19]] + [f[19]])
+        align.append(row)
     out = {"name": case.name, "checksum": case.checksum(), "nseq": len(case.seqs),
            "scorelimit7": int(m.group(1)), "scorelimit16": int(m.group(2)),
            "raw_columns": ["seqno", "strand", "len", "s7_ssse3", "s7_sse2", "s16", "bestpos16", "s63", "s16s", "bestpos16s", "bestq16s"],
-           "raw": raw, "cli": {}}
+           "raw": raw,
+           "align_columns": ["seqno", "dstrand", "s16s", "bestpos", "bestq", "score", "q_start", "d_start", "q_end", "d_end", "cigar",
+                             "with_hint [score, q_start, d_start, q_end, d_end, cigar] or null"],
+           "align": align, "cli": {}}
     common = [os.path.join(REF, "swipe"), "-d", base, "-i", qf, "-p", sym, "-G", str(case.gapopen), "-E", str(case.gapextend),
               "-v", str(case.keep), "-e", "10"]
     if case.protein:
@@ -49,11 +60,25 @@ def run(case):
         common += ["-r", str(case.match), "-q", str(case.mismatch)]
     for threads in (1, 8):
         x = subprocess.run(common + ["-a", str(threads), "-m", "7", "-b", "0"], capture_output=True, text=True, check=True)
+        nalign = min(case.keep, 30)
+        xa = subprocess.run(common + ["-a", str(threads), "-m", "7", "-b", str(nalign)], capture_output=True, text=True, check=True).stdout
+        pa = subprocess.run(common + ["-a", str(threads), "-m", "0", "-b", str(nalign)], capture_output=True, text=True, check=True).stdout
+        pa = pa[pa.index("Sequences producing"):] if "Sequences producing" in pa else ""
+        t9 = subprocess.run(common + ["-a", str(threads), "-m", "9", "-b", str(case.keep)], capture_output=True, text=True, check=True).stdout
+        t9 = "\n".join(t9.split("\n")[1:])          # first line carries the compile date
         if threads == 1:
             out["xml"] = x.stdout
+            out["nalign"] = nalign
+            out["xml_align"], out["plain_align"], out["tsv9"] = xa, pa, t9
+        else:
+            assert (out["xml_align"], out["plain_align"], out["tsv9"]) == (xa, pa, t9), "alignment output depends on thread count"
         tracks = list(map(int, re.findall(r"<track>(\d+)</track>", x.stdout)))
         scores = list(map(int, re.findall(r"<score>(-?\d+)</score>", x.stdout)))
         t = subprocess.run(common + ["-a", str(threads), "-m", "8", "-b", str(case.keep)], capture_output=True, text=True, check=True)
+        if threads == 1:
+            out["tsv"] = t.stdout
+        else:
+            assert out["tsv"] == t.stdout
         ev, bits = [], []
         for l in t.stdout.splitlines():
             f = l.split("\t")

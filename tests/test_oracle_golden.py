@@ -85,6 +85,21 @@ def test_hit_list_rank_evalue_bits_match_cli(name):
         assert [str(x[1]) for x in got] == cli["bits"]      # no statistics: the TSV shows the raw score
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_alignments_match_reference_align(name):
+    """align() (align.cc) for every positive-scoring sequence, started both ways hits_align starts it:
+    from scratch and from the search16s end point (hits.cc:587-616)."""
+    case, g = cases.get(name), load_golden(name)
+    M = case_matrix(case, oracle)
+    assert g["align"]
+    for seqno, ds, s16s, bp, bq, score, qs, dst, qe, de, cigar, hinted in g["align"]:
+        d = blastdb.revcomp_nt16(case.seqs[seqno]) if ds else case.seqs[seqno]
+        assert oracle.align(case.query, d, M, case.gapopen, case.gapextend) == (score, qs, dst, qe, de, cigar)
+        assert (hinted is not None) == (s16s < g["scorelimit16"] and bq > 0 and bp != 0)
+        if hinted is not None:
+            assert oracle.align(case.query, d, M, case.gapopen, case.gapextend, (s16s, bq, bp)) == tuple(hinted)
+
+
 def test_known_answers_from_baseline_md():
     """self hit 1957 = 758.4 bits; ties rank by descending sequence number."""
     M = oracle.matrix_builtin("BLOSUM62")
