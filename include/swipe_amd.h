@@ -42,6 +42,7 @@ extern "C" {
 #define SWA_ENOMEM     -3
 #define SWA_EIO        -4   /* database files unreadable or malformed */
 #define SWA_ESTATE     -5   /* call order (e.g. search before set_scoring) */
+#define SWA_ERANGE     -6   /* caller's buffer too small; the needed size is reported */
 
 #define SWA_SYMTYPE_NUCLEOTIDE 0   /* reference symtype 0: 4-bit base masks, A=1 C=2 G=4 T=8 */
 #define SWA_SYMTYPE_PROTEIN    1   /* reference symtype 1: NCBIstdaa codes 0..27 */
@@ -100,6 +101,11 @@ SWA_API void swa_free(void* p);
    for hit lists ("lcl|id title", asnparse.cc:753-887) and the sequence's length. */
 SWA_API int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
                         int64_t* seqlen);
+/* All definition lines of the entry (identical sequences merged by the formatter carry several), one per
+   line, as the reference prints them above an alignment (hits.cc:1870, maxdeflines = LONG_MAX).
+   *needed = bytes incl. NUL; SWA_ERANGE when buflen is smaller. */
+SWA_API int swa_blastdb_deflines(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
+                         int64_t* needed);
 SWA_API void swa_db_close(swa_db* db);
 
 /* ---- scoring ------------------------------------------------------------------------------ */
@@ -137,6 +143,48 @@ SWA_API int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* q
    which it uses them, swipe.cc:404). */
 SWA_API int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
                          int64_t* scores, int64_t* bestpos, int64_t* bestq);
+/* Same for (sequence, database strand) pairs: dstrands[i] = 1 takes the reverse complement of a
+   nucleotide sequence, which is how the reference aligns minus-strand hits - plus query against
+   db_getsequence(seqno, strand 1) (swipe.cc:359-362, database.cc:1327-1339).  dstrands may be NULL. */
+SWA_API int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
+                         const int32_t* dstrands, int64_t n, int64_t* scores, int64_t* bestpos, int64_t* bestq);
+/* db_getsequence (swipe.h:344, database.cc:1237) out of the resident shard: residues of one sequence in
+   reference symbol codes, reverse-complemented for dstrand 1.  *len is set even when cap is too small
+   (the call then returns SWA_ERANGE). */
+SWA_API int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, uint8_t* buf, int64_t cap, int64_t* len);
+
+/* The alignment phase for a list of hits: align_chunk + hits_align + align (swipe.cc:339-414,
+   hits.cc:546-618, align.cc:469-519).  End points come from the GPU (search16s semantics), the start
+   point and the edit script from the host part (traceback.cpp, linear space).  Coordinates are 0-based
+   and inclusive, in the frame the reference aligns in: the query as given against the database
+   sequence, reverse-complemented when dstrands[i] = 1.  The edit script is the reference's alignment
+   string: runs "M<n>" (column pair), "D<n>" (query symbols against a gap), "I<n>" (database symbols
+   against a gap), e.g. "M120D2M31I1M7".  Counts follow count_align (hits.cc:1021-1109). */
+typedef struct {
+  int64_t seqno;
+  int32_t dstrand;
+  int32_t hinted;                 /* 1: the search16s end point was used (hits.cc:587), 0: forward sweep */
+  int64_t score;
+  int64_t q_start, q_end, d_start, d_end;
+  int64_t dlen;
+  int64_t identities, positives, indels, aligned, gaps;
+  int64_t cigar_offset, cigar_len; /* edit script = text[cigar_offset .. +cigar_len), NUL-terminated */
+} swa_alignment_t;
+/* text receives all edit scripts back to back; *text_used = bytes needed.  SWA_ERANGE if text_cap is
+   smaller (out[] is complete even then; call again with a larger buffer for the scripts). */
+SWA_API int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
+                   const int32_t* dstrands, int64_t n, swa_alignment_t* out, char* text, int64_t text_cap,
+                   int64_t* text_used);
+
+/* The host part alone, for one sequence the caller holds (e.g. rank 0 finishing hits of other shards):
+   align() as hits_align calls it.  M as for swa_set_scoring; gapopen/gapextend are the -G/-E values
+   (NOT open+extend).  hint_score != 0: (hint_q_end, hint_d_end) is trusted as the end cell and
+   hint_score as the score (what swa_search_endpoints returns, subject to the hits.cc:587 rule which the
+   caller applies); hint_score == 0: the forward sweep finds both.  Pure host arithmetic, no device. */
+SWA_API int swa_traceback(const uint8_t* query, int64_t qlen, const uint8_t* dseq, int64_t dlen, const int64_t* M,
+                  int64_t gapopen, int64_t gapextend, int64_t hint_score, int64_t hint_q_end, int64_t hint_d_end,
+                  swa_alignment_t* out, char* text, int64_t text_cap, int64_t* text_used);
+
 /* Merge per-shard top-K lists (each ordered) into the global top-K with the reference's
    comparator - what the MPI master does with tag_search_report (swipe.cc:1951-1974). */
 SWA_API int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,

@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+SWA_ERANGE = -6
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libswipe_amd.so")
 
@@ -26,6 +28,12 @@ class Hit(C.Structure):
     _fields_ = [("seqno", C.c_int64), ("score", C.c_int64)]
 
 
+class Alignment(C.Structure):
+    _fields_ = [("seqno", C.c_int64), ("dstrand", C.c_int32), ("hinted", C.c_int32)] + \
+               [(n, C.c_int64) for n in ("score", "q_start", "q_end", "d_start", "d_end", "dlen", "identities",
+                                         "positives", "indels", "aligned", "gaps", "cigar_offset", "cigar_len")]
+
+
 class Stats(C.Structure):
     _fields_ = [("available", C.c_int)] + \
                [(n, C.c_double) for n in ("lam", "K", "H", "alpha", "beta", "Kmn", "logK",
@@ -35,7 +43,8 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
-    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_hits_merge",
+    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
+    "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
     "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
@@ -60,6 +69,7 @@ def load():
     L.swa_db_info.argtypes = [vp, C.POINTER(DbInfo)]
     L.swa_blastdb_read.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(vp), C.POINTER(vp), i64p, i64p, i64p, i64p]
     L.swa_blastdb_defline.argtypes = [C.c_char_p, C.c_int, i64, C.c_char_p, i64, i64p]
+    L.swa_blastdb_deflines.argtypes = [C.c_char_p, C.c_int, i64, C.c_char_p, i64, i64p]
     L.swa_free.argtypes = [vp]
     L.swa_free.restype = None
     L.swa_db_close.argtypes = [vp]
@@ -71,6 +81,10 @@ def load():
     L.swa_search2_topk.argtypes = [vp, vp, vp, i64, i64, i64, i64, C.POINTER(Hit), C.POINTER(C.c_int32), i64p, i64p, i64p,
                                    C.POINTER(Counters)]
     L.swa_search_endpoints.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp]
+    L.swa_search_endpoints_strand.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, vp]
+    L.swa_db_sequence.argtypes = [vp, i64, C.c_int, vp, i64, i64p]
+    L.swa_align_hits.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(Alignment), C.c_char_p, i64, i64p]
+    L.swa_traceback.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, C.POINTER(Alignment), C.c_char_p, i64, i64p]
     L.swa_hits_merge.argtypes = [C.POINTER(Hit), i64p, C.c_int, i64, i64, C.POINTER(Hit), i64p]
     L.swa_stats_init.argtypes = [C.c_int, C.c_char_p, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                                  C.c_double, C.c_double, C.POINTER(Stats)]

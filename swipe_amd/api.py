@@ -180,14 +180,50 @@ class Database:
         return ([(hits[i].seqno, hits[i].score, which[i]) for i in range(n.value)], tot.value, obv.value,
                 {f: getattr(c, f) for f, _ in c._fields_})
 
-    def search_endpoints(self, query: np.ndarray, seqnos):
-        """(score, bestpos, bestq) per listed sequence - the reference's search16s for the alignment phase."""
+    def search_endpoints(self, query: np.ndarray, seqnos, dstrands=None):
+        """(score, bestpos, bestq) per listed sequence - the reference's search16s for the alignment phase.
+        dstrands[i] = 1: against the reverse complement of that (nucleotide) sequence."""
         q = np.ascontiguousarray(query, dtype=np.uint8)
         ids = _i64(seqnos)
         out = [np.empty(len(ids), dtype=np.int64) for _ in range(3)]
-        _check(_lib.load().swa_search_endpoints(self._h, q.ctypes.data, len(q), ids.ctypes.data, len(ids),
-                                                out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+        ds = None if dstrands is None else np.ascontiguousarray(dstrands, dtype=np.int32)
+        _check(_lib.load().swa_search_endpoints_strand(self._h, q.ctypes.data, len(q), ids.ctypes.data,
+                                                       None if ds is None else ds.ctypes.data, len(ids),
+                                                       out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
         return out
+
+    def sequence(self, seqno: int, dstrand: int = 0) -> np.ndarray:
+        """db_getsequence: residues of one sequence of the shard (reverse-complemented for dstrand 1)."""
+        L = _lib.load()
+        n = C.c_int64()
+        rc = L.swa_db_sequence(self._h, seqno, dstrand, None, 0, C.byref(n))
+        if rc not in (0, _lib.SWA_ERANGE):
+            _check(rc)
+        buf = np.empty(max(n.value, 1), dtype=np.uint8)
+        _check(L.swa_db_sequence(self._h, seqno, dstrand, buf.ctypes.data, n.value, C.byref(n)))
+        return buf[: n.value]
+
+    def align(self, query: np.ndarray, seqnos, dstrands=None):
+        """The reference's alignment phase (align_chunk + hits_align + align) for the listed hits: a list of
+        dicts with score, 0-based inclusive q_start/q_end/d_start/d_end, the edit script ("M..D..I.."),
+        identities, positives, indels, aligned, gaps, dlen, and whether the GPU end point was used."""
+        L = _lib.load()
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        ids = _i64(seqnos)
+        ds = None if dstrands is None else np.ascontiguousarray(dstrands, dtype=np.int32)
+        out = (_lib.Alignment * max(len(ids), 1))()
+        cap = 1 << 16
+        while True:
+            text = C.create_string_buffer(cap)
+            used = C.c_int64()
+            rc = L.swa_align_hits(self._h, q.ctypes.data, len(q), ids.ctypes.data, None if ds is None else ds.ctypes.data,
+                                  len(ids), out, text, cap, C.byref(used))
+            if rc == _lib.SWA_ERANGE:
+                cap = used.value
+                continue
+            _check(rc)
+            break
+        return [_alignment_dict(out[i], text.raw) for i in range(len(ids))]
 
     def close(self):
         if self._h:
@@ -199,6 +235,29 @@ class Database:
             self.close()
         except Exception:
             pass
+
+
+def _alignment_dict(a, text: bytes) -> dict:
+    d = {f: getattr(a, f) for f, _ in a._fields_ if not f.startswith("cigar_")}
+    d["cigar"] = text[a.cigar_offset: a.cigar_offset + a.cigar_len].decode()
+    return d
+
+
+def traceback(query, dseq, matrix, gapopen: int, gapextend: int, hint=None) -> dict:
+    """Host part of the alignment phase for one sequence held by the caller (swa_traceback);
+    hint = (score, q_end, d_end) from search_endpoints or None for a forward sweep."""
+    L = _lib.load()
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    d = np.ascontiguousarray(dseq, dtype=np.uint8)
+    M = np.ascontiguousarray(matrix, dtype=np.int64)
+    hs, hq, hd = hint if hint else (0, 0, 0)
+    a = _lib.Alignment()
+    cap = 16 * (len(q) + len(d)) + 64
+    text = C.create_string_buffer(cap)
+    used = C.c_int64()
+    _check(L.swa_traceback(q.ctypes.data, len(q), d.ctypes.data, len(d), M.ctypes.data, gapopen, gapextend, hs, hq, hd,
+                           C.byref(a), text, cap, C.byref(used)))
+    return _alignment_dict(a, text.raw)
 
 
 def read_blastdb(basename: str, *, symtype: int = 1, first_seqno: int = 0, last_seqno: int = -1):

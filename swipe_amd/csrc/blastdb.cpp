@@ -300,39 +300,50 @@ std::string seq_id(Ber& b)
   return out;
 }
 
-std::string first_defline(const uint8_t* p, size_t n)
+// every Blast-def-line of the set (one per identical sequence merged into this entry), each rendered
+// "ids title" as parse_blast_def_line does (asnparse.cc:753-887), joined by '\n'
+std::string all_deflines(const uint8_t* p, size_t n)
 {
   Ber b{p, p + n};
   int tag; long len;
-  std::string title, ids;
-  if (!b.head(tag, len) || tag != 0x30) return std::string();         // Blast-def-line-set
-  int t2; long l2;
-  if (!b.head(t2, l2) || t2 != 0x30) return std::string();            // first Blast-def-line
-  const uint8_t* stop = l2 >= 0 ? b.p + l2 : nullptr;
-  while (b.p < b.end && (stop ? b.p < stop : !b.eoc())) {
-    int ft; long fl;
-    if (!b.head(ft, fl)) break;
-    if (ft == 0xA0) {                                                  // title
-      int it; long il;
-      if (b.head(it, il)) title = b.str(il);
-      b.close(fl);
-    } else if (ft == 0xA1) {                                           // seqid SEQUENCE OF Seq-id
-      int st; long sl;
-      if (b.head(st, sl)) {
-        const uint8_t* sstop = sl >= 0 ? b.p + sl : nullptr;
-        while (b.p < b.end && (sstop ? b.p < sstop : !b.eoc())) {
-          const std::string id = seq_id(b);
-          if (!ids.empty()) ids += "|";
-          ids += id;
+  std::string out;
+  if (!b.head(tag, len) || tag != 0x30) return out;                   // Blast-def-line-set
+  const uint8_t* set_stop = len >= 0 ? b.p + len : nullptr;
+  bool first = true;
+  while (b.p < b.end && (set_stop ? b.p < set_stop : !b.eoc())) {
+    int t2; long l2;
+    if (!b.head(t2, l2) || t2 != 0x30) break;                          // one Blast-def-line
+    std::string title, ids;
+    const uint8_t* stop = l2 >= 0 ? b.p + l2 : nullptr;
+    while (b.p < b.end && (stop ? b.p < stop : !b.eoc())) {
+      int ft; long fl;
+      if (!b.head(ft, fl)) break;
+      if (ft == 0xA0) {                                                // title
+        int it; long il;
+        if (b.head(it, il)) title = b.str(il);
+        b.close(fl);
+      } else if (ft == 0xA1) {                                         // seqid SEQUENCE OF Seq-id
+        int st; long sl;
+        if (b.head(st, sl)) {
+          const uint8_t* sstop = sl >= 0 ? b.p + sl : nullptr;
+          while (b.p < b.end && (sstop ? b.p < sstop : !b.eoc())) {
+            const std::string id = seq_id(b);
+            if (!ids.empty()) ids += "|";
+            ids += id;
+          }
+          b.close(sl);
         }
-        b.close(sl);
+        b.close(fl);
+      } else {
+        if (fl >= 0) b.p += fl; else { while (b.p < b.end && !b.eoc()) b.skip(); b.p += 2; }
       }
-      b.close(fl);
-    } else {
-      if (fl >= 0) b.p += fl; else { while (b.p < b.end && !b.eoc()) b.skip(); b.p += 2; }
     }
+    b.close(l2);
+    if (!first) out += '\n';
+    first = false;
+    out += ids + ((ids.empty() || title.empty()) ? "" : " ") + title;
   }
-  return ids + (title.empty() ? "" : " " + title);
+  return out;
 }
 }  // namespace
 
@@ -367,7 +378,7 @@ int swa::read_blast_deflines(const char* basename, int symtype, const std::vecto
     if (!v || local < 0) return fail(SWA_EINVAL, "Cant find database volume.");
     const uint64_t h1 = be32(v->hdr_off + 4 * local), h2 = be32(v->hdr_off + 4 * (local + 1));
     if (h2 < h1 || h2 > v->hdr.n) return fail(SWA_EIO, "corrupt header offsets in " + v->base);
-    deflines.push_back(first_defline(v->hdr.p + h1, size_t(h2 - h1)));
+    deflines.push_back(all_deflines(v->hdr.p + h1, size_t(h2 - h1)));
     const uint64_t o1 = be32(v->seq_off + 4 * local), o2 = be32(v->seq_off + 4 * (local + 1));
     if (protein) lengths.push_back(o2 > o1 ? int64_t(o2 - o1 - 1) : 0);
     else {

@@ -3,11 +3,10 @@
 //
 // Mirrors the control flow of the reference's main()/work() (swipe.cc:2436-2611): open the
 // database once, then for every query of the FASTA file: hits_init thresholds, search, hit list,
-// output.  Output formats: -m 7 (the reference's simple XML, reproduced byte for byte when no
-// alignments are requested) and -m 0 (banner, parameter block and the "Sequences producing
-// significant alignments" list).  The traceback/alignment phase (align.cc) is outside this
-// library's scope, so -b is accepted and ignored.  Errors follow the reference: message on
-// stderr, exit(1) (swipe.cc:158-170).
+// alignment phase for the best -b hits, output.  Output formats as the reference's hits_show
+// (hits.cc:1989-2025): -m 0 plain (hit list + pairwise alignments), -m 7 simple XML, -m 8 / -m 9
+// tab-separated (without / with comment lines) - reproduced byte for byte apart from the banner and
+// timing lines.  Errors follow the reference: message on stderr, exit(1) (swipe.cc:158-170).
 #include "../../include/swipe_amd.h"
 
 #include <algorithm>
@@ -89,6 +88,124 @@ void show_expect(FILE* out, double e)                        // hits.cc:1177-119
   else std::fprintf(out, "%5.0f", e);
 }
 
+// show_deflines (asnparse.cc:889-968): the definition lines of one database entry, truncated to maxlen
+// with "...", wrapped at linelen with `indent`, first defline marked '>' when several may be shown
+void show_deflines(FILE* out, const std::string& all, long indent, size_t maxlen, long linelen, long maxdeflines, bool descr)
+{
+  size_t from = 0;
+  for (long x = 0; from <= all.size(); ++x) {
+    size_t nl = all.find('\n', from);
+    if (nl == std::string::npos) nl = all.size();
+    std::string d = all.substr(from, nl - from);
+    from = nl + 1;
+    if (x >= maxdeflines) continue;
+    size_t show = d.size();
+    if (maxlen && show > maxlen) show = maxlen;
+    if (show < d.size() && show >= 3) d.replace(show - 3, 3, "...");
+    size_t pos = 0;
+    for (long line = 0; pos < show; ++line) {
+      long col = 0;
+      if (maxdeflines > 1) {
+        if (line) for (; col < 1 + indent; ++col) std::fputc(' ', out);
+        else { std::fputc(x ? ' ' : '>', out); ++col; }
+      }
+      while (pos < show && col < linelen) {
+        if (!descr && d[pos] == ' ') { pos = show; break; }
+        std::fputc(d[pos++], out);
+        ++col;
+      }
+      if (linelen < LONG_MAX) for (; col < linelen; ++col) std::fputc(' ', out);
+      if (maxdeflines > 1) std::fputc('\n', out);
+    }
+  }
+}
+
+// one aligned hit with what the display code of hits.cc needs
+struct Shown {
+  swa_alignment_t a;
+  std::string script;             // "M12D1..."
+  std::vector<uint8_t> dseq;      // database sequence in the frame it was aligned in
+  long q_first = 0, q_last = 0, d_first = 0, d_last = 0;
+  int poswidth = 1;
+};
+
+// tail of count_align / whole_align (hits.cc:1111-1174): 1-based display coordinates on the original strands
+void display_positions(Shown& h, bool nucleotide)
+{
+  h.q_first = long(h.a.q_start); h.q_last = long(h.a.q_end);
+  h.d_first = long(h.a.d_start); h.d_last = long(h.a.d_end);
+  if (nucleotide && h.a.dstrand) {
+    h.d_first = long(h.a.dlen) - 1 - h.d_first;
+    h.d_last = long(h.a.dlen) - 1 - h.d_last;
+  }
+  ++h.q_first; ++h.q_last; ++h.d_first; ++h.d_last;
+  long maxpos = std::max(std::max(h.q_first, h.q_last), std::max(h.d_first, h.d_last));
+  for (h.poswidth = 1; maxpos > 9; maxpos /= 10) ++h.poswidth;
+}
+
+template <typename F> void for_each_op(const std::string& script, F&& f)
+{
+  for (size_t i = 0; i < script.size();) {
+    const char op = script[i++];
+    long n = 0;
+    while (i < script.size() && std::isdigit((unsigned char)script[i])) n = 10 * n + (script[i++] - '0');
+    f(op, n);
+  }
+}
+
+// show_align + putalignop (hits.cc:647-813): 60-column blocks of Query / match line / Sbjct
+void show_pairwise(FILE* out, const Shown& h, const std::vector<uint8_t>& q, const int64_t* M, bool nucleotide, const char* sym)
+{
+  const int width = 60;
+  char ql[width + 1], al[width + 1], dl[width + 1];
+  long qpos = long(h.a.q_start), dpos = long(h.a.d_start), qs0 = 0, ds0 = 0;
+  int fill = 0;
+  auto flush = [&]() {
+    ql[fill] = al[fill] = dl[fill] = 0;
+    long q1 = qs0 + 1, q2 = qpos, d1 = ds0 + 1, d2 = dpos;
+    if (nucleotide && h.a.dstrand) { d1 = long(h.a.dlen) - d1 + 1; d2 = long(h.a.dlen) - d2 + 1; }
+    std::fprintf(out, "\n");
+    std::fprintf(out, "Query: %*ld %s %ld\n", h.poswidth, q1, ql, q2);
+    std::fprintf(out, "       %*s %s\n", h.poswidth, "", al);
+    std::fprintf(out, "Sbjct: %*ld %s %ld\n", h.poswidth, d1, dl, d2);
+    fill = 0;
+  };
+  for_each_op(h.script, [&](char op, long n) {
+    for (long k = 0; k < n; ++k) {
+      if (fill == 0) { qs0 = qpos; ds0 = dpos; }
+      if (op == 'M') {
+        const int a = q[size_t(qpos++)], b = h.dseq[size_t(dpos++)];
+        ql[fill] = sym[a];
+        dl[fill] = sym[b];
+        al[fill] = nucleotide ? (a == b ? '|' : ' ') : (a == b ? sym[a] : (M[32 * a + b] > 0 ? '+' : ' '));
+      } else if (op == 'D') {
+        ql[fill] = sym[q[size_t(qpos++)]]; al[fill] = ' '; dl[fill] = '-';
+      } else {
+        ql[fill] = '-'; al[fill] = ' '; dl[fill] = sym[h.dseq[size_t(dpos++)]];
+      }
+      if (++fill == width) flush();
+    }
+  });
+  if (fill > 0) flush();
+}
+
+// the three full-length lines of whole_align (hits.cc:815-953)
+void whole_lines(const Shown& h, const std::vector<uint8_t>& q, const int64_t* M, const char* sym, std::string& ql,
+                 std::string& al, std::string& dl)
+{
+  long qpos = long(h.a.q_start), dpos = long(h.a.d_start);
+  for_each_op(h.script, [&](char op, long n) {
+    for (long k = 0; k < n; ++k) {
+      if (op == 'M') {
+        const int a = q[size_t(qpos++)], b = h.dseq[size_t(dpos++)];
+        ql += sym[a]; dl += sym[b];
+        al += a == b ? '|' : (M[32 * a + b] > 0 ? '+' : ' ');
+      } else if (op == 'D') { ql += sym[q[size_t(qpos++)]]; al += ' '; dl += '-'; }
+      else { ql += '-'; al += ' '; dl += sym[h.dseq[size_t(dpos++)]]; }
+    }
+  });
+}
+
 void usage(const char* prog)
 {
   std::printf("Usage: %s [OPTIONS]\n", prog);
@@ -100,13 +217,13 @@ void usage(const char* prog)
   std::printf("  -G, --gapopen=NUM          gap open penalty (11)\n");
   std::printf("  -E, --gapextend=NUM        gap extension penalty (1)\n");
   std::printf("  -v, --num_descriptions=NUM sequence descriptions to show (250)\n");
-  std::printf("  -b, --num_alignments=NUM   accepted, alignments are not produced (0)\n");
+  std::printf("  -b, --num_alignments=NUM   sequence alignments to show (100)\n");
   std::printf("  -e, --evalue=REAL          maximum expect value of sequences to show (10.0)\n");
   std::printf("  -k, --minevalue=REAL       minimum expect value of sequences to show (0.0)\n");
   std::printf("  -c, --min_score=NUM        minimum score of sequences to show (1)\n");
   std::printf("  -u, --max_score=NUM        maximum score of sequences to show (inf.)\n");
   std::printf("  -a, --num_threads=NUM      accepted and ignored (one GPU)\n");
-  std::printf("  -m, --outfmt=NUM           output format [0,7=plain,xml] (0)\n");
+  std::printf("  -m, --outfmt=NUM           output format [0,7-9=plain,xml,tsv,tsv+] (0)\n");
   std::printf("  -p, --symtype=NAME/NUM     symbol type [0-1, blastn, blastp] (1)\n");
   std::printf("  -S, --strand=NAME/NUM      query strands to search [1-3] (3)\n");
   std::printf("  -o, --out=FILE             output file (stdout)\n");
@@ -119,7 +236,7 @@ int main(int argc, char** argv)
 {
   std::string dbname, queryname = "-", matrixname, outfile;
   long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
-  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0;
+  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100;
   double expect = 10.0, minexpect = 0.0;
   static const option longopts[] = {
       {"db", 1, 0, 'd'}, {"query", 1, 0, 'i'}, {"matrix", 1, 0, 'M'}, {"penalty", 1, 0, 'q'}, {"reward", 1, 0, 'r'},
@@ -138,7 +255,7 @@ int main(int argc, char** argv)
       case 'G': gapopen = std::atol(optarg); break;
       case 'E': gapextend = std::atol(optarg); break;
       case 'v': maxmatches = std::atol(optarg); break;
-      case 'b': break;
+      case 'b': alignments = std::atol(optarg); break;
       case 'a': break;
       case 'e': expect = std::atof(optarg); break;
       case 'k': minexpect = std::atof(optarg); break;
@@ -177,7 +294,8 @@ int main(int argc, char** argv)
   }
   if (effdbsize < 0) fatal("Illegal effective db size specified");
   if (dbname.empty()) fatal("No database specified.");
-  if (view != 0 && view != 7) fatal("Illegal view type.");
+  if (view != 0 && view != 7 && view != 8 && view != 9) fatal("Illegal view type.");
+  if (alignments < 0) fatal("Illegal number of alignments specified.");
   if (gapopen < 0 || gapextend < 0 || gapopen + gapextend < 1) fatal("Illegal gap penalties.");
   if (strands < 1 || strands > 3) fatal("Illegal query strands specified.");
   if (strands == 2 && protein) fatal("Illegal strand specified for protein query.");
@@ -205,14 +323,14 @@ int main(int argc, char** argv)
   if (!qf) fatal("Cannot open query file.");
   if (view == 0)
     std::fprintf(out, "swipe_amd (MI355X) - SWIPE-compatible Smith-Waterman database search\n\n");
-  else
+  else if (view == 7)
     std::fprintf(out, "<?xml version=\"1.0\"?>\n");
 
   std::string pending;
   Query q;
   while (read_query(qf, pending, protein, q)) {
     const int64_t qlen = int64_t(q.seq.size());
-    int64_t keep = maxmatches;                                         // hits.cc:287-315
+    int64_t keep = std::max(maxmatches, alignments);                   // hits.cc:287-315
     int64_t maxhits = info.seqcount * ((!protein && strands == 3) ? 2 : 1);
     if (keep > maxhits) keep = maxhits;
     swa_stats_t st;
@@ -237,27 +355,97 @@ int main(int argc, char** argv)
       check(swa_search2_topk(db, q.seq.data(), rc.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(),
                              which.data(), &nhits, &total, &obvious, &cnt));
     }
+    const int64_t showhits = std::min<int64_t>(nhits, maxmatches);       // hits_show, hits.cc:1996-2004
+    const int64_t showalignments = std::min<int64_t>(nhits, alignments);
     std::vector<int64_t> seqnos;
-    for (int64_t i = 0; i < nhits; ++i) seqnos.push_back(hits[size_t(i)].seqno);
-    std::vector<std::string> deflines;
-    std::vector<int64_t> lengths;
-    for (int64_t s : seqnos) {
-      char buf[4096];
-      int64_t len = 0;
-      check(swa_blastdb_defline(dbname.c_str(), int(symtype), s, buf, sizeof buf, &len));
-      deflines.push_back(buf);
-      lengths.push_back(len);
+    std::vector<int32_t> dstrands;
+    for (int64_t i = 0; i < nhits; ++i) {
+      seqnos.push_back(hits[size_t(i)].seqno);
+      dstrands.push_back(protein ? 0 : which[size_t(i)]);
     }
+    std::vector<std::string> deflines;
+    for (int64_t s : seqnos) {
+      std::vector<char> buf(4096);
+      int64_t need = 0;
+      int rc = swa_blastdb_deflines(dbname.c_str(), int(symtype), s, buf.data(), int64_t(buf.size()), &need);
+      if (rc == SWA_ERANGE) {
+        buf.resize(size_t(need));
+        rc = swa_blastdb_deflines(dbname.c_str(), int(symtype), s, buf.data(), int64_t(buf.size()), &need);
+      }
+      check(rc);
+      deflines.push_back(buf.data());
+    }
+
+    // alignment phase (align_threads, swipe.cc:628-647): always against the PLUS query; minus-strand
+    // hits take the reverse-complemented database sequence (swipe.cc:359-362, hits.cc:564-577)
+    std::vector<Shown> shown{size_t(showalignments)};
+    if (showalignments > 0) {
+      std::vector<swa_alignment_t> al{size_t(showalignments)};
+      std::vector<char> text(1 << 16);
+      int64_t used = 0;
+      int rc = swa_align_hits(db, q.seq.data(), qlen, seqnos.data(), dstrands.data(), showalignments, al.data(), text.data(),
+                              int64_t(text.size()), &used);
+      if (rc == SWA_ERANGE) {
+        text.resize(size_t(used));
+        rc = swa_align_hits(db, q.seq.data(), qlen, seqnos.data(), dstrands.data(), showalignments, al.data(), text.data(),
+                            int64_t(text.size()), &used);
+      }
+      check(rc);
+      for (int64_t i = 0; i < showalignments; ++i) {
+        Shown& h = shown[size_t(i)];
+        h.a = al[size_t(i)];
+        h.script.assign(text.data() + h.a.cigar_offset, size_t(h.a.cigar_len));
+        h.dseq.resize(size_t(h.a.dlen > 0 ? h.a.dlen : 1));
+        int64_t got = 0;
+        check(swa_db_sequence(db, h.a.seqno, h.a.dstrand, h.dseq.data(), h.a.dlen, &got));
+        display_positions(h, !protein);
+      }
+    }
+    const char* sym = protein ? "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ####" : "-acmgrsvtwyhkdbn################";   // query.cc:176-178
 
     std::string qid = q.description.substr(0, q.description.find(' '));
     if (view == 7) {                                                  // hits_show_xml, hits.cc:1660-1727
       std::fprintf(out, "<result>\n  <general>\n    <hitcount>%d</hitcount>\n  </general>\n  <hits>\n", int(nhits));
-      for (int64_t i = 0; i < nhits; ++i) {
+      for (int64_t i = 0; i < showhits; ++i) {
         std::fprintf(out, "    <hit>\n      <hitno>%ld</hitno>\n      <track>%ld</track>\n", long(i + 1), long(hits[size_t(i)].seqno));
-        std::fprintf(out, "      <query>%s</query>\n      <name>%s</name>\n", qid.c_str(), deflines[size_t(i)].c_str());
-        std::fprintf(out, "      <len>%ld</len>\n      <score>%ld</score>\n    </hit>\n", long(lengths[size_t(i)]), long(hits[size_t(i)].score));
+        std::fprintf(out, "      <query>%s</query>\n      <name>", qid.c_str());
+        show_deflines(out, deflines[size_t(i)], 0, 0, LONG_MAX, 1, true);
+        // dlen is only filled in for aligned hits (hits.cc:566); the others print the 0 of the fresh list
+        std::fprintf(out, "</name>\n      <len>%ld</len>\n      <score>%ld</score>\n",
+                     i < showalignments ? long(shown[size_t(i)].a.dlen) : 0L, long(hits[size_t(i)].score));
+        if (i < showalignments) {
+          const Shown& h = shown[size_t(i)];
+          std::string ql, al, dl;
+          whole_lines(h, q.seq, M, sym, ql, al, dl);
+          std::fprintf(out, "      <alignment>%s</alignment>\n", h.script.c_str());
+          std::fprintf(out, "      <qpos>%ld,%ld</qpos>\n      <dpos>%ld,%ld</dpos>\n", h.q_first, h.q_last, h.d_first, h.d_last);
+          std::fprintf(out, "      <qseq>%s</qseq>\n      <aseq>%s</aseq>\n      <dseq>%s</dseq>\n", ql.c_str(), al.c_str(), dl.c_str());
+        }
+        std::fprintf(out, "    </hit>\n");
       }
       std::fprintf(out, "  </hits>\n</result>\n");
+    } else if (view == 8 || view == 9) {                              // hits_show_tsv, hits.cc:1729-1789
+      if (view == 9) {
+        std::fprintf(out, "# swipe_amd (MI355X), output format of SWIPE 2.1.1 - Reference: T. Rognes (2011) Faster Smith-Waterman database searches with inter-sequence SIMD parallelisation, BMC Bioinformatics, 12:221.\n");
+        std::fprintf(out, "# Query: %s\n", q.description.c_str());
+        std::fprintf(out, "# Database: %s\n", dbname.c_str());
+        if (st.available)
+          std::fprintf(out, "# Fields: Query id, Subject id, %% identity, alignment length, mismatches, gap openings, q. start, q. end, s. start, s. end, e-value, bit score\n");
+        else
+          std::fprintf(out, "# Fields: Query id, Subject id, %% identity, alignment length, mismatches, gap openings, q. start, q. end, s. start, s. end, score\n");
+      }
+      for (int64_t i = 0; i < showalignments; ++i) {
+        const Shown& h = shown[size_t(i)];
+        std::fputs(qid.c_str(), out);
+        std::fputc('\t', out);
+        show_deflines(out, deflines[size_t(i)], 0, 0, LONG_MAX, 1, false);
+        std::fprintf(out, "\t%.2f\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld\t%ld", 100.0 * h.a.identities / h.a.aligned, long(h.a.aligned),
+                     long(h.a.aligned - h.a.identities - h.a.indels), long(h.a.gaps), h.q_first, h.q_last, h.d_first, h.d_last);
+        const long score = long(hits[size_t(i)].score);
+        if (st.available) std::fprintf(out, "\t%.2g\t%.1f", swa_evalue(&st, score), swa_bits(&st, score));
+        else std::fprintf(out, "\t%ld", score);
+        std::fprintf(out, "\n");
+      }
     } else {                                                          // args_show + hits_show_plain
       std::fprintf(out, "Database file:     %s\n", dbname.c_str());
       std::fprintf(out, "Database size:     %ld residues in %ld sequences\n", long(info.total_symcount), long(info.total_seqcount));
@@ -271,6 +459,7 @@ int main(int argc, char** argv)
       std::fprintf(out, "Max expect shown:  %-g\n", expect);
       std::fprintf(out, "Min score shown:   %ld\n", minscore);
       std::fprintf(out, "Max matches shown: %ld\n", maxmatches);
+      std::fprintf(out, "Alignments shown:  %ld\n", alignments);
       std::fprintf(out, "Symbol type:       %s\n\n", protein ? "Amino acid" : "Nucleotide");
       std::fprintf(out, "Elapsed:           %.4fs (device)\n", cnt.total_ms * 1e-3);
       std::fprintf(out, "Speed:             %.3f GCUPS\n\n", cnt.total_ms > 0 ? double(cnt.cells) / (cnt.total_ms * 1e-3) / 1e9 : 0.0);
@@ -283,16 +472,13 @@ int main(int argc, char** argv)
         } else {
           std::fprintf(out, "Sequences producing significant alignments:                         Score\n\n");
         }
-        const size_t width = protein ? 67 : 65;                       // hits.cc:1815-1822
-        for (int64_t i = 0; i < nhits; ++i) {
-          std::string d = deflines[size_t(i)];
-          if (d.size() > width) { d.resize(width); if (width >= 3) d.replace(width - 3, 3, "..."); }   // asnparse.cc:897-906
-          d.resize(width, ' ');
-          std::fputs(d.c_str(), out);
+        const long width = protein ? 67 : 65;                         // hits.cc:1814-1820
+        for (int64_t i = 0; i < showhits; ++i) {
+          show_deflines(out, deflines[size_t(i)], 0, size_t(width), width, 1, true);
           const long score = long(hits[size_t(i)].score);
           if (!protein) std::fprintf(out, " %c", which[size_t(i)] ? '-' : '+');
           if (st.available) {
-            const long bits = long(std::floor(st.lambda_d_log2 * score - st.logK_d_log2 + 0.5));   // hits.cc:1848
+            const long bits = long(std::floor(st.lambda_d_log2 * score - st.logK_d_log2 + 0.5));   // hits.cc:1846
             std::fprintf(out, " %5ld", bits);
             std::fprintf(out, "   ");
             show_expect(out, swa_evalue(&st, score));
@@ -301,8 +487,30 @@ int main(int argc, char** argv)
           }
           std::fputc('\n', out);
         }
+        for (int64_t i = 0; i < showalignments; ++i) {                // hits.cc:1867-1941
+          const Shown& h = shown[size_t(i)];
+          std::fprintf(out, "\n");
+          show_deflines(out, deflines[size_t(i)], 10, 0, 79, LONG_MAX, true);
+          std::fprintf(out, "          Length = %ld\n\n", long(h.a.dlen));
+          const long score = long(hits[size_t(i)].score);
+          if (st.available) {
+            std::fprintf(out, " Score = %.1lf bits (%ld), Expect = ", swa_bits(&st, score), score);
+            show_expect(out, swa_evalue(&st, score));
+          } else {
+            std::fprintf(out, " Score = %ld", score);
+          }
+          std::fputc('\n', out);
+          std::fprintf(out, " Identities = %ld/%ld (%ld%%)", long(h.a.identities), long(h.a.aligned), long(h.a.identities * 100 / h.a.aligned));
+          if (protein)
+            std::fprintf(out, ", Positives = %ld/%ld (%ld%%)", long(h.a.positives), long(h.a.aligned), long(h.a.positives * 100 / h.a.aligned));
+          if (h.a.indels)
+            std::fprintf(out, ", Gaps = %ld/%ld (%ld%%)", long(h.a.indels), long(h.a.aligned), long(h.a.indels * 100 / h.a.aligned));
+          std::fprintf(out, "\n");
+          if (!protein) std::fprintf(out, " Strand = %s\n", h.a.dstrand ? "Plus / Minus" : "Plus / Plus");
+          show_pairwise(out, h, q.seq, M, !protein, sym);
+          std::fprintf(out, "\n");
+        }
       }
-      std::fprintf(out, "\n");
     }
   }
   if (qf != stdin) std::fclose(qf);

@@ -375,7 +375,8 @@ swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ sc
 // hundred sequences per query, so throughput is irrelevant here.
 extern "C" __global__ void __launch_bounds__(64)
 swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                     const int32_t* __restrict__ ids, int n, const uint8_t* __restrict__ qseq, int qlen,
+                     const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
+                     const uint8_t* __restrict__ qseq, int qlen,
                      const int32_t* __restrict__ matrix, long long Q, long long R,
                      long long* __restrict__ Hs, long long* __restrict__ Es,
                      long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q)
@@ -384,10 +385,14 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
   if (t >= n) return;
   const int stride = gridDim.x * blockDim.x;
   const int64_t o = offsets[ids[t]], len = offsets[ids[t] + 1] - o;
+  // minus[t]: the reverse complement of a nucleotide sequence, as db_getsequence hands it out for
+  // strand 1 (database.cc:1327-1339); complementing a one-hot/IUPAC nibble = reversing its 4 bits
+  const bool rc = minus && minus[t];
   for (int i = 0; i < qlen; ++i) { Hs[(int64_t)i * stride + t] = 0; Es[(int64_t)i * stride + t] = 0; }
   long long S = 0, bp = 0, bq = -1;                       // d_best = d_begin, q_best = -1 (search16s.cc:483-486)
   for (int64_t j = 0; j < len; ++j) {
-    const int32_t* row = matrix + ((int)residues[o + j] << 5);
+    const int sym = rc ? (int)(__brev((unsigned)residues[o + len - 1 - j]) >> 28) : (int)residues[o + j];
+    const int32_t* row = matrix + (sym << 5);
     long long hd = 0, f = 0, cm = 0, cq = -1;
     for (int i = 0; i < qlen; ++i) {
       const int64_t a = (int64_t)i * stride + t;
@@ -478,13 +483,14 @@ extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* 
   hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids, int n,
+extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
+                                           const uint8_t* minus, int n,
                                            const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                            long long* Hs, long long* Es, long long* out, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
   const int blocks = (n + 63) / 64;
-  hipLaunchKernelGGL(swa_endpoints_kernel, dim3(blocks), dim3(64), 0, st, residues, offsets, ids, n, qseq, qlen, matrix, Q, R,
+  hipLaunchKernelGGL(swa_endpoints_kernel, dim3(blocks), dim3(64), 0, st, residues, offsets, ids, minus, n, qseq, qlen, matrix, Q, R,
                      Hs, Es, out, out + n, out + 2 * (size_t)n);
   return hipGetLastError();
 }

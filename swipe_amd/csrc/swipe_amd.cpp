@@ -10,6 +10,7 @@
 #include "../../include/swipe_amd.h"
 #include "host_util.h"
 #include "sw_device.h"
+#include "traceback.h"
 
 #include <hip/hip_runtime.h>
 
@@ -25,8 +26,8 @@ extern "C" {
 int swa_narrow_rows_for(int qlen);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
-hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids, int n,
-                                const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
+hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
+                                const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                 long long* Hs, long long* Es, long long* out, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
@@ -682,8 +683,21 @@ extern "C" int swa_blastdb_defline(const char* basename, int symtype, int64_t se
   std::vector<int64_t> len;
   const int rc = swa::read_blast_deflines(basename, symtype, std::vector<int64_t>{seqno}, d, len);
   if (rc != SWA_OK) return rc;
-  std::snprintf(buf, size_t(buflen), "%s", d[0].c_str());
+  std::snprintf(buf, size_t(buflen), "%s", d[0].substr(0, d[0].find('\n')).c_str());
   if (seqlen) *seqlen = len[0];
+  return SWA_OK;
+}
+
+extern "C" int swa_blastdb_deflines(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen, int64_t* needed)
+{
+  if (!basename || buflen < 0 || (buflen > 0 && !buf) || !needed) return fail(SWA_EINVAL, "bad argument");
+  std::vector<std::string> d;
+  std::vector<int64_t> len;
+  const int rc = swa::read_blast_deflines(basename, symtype, std::vector<int64_t>{seqno}, d, len);
+  if (rc != SWA_OK) return rc;
+  *needed = int64_t(d[0].size()) + 1;
+  if (*needed > buflen) return fail(SWA_ERANGE, "defline buffer too small");
+  std::memcpy(buf, d[0].c_str(), d[0].size() + 1);
   return SWA_OK;
 }
 
@@ -875,42 +889,200 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
   return SWA_OK;
 }
 
-extern "C" int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
-                                    int64_t* scores, int64_t* bestpos, int64_t* bestq)
+namespace {
+// search16s over the listed (sequence, strand) pairs: out = scores | bestpos | bestq, n entries each
+int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, const int32_t* dstrands,
+                        int64_t n, std::vector<long long>& out)
 {
-  int rc = check_query(db, query, qlen);
-  if (rc != SWA_OK) return rc;
-  if (n < 0 || (n > 0 && (!seqnos || !scores || !bestpos || !bestq))) return fail(SWA_EINVAL, "bad argument");
-  if (n == 0) return SWA_OK;
   if (n > (1 << 20)) return fail(SWA_EINVAL, "too many sequences for the alignment phase");
   std::vector<int32_t> ids((size_t(n)));
+  std::vector<uint8_t> minus((size_t(n)), 0);
   for (int64_t i = 0; i < n; ++i) {
     const int64_t local = seqnos[i] - db->first_seqno;
     if (local < 0 || local >= db->nseq) return fail(SWA_EINVAL, "sequence number outside this shard");
     ids[size_t(i)] = int32_t(local);
+    if (dstrands && dstrands[i]) {
+      if (db->symtype != SWA_SYMTYPE_NUCLEOTIDE) return fail(SWA_EINVAL, "database strand 1 needs a nucleotide database");
+      minus[size_t(i)] = 1;
+    }
   }
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
   const size_t threads = size_t((n + 63) / 64) * 64;
   DevBuf<int32_t> d_ids;
+  DevBuf<uint8_t> d_minus;
   DevBuf<long long> d_h, d_e, d_out;
   HIP_TRY(d_ids.reserve(size_t(n)));
+  HIP_TRY(d_minus.reserve(size_t(n)));
   HIP_TRY(d_h.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
   HIP_TRY(d_e.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
   HIP_TRY(d_out.reserve(3 * size_t(n)));
   HIP_TRY(db->qseq.reserve(size_t(qlen > 0 ? qlen : 1)));
   if (qlen) HIP_TRY(hipMemcpyAsync(db->qseq.p, query, size_t(qlen), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_ids.p, ids.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  HIP_TRY(swa_launch_endpoints(db->residues.p, db->offsets.p, d_ids.p, int(n), db->qseq.p, int(qlen), db->matrix.p,
-                               db->goe, db->ge, d_h.p, d_e.p, d_out.p, st));
-  std::vector<long long> out(3 * size_t(n));
+  HIP_TRY(hipMemcpyAsync(d_minus.p, minus.data(), size_t(n), hipMemcpyHostToDevice, st));
+  HIP_TRY(swa_launch_endpoints(db->residues.p, db->offsets.p, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
+                               db->matrix.p, db->goe, db->ge, d_h.p, d_e.p, d_out.p, st));
+  out.resize(3 * size_t(n));
   HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return SWA_OK;
+}
+
+// db_getsequence (database.cc:1237-1401) for symtype 0/1 out of the resident shard
+int fetch_sequence(swa_db* db, int64_t seqno, int dstrand, std::vector<uint8_t>& seq)
+{
+  const int64_t local = seqno - db->first_seqno;
+  if (local < 0 || local >= db->nseq) return fail(SWA_EINVAL, "sequence number outside this shard");
+  if (dstrand && db->symtype != SWA_SYMTYPE_NUCLEOTIDE) return fail(SWA_EINVAL, "database strand 1 needs a nucleotide database");
+  const int64_t o = db->h_offsets[size_t(local)], len = db->h_offsets[size_t(local) + 1] - o;
+  seq.resize(size_t(len));
+  if (len) {
+    HIP_TRY(hipSetDevice(db->device));
+    HIP_TRY(hipMemcpy(seq.data(), db->residues.p + o, size_t(len), hipMemcpyDeviceToHost));
+  }
+  if (dstrand) {
+    static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // database.cc ntcompl
+    std::reverse(seq.begin(), seq.end());
+    for (uint8_t& c : seq) c = compl4[c & 15];
+  }
+  return SWA_OK;
+}
+}  // namespace
+
+extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
+                                           const int32_t* dstrands, int64_t n, int64_t* scores, int64_t* bestpos,
+                                           int64_t* bestq)
+{
+  int rc = check_query(db, query, qlen);
+  if (rc != SWA_OK) return rc;
+  if (n < 0 || (n > 0 && (!seqnos || !scores || !bestpos || !bestq))) return fail(SWA_EINVAL, "bad argument");
+  if (n == 0) return SWA_OK;
+  std::vector<long long> out;
+  rc = endpoints_on_device(db, query, qlen, seqnos, dstrands, n, out);
+  if (rc != SWA_OK) return rc;
   for (int64_t i = 0; i < n; ++i) {
     scores[i] = out[size_t(i)];
     bestpos[i] = out[size_t(n + i)];
     bestq[i] = out[size_t(2 * n + i)];
   }
+  return SWA_OK;
+}
+
+extern "C" int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
+                                    int64_t* scores, int64_t* bestpos, int64_t* bestq)
+{
+  return swa_search_endpoints_strand(db, query, qlen, seqnos, nullptr, n, scores, bestpos, bestq);
+}
+
+extern "C" int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, uint8_t* buf, int64_t cap, int64_t* len)
+{
+  if (!db || !len || cap < 0 || (cap > 0 && !buf)) return fail(SWA_EINVAL, "bad argument");
+  std::vector<uint8_t> seq;
+  const int rc = fetch_sequence(db, seqno, dstrand, seq);
+  if (rc != SWA_OK) return rc;
+  *len = int64_t(seq.size());
+  if (int64_t(seq.size()) > cap) return fail(SWA_ERANGE, "sequence buffer too small");
+  if (!seq.empty()) std::memcpy(buf, seq.data(), seq.size());
+  return SWA_OK;
+}
+
+namespace {
+// hits_align's call of align() (hits.cc:585-616) for one sequence already on the host.  hint_score != 0:
+// trust (q_end, d_end); otherwise find score and end by the forward sweep.
+int align_on_host(const uint8_t* query, int64_t qlen, const uint8_t* dseq, int64_t dlen, const int32_t* matrix,
+                  int64_t gapopen, int64_t gapextend, int64_t hint_score, int64_t q_end, int64_t d_end,
+                  swa_alignment_t& a, std::vector<swa::EditOp>& ops)
+{
+  int64_t score = hint_score;
+  a.hinted = hint_score ? 1 : 0;
+  if (!hint_score) {
+    q_end = d_end = 0;
+    score = swa::forward_end(query, qlen, dseq, dlen, matrix, gapopen, gapextend, &q_end, &d_end);
+  }
+  int64_t q_start = 0, d_start = 0;
+  if (qlen <= 0 || dlen <= 0 || q_end >= qlen || d_end >= dlen || q_end < 0 || d_end < 0 ||
+      !swa::backward_start(query, dseq, matrix, gapopen, gapextend, score, q_end, d_end, &q_start, &d_start))
+    return fail(SWA_EINVAL, "Internal error in align function.");     // align.cc:156 (e.g. a hit of score 0)
+  ops.clear();
+  swa::edit_script(query, dseq, matrix, gapopen, gapextend, q_start, d_start, q_end, d_end, ops);
+  swa::count_columns(query, dseq, matrix, q_start, d_start, ops, &a.identities, &a.positives, &a.indels, &a.aligned,
+                     &a.gaps);
+  a.score = score;
+  a.dlen = dlen;
+  a.q_start = q_start; a.q_end = q_end; a.d_start = d_start; a.d_end = d_end;
+  return SWA_OK;
+}
+}  // namespace
+
+extern "C" int swa_traceback(const uint8_t* query, int64_t qlen, const uint8_t* dseq, int64_t dlen, const int64_t* M,
+                             int64_t gapopen, int64_t gapextend, int64_t hint_score, int64_t hint_q_end,
+                             int64_t hint_d_end, swa_alignment_t* out, char* text, int64_t text_cap, int64_t* text_used)
+{
+  if (!query || !dseq || !M || !out || !text_used || text_cap < 0 || (text_cap > 0 && !text) || qlen < 0 || dlen < 0)
+    return fail(SWA_EINVAL, "bad argument");
+  for (int64_t i = 0; i < qlen; ++i) if (query[i] >= 32) return fail(SWA_EINVAL, "query symbol code >= 32");
+  for (int64_t j = 0; j < dlen; ++j) if (dseq[j] >= 32) return fail(SWA_EINVAL, "sequence symbol code >= 32");
+  std::vector<int32_t> m32(1024);
+  for (int i = 0; i < 1024; ++i) m32[size_t(i)] = int32_t(M[i]);
+  std::memset(out, 0, sizeof *out);
+  std::vector<swa::EditOp> ops;
+  const int rc = align_on_host(query, qlen, dseq, dlen, m32.data(), gapopen, gapextend, hint_score, hint_q_end,
+                               hint_d_end, *out, ops);
+  if (rc != SWA_OK) return rc;
+  std::string s;
+  for (const swa::EditOp& op : ops) { s += op.kind; s += std::to_string(op.count); }
+  out->cigar_offset = 0;
+  out->cigar_len = int64_t(s.size());
+  *text_used = int64_t(s.size()) + 1;
+  if (*text_used > text_cap) return fail(SWA_ERANGE, "text buffer too small for the edit script");
+  std::memcpy(text, s.c_str(), s.size() + 1);
+  return SWA_OK;
+}
+
+// align_chunk + hits_align (swipe.cc:339-414, hits.cc:546-618): end points on the GPU, start point and edit
+// script on the host
+extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
+                              const int32_t* dstrands, int64_t n, swa_alignment_t* out, char* text, int64_t text_cap,
+                              int64_t* text_used)
+{
+  int rc = check_query(db, query, qlen);
+  if (rc != SWA_OK) return rc;
+  if (n < 0 || text_cap < 0 || !text_used || (n > 0 && (!seqnos || !out)) || (text_cap > 0 && !text))
+    return fail(SWA_EINVAL, "bad argument");
+  *text_used = 0;
+  if (n == 0) return SWA_OK;
+  std::vector<long long> ends;
+  rc = endpoints_on_device(db, query, qlen, seqnos, dstrands, n, ends);
+  if (rc != SWA_OK) return rc;
+  const int64_t gapopen = db->goe - db->ge, gapextend = db->ge;
+  const int64_t limit16 = 65536 - db->hi;                           // SCORELIMIT_16, matrices.cc:578
+  std::string all;
+  std::vector<uint8_t> dseq;
+  std::vector<swa::EditOp> ops;
+  for (int64_t i = 0; i < n; ++i) {
+    const int strand = dstrands ? (dstrands[i] ? 1 : 0) : 0;
+    rc = fetch_sequence(db, seqnos[i], strand, dseq);
+    if (rc != SWA_OK) return rc;
+    swa_alignment_t& a = out[i];
+    std::memset(&a, 0, sizeof a);
+    const int64_t score = ends[size_t(i)], d_end = ends[size_t(n + i)], q_end = ends[size_t(2 * n + i)];
+    // the hint is honoured only if the 16-bit lanes did not saturate and neither coordinate is 0
+    // (swipe.cc:404, hits.cc:587); otherwise align() starts from scratch
+    const bool hinted = score < limit16 && q_end > 0 && d_end != 0;
+    rc = align_on_host(query, qlen, dseq.data(), int64_t(dseq.size()), db->h_matrix, gapopen, gapextend,
+                       hinted ? score : 0, q_end, d_end, a, ops);
+    if (rc != SWA_OK) return rc;
+    a.seqno = seqnos[i];
+    a.dstrand = strand;
+    a.cigar_offset = int64_t(all.size());
+    for (const swa::EditOp& op : ops) { all += op.kind; all += std::to_string(op.count); }
+    a.cigar_len = int64_t(all.size()) - a.cigar_offset;
+    all += '\0';
+  }
+  *text_used = int64_t(all.size());
+  if (int64_t(all.size()) > text_cap) return fail(SWA_ERANGE, "text buffer too small for the edit scripts");
+  std::memcpy(text, all.data(), all.size());
   return SWA_OK;
 }
 

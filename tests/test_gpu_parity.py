@@ -340,6 +340,63 @@ def test_cli_output_equals_reference_cli(tmp_path, name):
     assert [l for l in plain[k + 2:] if l.strip()] == g["plain_hits"]
 
 
+@pytest.mark.parametrize("name", ["p1k", "multivol", "nt", "asym", "edges", "limit16"])
+def test_cli_alignment_output_equals_reference_cli(tmp_path, name):
+    """-b > 0: the alignment phase end to end.  -m 7 (edit scripts, coordinates, the three alignment
+    lines), -m 8 / -m 9 (identity, length, mismatches, gap openings, coordinates, E-value, bits) and
+    the -m 0 pairwise blocks must equal the reference's output byte for byte."""
+    import subprocess
+    from conftest import ROOT
+    case, g = cases.get(name), load_golden(name)
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    alpha = blastdb.NCBISTDAA if case.protein else blastdb.NCBI4NA
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    args = [exe, "-d", base, "-i", qf, "-p", "1" if case.protein else "0", "-G", str(case.gapopen), "-E", str(case.gapextend),
+            "-v", str(case.keep), "-e", "10"]
+    if case.protein:
+        mat = case.matrix
+        if mat == "@text":
+            mat = str(tmp_path / "matrix.txt")
+            open(mat, "w").write(case.matrix_text)
+        args += ["-M", mat]
+    else:
+        args += ["-r", str(case.match), "-q", str(case.mismatch)]
+    run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
+    assert run(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]
+    assert run(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
+    t9 = run(["-m", "9", "-b", str(case.keep)]).split("\n")[1:]
+    want = g["tsv9"].split("\n")
+    assert t9[0] == want[0] and t9[1].startswith("# Database: ") and t9[2:] == want[2:]
+    plain = run(["-m", "0", "-b", str(g["nalign"])])
+    assert plain[plain.index("Sequences producing"):] == g["plain_align"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_alignment_phase_matches_reference(name):
+    """swa_align_hits (GPU end points + host traceback) for EVERY positive-scoring (sequence, strand) of the
+    case against the reference's align() as hits_align runs it (with the search16s hint whenever
+    hits.cc:587 honours it)."""
+    case, g = cases.get(name), load_golden(name)
+    db = open_case(case)
+    rows = g["align"]
+    got = db.align(case.query, [r[0] for r in rows], [r[1] for r in rows])
+    assert len(got) == len(rows)
+    for a, (seqno, ds, s16s, bp, bq, score, qs, dst, qe, de, cigar, hinted) in zip(got, rows):
+        want = hinted if hinted is not None else [score, qs, dst, qe, de, cigar]
+        assert [a["score"], a["q_start"], a["d_start"], a["q_end"], a["d_end"], a["cigar"]] == want, (seqno, ds)
+        assert a["hinted"] == (hinted is not None) and a["seqno"] == seqno and a["dstrand"] == ds
+        d = blastdb.revcomp_nt16(case.seqs[seqno]) if ds else case.seqs[seqno]
+        assert np.array_equal(db.sequence(seqno, ds), d)
+    e = db.search_endpoints(case.query, [r[0] for r in rows], [r[1] for r in rows])
+    for k, r in enumerate(rows):
+        if r[2] < g["scorelimit16"]:
+            assert (int(e[0][k]), int(e[1][k]), int(e[2][k])) == (r[2], r[3], r[4])
+    db.close()
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     import subprocess
     from conftest import ROOT

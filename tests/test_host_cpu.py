@@ -166,3 +166,36 @@ def test_shard_bounds_balance_residues():
         sizes = [int(off[hi] - off[lo]) for lo, hi in b]
         assert max(sizes) - min(sizes) <= 2 * 35000
     assert parallel.shard_bounds(np.zeros(1, np.int64), 4) == [(0, 0)] * 4
+
+
+@pytest.mark.parametrize("name", [f.__name__[5:] for f in cases.ALL])
+def test_host_traceback_matches_reference_alignments(name):
+    """swa_traceback (host half of the alignment phase) against the reference's align() outputs of the
+    goldens - every positive-scoring sequence, with and without the search16s hint - and the oracle."""
+    from conftest import load_golden
+    case, g = cases.get(name), load_golden(name)
+    M = case_matrix(case, swipe_amd)
+    Mo = case_matrix(case, oracle)
+    for seqno, ds, s16s, bp, bq, score, qs, dst, qe, de, cigar, hinted in g["align"]:
+        d = blastdb.revcomp_nt16(case.seqs[seqno]) if ds else case.seqs[seqno]
+        a = swipe_amd.traceback(case.query, d, M, case.gapopen, case.gapextend)
+        assert (a["score"], a["q_start"], a["d_start"], a["q_end"], a["d_end"], a["cigar"]) == (score, qs, dst, qe, de, cigar)
+        assert a["hinted"] == 0 and a["dlen"] == len(d)
+        if hinted is not None:
+            b = swipe_amd.traceback(case.query, d, M, case.gapopen, case.gapextend, (s16s, bq, bp))
+            assert [b["score"], b["q_start"], b["d_start"], b["q_end"], b["d_end"], b["cigar"]] == hinted
+            assert b["hinted"] == 1
+            assert oracle.align(case.query, d, Mo, case.gapopen, case.gapextend, (s16s, bq, bp)) == tuple(hinted)
+
+
+def test_host_traceback_counts_and_errors():
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    q = cases.Q375
+    d = np.concatenate([q[:100], q[103:200], np.array([1, 1], np.uint8), q[200:]])
+    a = swipe_amd.traceback(q, d, M, 11, 1)
+    assert a["cigar"] == "M100D3M97I2M175" and a["gaps"] == 2 and a["indels"] == 5 and a["aligned"] == 377
+    assert a["identities"] == 372 and a["positives"] == 372
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.traceback(q, np.zeros(0, np.uint8), M, 11, 1)      # score 0: the reference's internal error
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.traceback(q, np.full(5, 40, np.uint8), M, 11, 1)  # symbol code out of range
