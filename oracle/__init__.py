@@ -62,6 +62,10 @@ def lib():
         L.swo_align.argtypes = [u8p, C.c_long, u8p, C.c_long, lp, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long,
                                 C.c_void_p, C.c_char_p, C.c_long]
         L.swo_align.restype = C.c_long
+        L.swo_translate_table.argtypes = [C.c_int, u8p]
+        L.swo_translate_table.restype = C.c_int
+        L.swo_translate.argtypes = [u8p, C.c_long, C.c_int, C.c_int, u8p, u8p]
+        L.swo_translate.restype = C.c_long
         _LIB = L
     return _LIB
 
@@ -164,6 +168,26 @@ def align(q, d, M, gapopen, gapextend, hint=None):
     return res[4], res[0], res[1], res[2], res[3], buf.value.decode()
 
 
+def translate_table(gencode: int) -> np.ndarray:
+    t = np.zeros(4096, dtype=np.uint8)
+    if not lib().swo_translate_table(gencode, t.ctypes.data):
+        raise ValueError("Illegal genetic code specified.")
+    return t
+
+
+def translate(dna, strand: int, frame: int, table: np.ndarray) -> np.ndarray:
+    """frame (0..2) of strand (0/1) of a nucleotide sequence in nibble codes -> NCBIstdaa codes"""
+    dna, dp = _u8(dna)
+    out = np.zeros(max(len(dna) // 3, 1), dtype=np.uint8)
+    n = lib().swo_translate(dp, len(dna), strand, frame, table.ctypes.data, out.ctypes.data)
+    return out[:n].copy()
+
+
+def frames(dna, table: np.ndarray):
+    """the six translations in the reference's order 3*strand + frame"""
+    return [translate(dna, t // 3, t % 3, table) for t in range(6)]
+
+
 def pack(seqs):
     """list of residue arrays -> (concatenated uint8, int64 offsets[n+1])"""
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
@@ -232,6 +256,12 @@ class HitList:
     def hits(self):
         h = self.c
         return [(h.list[i].seqno, h.list[i].score, h.list[i].qstrand, h.list[i].dstrand) for i in range(h.count)]
+
+    def full(self):
+        """(seqno, score, qstrand, qframe, dstrand, dframe) per kept hit"""
+        h = self.c
+        return [(h.list[i].seqno, h.list[i].score, h.list[i].qstrand, h.list[i].qframe, h.list[i].dstrand, h.list[i].dframe)
+                for i in range(h.count)]
 
     def expect(self, score):
         return lib().swo_hits_expect(self._h, int(score))

@@ -482,16 +482,23 @@ swo_hits* swo_hits_new(long descriptions, long alignments, long minscore, long m
                        const char* matrix, long match, long mismatch, long gapopen, long gapextend,
                        long qlen, long dbseqs, long dbsyms, long effdbsize)
 {
-  /* hits.cc:283-511 for symtype 0 and 1 */
+  /* hits.cc:283-511 for symtype 0..4; for the translated types qlen / dbsyms are NUCLEOTIDE counts where
+     the query / database is nucleotide, as query.nt[0].len and db_getsymcount() are */
   swo_hits* h = (swo_hits*)calloc(1, sizeof(swo_hits));
   h->keephits = descriptions > alignments ? descriptions : alignments;
   long maxhits = dbseqs;
   if (symtype == 0 && querystrands == 3) maxhits *= 2;              /* hits.cc:290-294 */
+  if (symtype == 2) maxhits *= querystrands == 3 ? 6 : 3;           /* hits.cc:295-301 */
+  if (symtype == 3) maxhits *= 6;                                   /* hits.cc:302-305 */
+  if (symtype == 4) maxhits *= querystrands == 3 ? 36 : 18;         /* hits.cc:306-312 */
   if (h->keephits > maxhits) h->keephits = maxhits;
   h->list = (swo_hit*)calloc((size_t)(h->keephits > 0 ? h->keephits : 1), sizeof(swo_hit));
   swo_ka p;
   int avail = symtype == 0 ? swo_stats_nucleotide(match, mismatch, gapopen, gapextend, &p)
+            : symtype == 4 ? swo_stats_protein(matrix, 32767, 32767, &p)      /* ungapped row, hits.cc:401-410 */
                            : swo_stats_protein(matrix, gapopen, gapextend, &p);
+  if (symtype == 2 || symtype == 4) qlen = qlen / 3;               /* hits.cc:436-437 */
+  if ((symtype == 3 || symtype == 4) && effdbsize <= 0) dbsyms = dbsyms / 3;   /* hits.cc:446-449 */
   h->stats_available = avail;
   h->scorethreshold = minscore;
   h->upperscorethreshold = maxscore;
@@ -728,4 +735,54 @@ long swo_align(const unsigned char* qseq, long qlen, const unsigned char* dseq, 
   }
   free(s.text);
   return n;
+}
+
+
+/* ===== translated searches: genetic code tables and six-frame translation ================ */
+/* translate_createtable (query.cc:377-455): table[256*a + 16*b + c] for three IUPAC nibbles (A=1 C=2 G=4
+   T=8): the amino acid every compatible codon agrees on, B for a D/N mix, Z for an E/Q mix, else X */
+int swo_translate_table(int gencode, unsigned char* table)
+{
+  if (gencode < 1 || gencode > 23 || !refdata_gencode[gencode - 1][0]) return 0;
+  const char* code = refdata_gencode[gencode - 1];
+  static const int tcag_of_bit[4] = {2, 1, 3, 0};           /* bit 0 = A, 1 = C, 2 = G, 3 = T -> index in T,C,A,G order */
+  for (int a = 0; a < 16; a++)
+    for (int b = 0; b < 16; b++)
+      for (int c = 0; c < 16; c++) {
+        char aa = '-';
+        for (int i = 0; i < 4; i++)
+          for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 4; k++) {
+              if (!((a >> i) & 1) || !((b >> j) & 1) || !((c >> k) & 1)) continue;
+              const char x = code[16 * tcag_of_bit[i] + 4 * tcag_of_bit[j] + tcag_of_bit[k]];
+              if (aa == '-' || aa == x) aa = x;
+              else if (aa == 'B' && (x == 'D' || x == 'N')) ;
+              else if ((aa == 'D' && (x == 'B' || x == 'N')) || (aa == 'N' && (x == 'B' || x == 'D'))) aa = 'B';
+              else if (aa == 'Z' && (x == 'Q' || x == 'E')) ;
+              else if ((aa == 'E' && (x == 'Z' || x == 'Q')) || (aa == 'Q' && (x == 'Z' || x == 'E'))) aa = 'Z';
+              else aa = 'X';
+            }
+        if (aa == '-') aa = 'X';
+        table[256 * a + 16 * b + c] = (unsigned char) aa_code(aa);
+      }
+  return 1;
+}
+
+/* translate (query.cc:463-506) = db_translate (database.cc:1182-1218): frame f of strand s has
+   (dlen - f) / 3 codons; strand 1 reads the reverse complement.  Returns the protein length. */
+long swo_translate(const unsigned char* dna, long dlen, int strand, int frame, const unsigned char* table,
+                   unsigned char* prot)
+{
+  static const unsigned char compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  const long plen = dlen - frame >= 0 ? (dlen - frame) / 3 : 0;
+  if (!strand) {
+    long pos = frame;
+    for (long k = 0; k < plen; k++, pos += 3)
+      prot[k] = table[256 * dna[pos] + 16 * dna[pos + 1] + dna[pos + 2]];
+  } else {
+    long pos = dlen - 1 - frame;
+    for (long k = 0; k < plen; k++, pos -= 3)
+      prot[k] = table[256 * compl4[dna[pos] & 15] + 16 * compl4[dna[pos - 1] & 15] + compl4[dna[pos - 2] & 15]];
+  }
+  return plen;
 }

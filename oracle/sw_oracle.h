@@ -90,6 +90,13 @@ double swo_hits_expect(const swo_hits* h, long score);   /* Kmn * exp(-lambda*sc
 double swo_hits_bits(const swo_hits* h, long score);     /* lambda/ln2*score - lnK/ln2 */
 void swo_hits_free(swo_hits* h);
 
+/* ---- translated searches (query.cc:377-506, database.cc:1182-1218) -------------------------- */
+/* table[4096] indexed 256*a + 16*b + c by three IUPAC nibbles; 0 for an unassigned genetic code number */
+int  swo_translate_table(int gencode, unsigned char* table);
+/* frame (0..2) of strand (0/1) of dna[dlen] (nibble codes) into prot; returns (dlen - frame) / 3 */
+long swo_translate(const unsigned char* dna, long dlen, int strand, int frame, const unsigned char* table,
+                   unsigned char* prot);
+
 /* ---- alignment phase (align.cc:38-519 as called from hits_align, hits.cc:546-618) ---------- */
 typedef struct { long q_start, d_start, q_end, d_end, score; } swo_alignment;
 /* gapopen/gapextend as passed by hits_align (NOT open+extend).  hint_score != 0: trust

@@ -49,6 +49,17 @@ class Case:
     volumes: int = 1
     keep: int = 250
     extra: dict = field(default_factory=dict)
+    symtype: Optional[int] = None     # reference -p: 0 nt, 1 aa, 2 translated query, 3 translated db, 4 both
+    query_gencode: int = 1
+    db_gencode: int = 1
+
+    @property
+    def sym(self) -> int:
+        return self.symtype if self.symtype is not None else (1 if self.protein else 0)
+
+    @property
+    def query_is_nt(self) -> bool:
+        return self.sym in (0, 2, 4)
 
     def checksum(self) -> str:
         h = hashlib.sha1()
@@ -123,11 +134,72 @@ def case_multivol() -> Case:
     return Case("multivol", True, c.seqs[:400], Q375, volumes=3, keep=50)
 
 
+STANDARD_CODE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"   # codons in T,C,A,G order
+
+
+def back_translate(protein: np.ndarray, salt: int = 0) -> np.ndarray:
+    """NCBIstdaa codes -> one-hot nucleotide codes (A=1 C=2 G=4 T=8), picking among synonymous codons of the
+    standard code deterministically."""
+    base = [8, 2, 1, 4]     # T C A G
+    out = []
+    for k, aa in enumerate(protein):
+        letter = blastdb.NCBISTDAA[int(aa)]
+        codons = [c for c in range(64) if STANDARD_CODE[c] == letter] or [c for c in range(64) if STANDARD_CODE[c] == "A"]
+        c = codons[(k * 7 + salt) % len(codons)]
+        out += [base[c >> 4], base[(c >> 2) & 3], base[c & 3]]
+    return np.array(out, dtype=np.uint8)
+
+
+def case_blastx() -> Case:
+    """-p 2: nucleotide query translated in six frames against a protein database."""
+    rtab, ntab = synth.residue_table_protein(), synth.residue_table_nucleotide()
+    ltab = synth.length_table()
+    gene = back_translate(Q375[40:160], 1)
+    other = blastdb.revcomp_nt16(back_translate(Q375[200:290], 2))
+    q = np.concatenate([_rng_seq(21, 2, ntab), gene, _rng_seq(22, 31, ntab), other, _rng_seq(23, 4, ntab)])
+    q[100] = 15          # N inside a codon
+    q[203] = 5           # R
+    seqs = [synth.make_sequence(3, s, ltab, rtab, None) for s in range(120)]
+    seqs += [Q375, Q375[30:170], Q375[190:300], Q375[::-1].copy(), np.zeros(0, np.uint8), Q375[:1], Q375[50:53]]
+    return Case("blastx", True, seqs, q, keep=40, symtype=2)
+
+
+def case_tblastn() -> Case:
+    """-p 3: protein query against a nucleotide database translated in six frames (genetic code 4 for the
+    database: TGA = W)."""
+    rtab, ntab = synth.residue_table_protein(), synth.residue_table_nucleotide()
+    ltab = synth.length_table()
+    q = Q375[:150]
+    seqs = [synth.make_sequence(4, s, ltab, ntab, None) for s in range(100)]
+    gene = back_translate(q[10:140], 3)
+    seqs += [np.concatenate([_rng_seq(31, 7, ntab), gene, _rng_seq(32, 11, ntab)]),          # frame +2
+             np.concatenate([_rng_seq(33, 3, ntab), blastdb.revcomp_nt16(gene), _rng_seq(34, 5, ntab)]),   # minus strand
+             np.concatenate([gene[:150], _rng_seq(35, 1, ntab), gene[150:]])]                # frame shift inside
+    amb = gene.copy()
+    amb[30:33] = 15
+    amb[61] = 3           # M = A|C
+    seqs += [amb, np.zeros(0, np.uint8), gene[:1], gene[:2], gene[:3], gene[:4], gene[:5], gene[:6], gene[:7]]
+    return Case("tblastn", False, seqs, q, keep=40, symtype=3, db_gencode=4)
+
+
+def case_tblastx() -> Case:
+    """-p 4: both translated (36 frame pairs); query code 1, database code 2."""
+    ntab = synth.residue_table_nucleotide()
+    ltab = synth.length_table()
+    gene = back_translate(Q375[100:200], 5)
+    q = np.concatenate([_rng_seq(41, 1, ntab), gene, _rng_seq(42, 20, ntab)])
+    seqs = [synth.make_sequence(5, s, ltab, ntab, None)[:400] for s in range(40)]
+    seqs += [np.concatenate([_rng_seq(43, 5, ntab), gene[30:270], _rng_seq(44, 9, ntab)]),
+             blastdb.revcomp_nt16(np.concatenate([_rng_seq(45, 10, ntab), gene[:200]])), q.copy(), np.zeros(0, np.uint8), q[:4]]
+    return Case("tblastx", False, seqs, q, keep=40, symtype=4, query_gencode=1, db_gencode=2)
+
+
 ALL = [case_p1k, case_edges, case_limit16, case_asym, case_nt, case_multivol]
+TRANSLATED = [case_blastx, case_tblastn, case_tblastx]
 
 
 def get(name: str) -> Case:
-    for f in ALL:
+    for f in ALL + TRANSLATED:
         if f.__name__ == "case_" + name:
             return f()
     raise KeyError(name)

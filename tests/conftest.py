@@ -33,7 +33,7 @@ def load_golden(name):
 
 def case_matrix(case, mod):
     """matrix (int64[1024]) of a case through module `mod` (oracle or swipe_amd)."""
-    if not case.protein:
+    if case.sym == 0:
         return mod.matrix_nucleotide(case.match, case.mismatch)
     if case.matrix == "@text":
         return mod.matrix_parse(case.matrix_text)

@@ -117,3 +117,74 @@ def test_stats_tables():
     assert oracle.stats_protein("BLOSUM62", 11, 1)[:2] == (0.267, 0.041)
     assert oracle.stats_nucleotide(1, -3, 5, 2)[:2] == (1.374, 0.711)     # both >= maxima -> the (0,0) row
     assert oracle.stats_protein("BLOSUM62", 3, 3) is None
+
+
+TNAMES = [f.__name__[5:] for f in cases.TRANSLATED]
+
+
+def frame_sets(case):
+    """(query frames, per-sequence database frames) the reference searches for -p 2/3/4 (swipe.cc:289-324)"""
+    qt = oracle.translate_table(case.query_gencode)
+    dt = oracle.translate_table(case.db_gencode)
+    qf = oracle.frames(case.query, qt) if case.sym in (2, 4) else [case.query]
+    df = [oracle.frames(s, dt) if case.sym in (3, 4) else [s] for s in case.seqs]
+    return qf, df
+
+
+@pytest.mark.parametrize("name", TNAMES)
+def test_translated_case_regenerates_identically(name):
+    assert cases.get(name).checksum() == load_golden(name)["checksum"]
+
+
+@pytest.mark.parametrize("name", TNAMES)
+def test_translated_lanes_and_alignments_match_reference(name):
+    """genetic-code tables + six-frame translation (query.cc:377-506, database.cc:1182-1218) feeding the same
+    kernels: every (query frame, database frame) pair of every sequence, all lane widths, and align()."""
+    case, g = cases.get(name), load_golden(name)
+    M = case_matrix(case, oracle)
+    goe, ge = case.gapopen + case.gapextend, case.gapextend
+    qf, df = frame_sets(case)
+    assert len(g["raw"]) == len(case.seqs) * len(qf) * len(df[0])
+    for seqno, qtag, dtag, length, s7a, s7b, s16, bp16, s63, s16s, bp16s, bq16s in g["raw"]:
+        d, q = df[seqno][dtag], qf[qtag]
+        assert len(d) == length
+        assert oracle.search7_lane(d, q, M, goe, ge) == s7a == s7b
+        assert oracle.search16_lane(d, q, M, goe, ge) == (s16, bp16)
+        assert oracle.search16s_lane(d, q, M, goe, ge) == (s16s, bp16s, bq16s)
+        assert oracle.fullsw(d, q, M, goe, ge) == s63
+    assert g["align"]
+    for seqno, qtag, dtag, s16s, bp, bq, score, qs, dst, qe, de, cigar, hinted in g["align"]:
+        d, q = df[seqno][dtag], qf[qtag]
+        assert oracle.align(q, d, M, case.gapopen, case.gapextend) == (score, qs, dst, qe, de, cigar)
+        if hinted is not None:
+            assert oracle.align(q, d, M, case.gapopen, case.gapextend, (s16s, bq, bp)) == tuple(hinted)
+
+
+@pytest.mark.parametrize("name", TNAMES)
+def test_translated_hit_list_matches_cli(name):
+    """hits_init for symtype 2/3/4 (lengths in codons, ungapped statistics for -p 4, maxhits per frame pair)
+    and the insertion order (query frame outer, database frame inner, swipe.cc:1403-1470)."""
+    case, g = cases.get(name), load_golden(name)
+    assert g["cli"]["1"] == g["cli"]["8"]
+    cli = g["cli"]["1"]
+    nsym = int(sum(len(s) for s in case.seqs))
+    h = oracle.HitList(descriptions=case.keep, alignments=0, symtype=case.sym, matrix=case.matrix, gapopen=case.gapopen,
+                       gapextend=case.gapextend, qlen=len(case.query), dbseqs=len(case.seqs), dbsyms=nsym)
+    qtags = sorted({r[1] for r in g["raw"]})
+    for qt in qtags:                                     # one search_chunk pass per query frame
+        for r in g["raw"]:
+            if r[1] == qt:
+                h.enter(r[0], r[8], qt // 3, qt % 3, r[2] // 3, r[2] % 3)
+    got = h.full()
+    assert [x[0] for x in got] == cli["seqno"]
+    assert [x[1] for x in got] == cli["score"]
+    label = lambda s, f: "%s%d" % ("-" if s else "+", f + 1)
+    if case.sym == 2:
+        assert [label(x[2], x[3]) for x in got] == cli["strand"]
+    elif case.sym == 3:
+        assert [label(x[4], x[5]) for x in got] == cli["strand"]
+    else:
+        assert [label(x[2], x[3]) + "/" + label(x[4], x[5]) for x in got] == cli["strand"]
+    assert h.c.stats_available
+    assert ["%.2g" % h.expect(x[1]) for x in got] == cli["evalue"]
+    assert ["%.1f" % h.bits(x[1]) for x in got] == cli["bits"]
