@@ -46,6 +46,11 @@ extern "C" {
 
 #define SWA_SYMTYPE_NUCLEOTIDE 0   /* reference symtype 0: 4-bit base masks, A=1 C=2 G=4 T=8 */
 #define SWA_SYMTYPE_PROTEIN    1   /* reference symtype 1: NCBIstdaa codes 0..27 */
+/* translated searches (reference -p 2/3/4, swipe.cc:289-324): the names only select statistics in
+   swa_stats_init; the searches themselves are protein searches over translated frames */
+#define SWA_SYMTYPE_TRANSLATED_QUERY 2   /* nucleotide query in 3/6 frames against a protein database */
+#define SWA_SYMTYPE_TRANSLATED_DB    3   /* protein query against a nucleotide database in 6 frames */
+#define SWA_SYMTYPE_TRANSLATED_BOTH  4   /* 3/6 query frames against 6 database frames */
 
 typedef struct swa_db swa_db;     /* one database shard resident in HBM, read-only after open */
 
@@ -56,6 +61,8 @@ typedef struct {
   int64_t first_seqno;   /* global number of the shard's first sequence */
   int64_t total_seqcount, total_symcount;   /* whole database (all shards), for statistics */
   int64_t hbm_bytes;     /* device memory held */
+  int64_t frames;        /* 1, or 6 for a nucleotide shard held as its six translations (then seqcount,
+                            symcount, longest and total_* count nucleotide sequences / bases) */
 } swa_db_info_t;
 
 /* counters of the escalation loop; the reference's compute7/compute16/compute63
@@ -88,6 +95,16 @@ SWA_API int swa_db_open(const char* basename, int symtype, int device,
 SWA_API int swa_db_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq,
                        int symtype, int device, int64_t first_seqno,
                        int64_t total_seqcount, int64_t total_symcount, swa_db** out);
+/* Translated database (reference -p 3 / -p 4: db_getsequence translating on every fetch,
+   database.cc:1360-1388).  Here the nucleotide shard is translated ONCE, on the GPU, into its six frames
+   (genetic code db_gencode, 1..23) and from then on behaves as a protein shard of 6 * nseq virtual
+   sequences, virtual index 6 * (seqno - first_seqno) + 3 * dstrand + dframe, in the reference's order.
+   swa_search then delivers 6 scores per sequence; hit lists come from swa_search_frames_topk. */
+SWA_API int swa_db_open_translated(const char* basename, int db_gencode, int device, int64_t first_seqno,
+                           int64_t last_seqno, swa_db** out);
+SWA_API int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
+                                  int db_gencode, int device, int64_t first_seqno, int64_t total_seqcount,
+                                  int64_t total_symcount, swa_db** out);
 SWA_API int swa_db_info(const swa_db* db, swa_db_info_t* info);
 /* Host-only: read sequences [first_seqno, last_seqno] of a BLAST v4 database into malloc'ed
    arrays in reference symbol codes (what db_getsequence returns, database.cc:1237-1401:
@@ -115,7 +132,9 @@ SWA_API int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapopenex
 
 /* ---- search --------------------------------------------------------------------------------- */
 /* Exact Smith-Waterman score of `query` (reference symbol codes) against every sequence of the
-   shard: scores[s - first_seqno].  `scores` may be NULL (bench: results stay on device). */
+   shard: scores[s - first_seqno]; for a translated shard 6 scores per sequence,
+   scores[6 * (s - first_seqno) + 3 * dstrand + dframe].  `scores` may be NULL (bench: results stay on
+   device). */
 SWA_API int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores,
                swa_counters_t* counters);
 /* The hits_enter loop on device: keeps the `keep` best (score desc, seqno desc) among
@@ -136,6 +155,18 @@ SWA_API int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* q
                      int64_t keep, int64_t minscore, int64_t maxscore, swa_hit_t* hits,
                      int32_t* which, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                      swa_counters_t* counters);
+/* The general form behind every -p mode: nq query frames (1 for -p 1/3, 3 or 6 for -p 2/4; also the two
+   strands of -p 0) against every frame the shard holds, merged into ONE hit list exactly as the
+   reference's search_chunk + hits_enter leave it (swipe.cc:1403-1592, hits.cc:163-222): score descending,
+   sequence number descending, then query frame (position in `queries`) and database frame ascending - the
+   reference's insertion order for equal (score, seqno).  qtags[i] = 3 * qstrand + qframe is copied into the
+   hits of query i.  Frames of length 0 are legal. */
+typedef struct { int64_t seqno, score; int32_t qstrand, qframe, dstrand, dframe; } swa_fhit_t;
+SWA_API int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* queries, const int64_t* qlens,
+                           const int32_t* qtags, int64_t keep, int64_t minscore, int64_t maxscore,
+                           swa_fhit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
+                           swa_counters_t* counters);
+
 /* Alignment-phase end points (search16s, swipe.h:237-249; called from align_chunk, swipe.cc:381): for
    each listed sequence the exact score, the 0-based database column where the final maximum is first
    reached and the smallest query row holding it in that column (search16s.cc:391-405).  Values equal
@@ -143,15 +174,20 @@ SWA_API int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* q
    which it uses them, swipe.cc:404). */
 SWA_API int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
                          int64_t* scores, int64_t* bestpos, int64_t* bestq);
-/* Same for (sequence, database strand) pairs: dstrands[i] = 1 takes the reverse complement of a
-   nucleotide sequence, which is how the reference aligns minus-strand hits - plus query against
-   db_getsequence(seqno, strand 1) (swipe.cc:359-362, database.cc:1327-1339).  dstrands may be NULL. */
+/* Same for (sequence, database strand, database frame) triples, the reference's packed start_list entries
+   (seqno << 3) | (dstrand << 2) | dframe (swipe.cc:359-362).  Nucleotide shard: dstrands[i] = 1 takes the
+   reverse complement, which is how the reference aligns minus-strand hits - plus query against
+   db_getsequence(seqno, strand 1) (database.cc:1327-1339).  Translated shard: (dstrand, dframe) picks one
+   of the six translations.  dstrands / dframes may be NULL (= 0). */
 SWA_API int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
-                         const int32_t* dstrands, int64_t n, int64_t* scores, int64_t* bestpos, int64_t* bestq);
+                         const int32_t* dstrands, const int32_t* dframes, int64_t n, int64_t* scores,
+                         int64_t* bestpos, int64_t* bestq);
 /* db_getsequence (swipe.h:344, database.cc:1237) out of the resident shard: residues of one sequence in
-   reference symbol codes, reverse-complemented for dstrand 1.  *len is set even when cap is too small
-   (the call then returns SWA_ERANGE). */
-SWA_API int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, uint8_t* buf, int64_t cap, int64_t* len);
+   reference symbol codes - reverse-complemented for dstrand 1 of a nucleotide shard, the chosen translation
+   of a translated shard (*ntlen = its nucleotide length, else 0; may be NULL).  *len is set even when cap
+   is too small (the call then returns SWA_ERANGE). */
+SWA_API int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, uint8_t* buf, int64_t cap,
+                    int64_t* len, int64_t* ntlen);
 
 /* The alignment phase for a list of hits: align_chunk + hits_align + align (swipe.cc:339-414,
    hits.cc:546-618, align.cc:469-519).  End points come from the GPU (search16s semantics), the start
@@ -162,19 +198,21 @@ SWA_API int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, uint8_t* buf
    against a gap), e.g. "M120D2M31I1M7".  Counts follow count_align (hits.cc:1021-1109). */
 typedef struct {
   int64_t seqno;
-  int32_t dstrand;
+  int32_t dstrand, dframe;
   int32_t hinted;                 /* 1: the search16s end point was used (hits.cc:587), 0: forward sweep */
+  int32_t reserved;
   int64_t score;
   int64_t q_start, q_end, d_start, d_end;
-  int64_t dlen;
+  int64_t dlen;                   /* length of the sequence aligned against (a translation for translated shards) */
+  int64_t dlennt;                 /* its nucleotide length for translated shards (hits.cc:567), else 0 */
   int64_t identities, positives, indels, aligned, gaps;
   int64_t cigar_offset, cigar_len; /* edit script = text[cigar_offset .. +cigar_len), NUL-terminated */
 } swa_alignment_t;
 /* text receives all edit scripts back to back; *text_used = bytes needed.  SWA_ERANGE if text_cap is
    smaller (out[] is complete even then; call again with a larger buffer for the scripts). */
 SWA_API int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
-                   const int32_t* dstrands, int64_t n, swa_alignment_t* out, char* text, int64_t text_cap,
-                   int64_t* text_used);
+                   const int32_t* dstrands, const int32_t* dframes, int64_t n, swa_alignment_t* out, char* text,
+                   int64_t text_cap, int64_t* text_used);
 
 /* The host part alone, for one sequence the caller holds (e.g. rank 0 finishing hits of other shards):
    align() as hits_align calls it.  M as for swa_set_scoring; gapopen/gapextend are the -G/-E values
@@ -198,6 +236,8 @@ typedef struct {
   int64_t lenadj, m, n;
   int64_t scorethreshold, upperscorethreshold;   /* after the E-value cut, hits.cc:486-508 */
 } swa_stats_t;
+/* symtype 0..4 as the reference's -p; for the translated types pass NUCLEOTIDE counts where the query /
+   database is nucleotide (qlen = query.nt[0].len, db_symcount = bases), as hits_init reads them. */
 SWA_API int swa_stats_init(int symtype, const char* matrixname, int64_t match, int64_t mismatch,
                    int64_t gapopen, int64_t gapextend, int64_t qlen,
                    int64_t db_seqcount, int64_t db_symcount, int64_t effdbsize,
@@ -205,6 +245,15 @@ SWA_API int swa_stats_init(int symtype, const char* matrixname, int64_t match, i
                    swa_stats_t* out);
 SWA_API double swa_evalue(const swa_stats_t* st, int64_t score);   /* hits.cc:1777 */
 SWA_API double swa_bits(const swa_stats_t* st, int64_t score);     /* hits.cc:1779 */
+/* Genetic codes 1..23 (query.cc:118-170).  swa_translate_table fills table[4096], indexed 256a + 16b + c
+   by the three IUPAC nibbles of a codon, with NCBIstdaa codes (translate_createtable, query.cc:377-455);
+   swa_translate is translate() / db_translate() (query.cc:463-506): frame 0..2 of strand 0/1, *plen =
+   (dlen - frame) / 3 residues into prot.  Host helpers for queries; databases are translated on the GPU. */
+SWA_API const char* swa_gencode_name(int gencode);   /* NULL for an unassigned number */
+SWA_API int swa_translate_table(int gencode, uint8_t* table);
+SWA_API int swa_translate(const uint8_t* dna, int64_t dlen, int strand, int frame, const uint8_t* table,
+                  uint8_t* prot, int64_t* plen);
+
 /* Built-in matrices by name (matrices.cc:540-559); returns SWA_EINVAL for unknown names. */
 SWA_API int swa_matrix_builtin(const char* name, int64_t* matrix);
 SWA_API int swa_matrix_nucleotide(int64_t match, int64_t mismatch, int64_t* matrix);

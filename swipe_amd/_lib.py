@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libswipe_amd.so")
 
 class DbInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("seqcount", "symcount", "longest", "first_seqno",
-                                         "total_seqcount", "total_symcount", "hbm_bytes")]
+                                         "total_seqcount", "total_symcount", "hbm_bytes", "frames")]
 
 
 class Counters(C.Structure):
@@ -29,9 +29,15 @@ class Hit(C.Structure):
 
 
 class Alignment(C.Structure):
-    _fields_ = [("seqno", C.c_int64), ("dstrand", C.c_int32), ("hinted", C.c_int32)] + \
-               [(n, C.c_int64) for n in ("score", "q_start", "q_end", "d_start", "d_end", "dlen", "identities",
+    _fields_ = [("seqno", C.c_int64), ("dstrand", C.c_int32), ("dframe", C.c_int32), ("hinted", C.c_int32),
+                ("reserved", C.c_int32)] + \
+               [(n, C.c_int64) for n in ("score", "q_start", "q_end", "d_start", "d_end", "dlen", "dlennt", "identities",
                                          "positives", "indels", "aligned", "gaps", "cigar_offset", "cigar_len")]
+
+
+class FrameHit(C.Structure):
+    _fields_ = [("seqno", C.c_int64), ("score", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("qstrand", "qframe", "dstrand", "dframe")]
 
 
 class Stats(C.Structure):
@@ -43,6 +49,8 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
+    "swa_db_open_translated", "swa_db_from_memory_translated", "swa_search_frames_topk",
+    "swa_gencode_name", "swa_translate_table", "swa_translate",
     "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
     "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
@@ -81,9 +89,17 @@ def load():
     L.swa_search2_topk.argtypes = [vp, vp, vp, i64, i64, i64, i64, C.POINTER(Hit), C.POINTER(C.c_int32), i64p, i64p, i64p,
                                    C.POINTER(Counters)]
     L.swa_search_endpoints.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp]
-    L.swa_search_endpoints_strand.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, vp]
-    L.swa_db_sequence.argtypes = [vp, i64, C.c_int, vp, i64, i64p]
-    L.swa_align_hits.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(Alignment), C.c_char_p, i64, i64p]
+    L.swa_search_endpoints_strand.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, vp]
+    L.swa_db_sequence.argtypes = [vp, i64, C.c_int, C.c_int, vp, i64, i64p, i64p]
+    L.swa_align_hits.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(Alignment), C.c_char_p, i64, i64p]
+    L.swa_db_open_translated.argtypes = [C.c_char_p, C.c_int, C.c_int, i64, i64, C.POINTER(vp)]
+    L.swa_db_from_memory_translated.argtypes = [vp, vp, i64, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp)]
+    L.swa_search_frames_topk.argtypes = [vp, C.c_int, C.POINTER(vp), i64p, C.POINTER(C.c_int32), i64, i64, i64,
+                                         C.POINTER(FrameHit), i64p, i64p, i64p, C.POINTER(Counters)]
+    L.swa_gencode_name.argtypes = [C.c_int]
+    L.swa_gencode_name.restype = C.c_char_p
+    L.swa_translate_table.argtypes = [C.c_int, vp]
+    L.swa_translate.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, i64p]
     L.swa_traceback.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, C.POINTER(Alignment), C.c_char_p, i64, i64p]
     L.swa_hits_merge.argtypes = [C.POINTER(Hit), i64p, C.c_int, i64, i64, C.POINTER(Hit), i64p]
     L.swa_stats_init.argtypes = [C.c_int, C.c_char_p, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,

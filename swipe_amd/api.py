@@ -106,13 +106,29 @@ class Database:
         return cls(h)
 
     @classmethod
+    def open_translated(cls, basename: str, *, db_gencode: int = 1, device: int = 0, first_seqno: int = 0,
+                        last_seqno: int = -1):
+        """A nucleotide database held as its six translations (reference -p 3 / -p 4)."""
+        h = C.c_void_p()
+        _check(_lib.load().swa_db_open_translated(os.fsencode(basename), db_gencode, device, first_seqno, last_seqno,
+                                                  C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_arrays(cls, residues: np.ndarray, offsets: np.ndarray, *, symtype: int = 1, device: int = 0,
-                    first_seqno: int = 0, total_seqcount: int = 0, total_symcount: int = 0):
+                    first_seqno: int = 0, total_seqcount: int = 0, total_symcount: int = 0,
+                    translate_gencode: Optional[int] = None):
+        """translate_gencode: residues are nucleotides to be held as their six translations under that code"""
         residues = np.ascontiguousarray(residues, dtype=np.uint8)
         offsets = _i64(offsets)
         h = C.c_void_p()
-        _check(_lib.load().swa_db_from_memory(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1, symtype,
-                                              device, first_seqno, total_seqcount, total_symcount, C.byref(h)))
+        if translate_gencode is not None:
+            _check(_lib.load().swa_db_from_memory_translated(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                                             translate_gencode, device, first_seqno, total_seqcount,
+                                                             total_symcount, C.byref(h)))
+        else:
+            _check(_lib.load().swa_db_from_memory(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1, symtype,
+                                                  device, first_seqno, total_seqcount, total_symcount, C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -136,7 +152,8 @@ class Database:
     def search(self, query: np.ndarray, *, want_scores: bool = True):
         q = np.ascontiguousarray(query, dtype=np.uint8)
         c = _lib.Counters()
-        scores = np.empty(self.info()["seqcount"], dtype=np.int64) if want_scores else None
+        i = self.info()
+        scores = np.empty(i["seqcount"] * i["frames"], dtype=np.int64) if want_scores else None
         _check(_lib.load().swa_search(self._h, q.ctypes.data, len(q), scores.ctypes.data if want_scores else None,
                                       C.byref(c)))
         return scores, {f: getattr(c, f) for f, _ in c._fields_}
@@ -158,7 +175,7 @@ class Database:
         if len(q1) != len(q2):
             raise SwaError("search2 needs two queries of equal length")
         c = _lib.Counters()
-        n = self.info()["seqcount"]
+        n = self.info()["seqcount"] * self.info()["frames"]
         s1 = np.empty(n, dtype=np.int64) if want_scores else None
         s2 = np.empty(n, dtype=np.int64) if want_scores else None
         _check(_lib.load().swa_search2(self._h, q1.ctypes.data, q2.ctypes.data, len(q1),
@@ -180,30 +197,50 @@ class Database:
         return ([(hits[i].seqno, hits[i].score, which[i]) for i in range(n.value)], tot.value, obv.value,
                 {f: getattr(c, f) for f, _ in c._fields_})
 
-    def search_endpoints(self, query: np.ndarray, seqnos, dstrands=None):
+    def search_frames_topk(self, queries, qtags=None, *, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
+        """Up to six query frames against every frame the shard holds, one merged hit list in the reference's
+        order: ([(seqno, score, qstrand, qframe, dstrand, dframe)], totalhits, obvious, counters)."""
+        L = _lib.load()
+        qs = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
+        ptr = (C.c_void_p * len(qs))(*[q.ctypes.data for q in qs])
+        lens = (C.c_int64 * len(qs))(*[len(q) for q in qs])
+        tags = (C.c_int32 * len(qs))(*(qtags if qtags is not None else range(len(qs))))
+        hits = (_lib.FrameHit * max(keep, 1))()
+        n, tot, obv = C.c_int64(), C.c_int64(), C.c_int64()
+        c = _lib.Counters()
+        _check(L.swa_search_frames_topk(self._h, len(qs), ptr, lens, tags, keep, minscore, maxscore, hits, C.byref(n),
+                                        C.byref(tot), C.byref(obv), C.byref(c)))
+        return ([(h.seqno, h.score, h.qstrand, h.qframe, h.dstrand, h.dframe) for h in hits[: n.value]], tot.value,
+                obv.value, {f: getattr(c, f) for f, _ in c._fields_})
+
+    def search_endpoints(self, query: np.ndarray, seqnos, dstrands=None, dframes=None):
         """(score, bestpos, bestq) per listed sequence - the reference's search16s for the alignment phase.
-        dstrands[i] = 1: against the reverse complement of that (nucleotide) sequence."""
+        dstrands[i] = 1: against the reverse complement of that (nucleotide) sequence; translated shards take
+        (dstrand, dframe)."""
         q = np.ascontiguousarray(query, dtype=np.uint8)
         ids = _i64(seqnos)
         out = [np.empty(len(ids), dtype=np.int64) for _ in range(3)]
         ds = None if dstrands is None else np.ascontiguousarray(dstrands, dtype=np.int32)
+        df = None if dframes is None else np.ascontiguousarray(dframes, dtype=np.int32)
         _check(_lib.load().swa_search_endpoints_strand(self._h, q.ctypes.data, len(q), ids.ctypes.data,
-                                                       None if ds is None else ds.ctypes.data, len(ids),
+                                                       None if ds is None else ds.ctypes.data,
+                                                       None if df is None else df.ctypes.data, len(ids),
                                                        out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
         return out
 
-    def sequence(self, seqno: int, dstrand: int = 0) -> np.ndarray:
-        """db_getsequence: residues of one sequence of the shard (reverse-complemented for dstrand 1)."""
+    def sequence(self, seqno: int, dstrand: int = 0, dframe: int = 0) -> np.ndarray:
+        """db_getsequence: residues of one sequence of the shard (reverse-complemented for dstrand 1 of a
+        nucleotide shard; the chosen translation of a translated shard)."""
         L = _lib.load()
         n = C.c_int64()
-        rc = L.swa_db_sequence(self._h, seqno, dstrand, None, 0, C.byref(n))
+        rc = L.swa_db_sequence(self._h, seqno, dstrand, dframe, None, 0, C.byref(n), None)
         if rc not in (0, _lib.SWA_ERANGE):
             _check(rc)
         buf = np.empty(max(n.value, 1), dtype=np.uint8)
-        _check(L.swa_db_sequence(self._h, seqno, dstrand, buf.ctypes.data, n.value, C.byref(n)))
+        _check(L.swa_db_sequence(self._h, seqno, dstrand, dframe, buf.ctypes.data, n.value, C.byref(n), None))
         return buf[: n.value]
 
-    def align(self, query: np.ndarray, seqnos, dstrands=None):
+    def align(self, query: np.ndarray, seqnos, dstrands=None, dframes=None):
         """The reference's alignment phase (align_chunk + hits_align + align) for the listed hits: a list of
         dicts with score, 0-based inclusive q_start/q_end/d_start/d_end, the edit script ("M..D..I.."),
         identities, positives, indels, aligned, gaps, dlen, and whether the GPU end point was used."""
@@ -211,13 +248,14 @@ class Database:
         q = np.ascontiguousarray(query, dtype=np.uint8)
         ids = _i64(seqnos)
         ds = None if dstrands is None else np.ascontiguousarray(dstrands, dtype=np.int32)
+        df = None if dframes is None else np.ascontiguousarray(dframes, dtype=np.int32)
         out = (_lib.Alignment * max(len(ids), 1))()
         cap = 1 << 16
         while True:
             text = C.create_string_buffer(cap)
             used = C.c_int64()
             rc = L.swa_align_hits(self._h, q.ctypes.data, len(q), ids.ctypes.data, None if ds is None else ds.ctypes.data,
-                                  len(ids), out, text, cap, C.byref(used))
+                                  None if df is None else df.ctypes.data, len(ids), out, text, cap, C.byref(used))
             if rc == _lib.SWA_ERANGE:
                 cap = used.value
                 continue
@@ -238,7 +276,7 @@ class Database:
 
 
 def _alignment_dict(a, text: bytes) -> dict:
-    d = {f: getattr(a, f) for f, _ in a._fields_ if not f.startswith("cigar_")}
+    d = {f: getattr(a, f) for f, _ in a._fields_ if not f.startswith("cigar_") and f != "reserved"}
     d["cigar"] = text[a.cigar_offset: a.cigar_offset + a.cigar_len].decode()
     return d
 
@@ -258,6 +296,22 @@ def traceback(query, dseq, matrix, gapopen: int, gapextend: int, hint=None) -> d
     _check(L.swa_traceback(q.ctypes.data, len(q), d.ctypes.data, len(d), M.ctypes.data, gapopen, gapextend, hs, hq, hd,
                            C.byref(a), text, cap, C.byref(used)))
     return _alignment_dict(a, text.raw)
+
+
+def translate_table(gencode: int) -> np.ndarray:
+    """table[4096] of NCBIstdaa codes indexed by three IUPAC nibbles (translate_createtable)"""
+    t = np.zeros(4096, dtype=np.uint8)
+    _check(_lib.load().swa_translate_table(gencode, t.ctypes.data))
+    return t
+
+
+def translate(dna, strand: int, frame: int, table: np.ndarray) -> np.ndarray:
+    """translate(): frame 0..2 of strand 0/1 of a nucleotide sequence (nibble codes) as NCBIstdaa codes"""
+    d = np.ascontiguousarray(dna, dtype=np.uint8)
+    out = np.zeros(max(len(d) // 3, 1), dtype=np.uint8)
+    n = C.c_int64()
+    _check(_lib.load().swa_translate(d.ctypes.data, len(d), strand, frame, table.ctypes.data, out.ctypes.data, C.byref(n)))
+    return out[: n.value].copy()
 
 
 def read_blastdb(basename: str, *, symtype: int = 1, first_seqno: int = 0, last_seqno: int = -1):

@@ -1,5 +1,5 @@
-// swipe_amd: command-line driver with SWIPE's options for the searches this library covers
-// (protein -p 1 / blastp and nucleotide -p 0 / blastn), on one MI355X.
+// swipe_amd: command-line driver with SWIPE's options on one MI355X: -p 0 blastn, 1 blastp, 2 blastx,
+// 3 tblastn, 4 tblastx (translated databases are translated once on the GPU when they are opened).
 //
 // Mirrors the control flow of the reference's main()/work() (swipe.cc:2436-2611): open the
 // database once, then for every query of the FASTA file: hits_init thresholds, search, hit list,
@@ -123,20 +123,48 @@ void show_deflines(FILE* out, const std::string& all, long indent, size_t maxlen
 // one aligned hit with what the display code of hits.cc needs
 struct Shown {
   swa_alignment_t a;
+  int qstrand = 0, qframe = 0;
   std::string script;             // "M12D1..."
   std::vector<uint8_t> dseq;      // database sequence in the frame it was aligned in
+  const std::vector<uint8_t>* qseq = nullptr;   // query frame it was aligned with
   long q_first = 0, q_last = 0, d_first = 0, d_last = 0;
   int poswidth = 1;
 };
 
+// what a display routine needs to know about the search type
+struct Mode {
+  long symtype;
+  long q_len_nt;                  // nucleotide length of the query (symtype 0, 2, 4)
+  bool q_translated() const { return symtype == 2 || symtype == 4; }
+  bool d_translated() const { return symtype == 3 || symtype == 4; }
+};
+
 // tail of count_align / whole_align (hits.cc:1111-1174): 1-based display coordinates on the original strands
-void display_positions(Shown& h, bool nucleotide)
+void display_positions(Shown& h, const Mode& m)
 {
   h.q_first = long(h.a.q_start); h.q_last = long(h.a.q_end);
   h.d_first = long(h.a.d_start); h.d_last = long(h.a.d_end);
-  if (nucleotide && h.a.dstrand) {
+  if (m.symtype == 0 && h.a.dstrand) {
     h.d_first = long(h.a.dlen) - 1 - h.d_first;
     h.d_last = long(h.a.dlen) - 1 - h.d_last;
+  }
+  if (m.q_translated()) {
+    if (h.qstrand) {
+      h.q_first = m.q_len_nt - 1 - 3 * h.q_first - h.qframe;
+      h.q_last = m.q_len_nt - 1 - 3 * h.q_last - h.qframe - 2;
+    } else {
+      h.q_first = 3 * h.q_first + h.qframe;
+      h.q_last = 3 * h.q_last + h.qframe + 2;
+    }
+  }
+  if (m.d_translated()) {
+    if (h.a.dstrand) {
+      h.d_first = long(h.a.dlennt) - 1 - 3 * h.d_first - h.a.dframe;
+      h.d_last = long(h.a.dlennt) - 1 - 3 * h.d_last - h.a.dframe - 2;
+    } else {
+      h.d_first = 3 * h.d_first + h.a.dframe;
+      h.d_last = 3 * h.d_last + h.a.dframe + 2;
+    }
   }
   ++h.q_first; ++h.q_last; ++h.d_first; ++h.d_last;
   long maxpos = std::max(std::max(h.q_first, h.q_last), std::max(h.d_first, h.d_last));
@@ -154,16 +182,26 @@ template <typename F> void for_each_op(const std::string& script, F&& f)
 }
 
 // show_align + putalignop (hits.cc:647-813): 60-column blocks of Query / match line / Sbjct
-void show_pairwise(FILE* out, const Shown& h, const std::vector<uint8_t>& q, const int64_t* M, bool nucleotide, const char* sym)
+void show_pairwise(FILE* out, const Shown& h, const Mode& m, const int64_t* M, const char* sym)
 {
+  const std::vector<uint8_t>& q = *h.qseq;
+  const bool nucleotide = m.symtype == 0;
   const int width = 60;
   char ql[width + 1], al[width + 1], dl[width + 1];
   long qpos = long(h.a.q_start), dpos = long(h.a.d_start), qs0 = 0, ds0 = 0;
   int fill = 0;
   auto flush = [&]() {
     ql[fill] = al[fill] = dl[fill] = 0;
-    long q1 = qs0 + 1, q2 = qpos, d1 = ds0 + 1, d2 = dpos;
+    long q1 = qs0 + 1, q2 = qpos, d1 = ds0 + 1, d2 = dpos;                       // hits.cc:706-747
     if (nucleotide && h.a.dstrand) { d1 = long(h.a.dlen) - d1 + 1; d2 = long(h.a.dlen) - d2 + 1; }
+    if (m.q_translated()) {
+      if (h.qstrand) { q1 = m.q_len_nt - 3 * qs0 - h.qframe; q2 = m.q_len_nt - 3 * qpos - h.qframe + 1; }
+      else { q1 = 3 * qs0 + h.qframe + 1; q2 = 3 * qpos + h.qframe; }
+    }
+    if (m.d_translated()) {
+      if (h.a.dstrand) { d1 = long(h.a.dlennt) - 3 * ds0 - h.a.dframe; d2 = long(h.a.dlennt) - 3 * dpos - h.a.dframe + 1; }
+      else { d1 = 3 * ds0 + h.a.dframe + 1; d2 = 3 * dpos + h.a.dframe; }
+    }
     std::fprintf(out, "\n");
     std::fprintf(out, "Query: %*ld %s %ld\n", h.poswidth, q1, ql, q2);
     std::fprintf(out, "       %*s %s\n", h.poswidth, "", al);
@@ -190,9 +228,9 @@ void show_pairwise(FILE* out, const Shown& h, const std::vector<uint8_t>& q, con
 }
 
 // the three full-length lines of whole_align (hits.cc:815-953)
-void whole_lines(const Shown& h, const std::vector<uint8_t>& q, const int64_t* M, const char* sym, std::string& ql,
-                 std::string& al, std::string& dl)
+void whole_lines(const Shown& h, const int64_t* M, const char* sym, std::string& ql, std::string& al, std::string& dl)
 {
+  const std::vector<uint8_t>& q = *h.qseq;
   long qpos = long(h.a.q_start), dpos = long(h.a.d_start);
   for_each_op(h.script, [&](char op, long n) {
     for (long k = 0; k < n; ++k) {
@@ -224,7 +262,9 @@ void usage(const char* prog)
   std::printf("  -u, --max_score=NUM        maximum score of sequences to show (inf.)\n");
   std::printf("  -a, --num_threads=NUM      accepted and ignored (one GPU)\n");
   std::printf("  -m, --outfmt=NUM           output format [0,7-9=plain,xml,tsv,tsv+] (0)\n");
-  std::printf("  -p, --symtype=NAME/NUM     symbol type [0-1, blastn, blastp] (1)\n");
+  std::printf("  -p, --symtype=NAME/NUM     symbol type/translation [0-4] (1)\n");
+  std::printf("  -Q, --query_gencode=NUM    query genetic code [1-23] (1)\n");
+  std::printf("  -D, --db_gencode=NUM       database genetic code [1-23] (1)\n");
   std::printf("  -S, --strand=NAME/NUM      query strands to search [1-3] (3)\n");
   std::printf("  -o, --out=FILE             output file (stdout)\n");
   std::printf("  -z, --dbsize=NUM           set effective database size (0)\n");
@@ -236,16 +276,17 @@ int main(int argc, char** argv)
 {
   std::string dbname, queryname = "-", matrixname, outfile;
   long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
-  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100;
+  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100, query_gencode = 1, db_gencode = 1;
   double expect = 10.0, minexpect = 0.0;
   static const option longopts[] = {
       {"db", 1, 0, 'd'}, {"query", 1, 0, 'i'}, {"matrix", 1, 0, 'M'}, {"penalty", 1, 0, 'q'}, {"reward", 1, 0, 'r'},
       {"gapopen", 1, 0, 'G'}, {"gapextend", 1, 0, 'E'}, {"num_descriptions", 1, 0, 'v'}, {"num_alignments", 1, 0, 'b'},
       {"evalue", 1, 0, 'e'}, {"minevalue", 1, 0, 'k'}, {"min_score", 1, 0, 'c'}, {"max_score", 1, 0, 'u'},
       {"num_threads", 1, 0, 'a'}, {"outfmt", 1, 0, 'm'}, {"symtype", 1, 0, 'p'}, {"strand", 1, 0, 'S'}, {"out", 1, 0, 'o'},
-      {"dbsize", 1, 0, 'z'}, {"gpu", 1, 0, 'g'}, {"help", 0, 0, 'h'}, {0, 0, 0, 0}};
+      {"dbsize", 1, 0, 'z'}, {"gpu", 1, 0, 'g'}, {"query_gencode", 1, 0, 'Q'}, {"db_gencode", 1, 0, 'D'}, {"help", 0, 0, 'h'},
+      {0, 0, 0, 0}};
   int c;
-  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:h", longopts, nullptr)) != -1) {
+  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:Q:D:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'd': dbname = optarg; break;
       case 'i': queryname = optarg; break;
@@ -265,21 +306,27 @@ int main(int argc, char** argv)
       case 'o': outfile = optarg; break;
       case 'z': effdbsize = std::atol(optarg); break;
       case 'g': device = std::atol(optarg); break;
+      case 'Q': query_gencode = std::atol(optarg); break;
+      case 'D': db_gencode = std::atol(optarg); break;
       case 'S':
         strands = !std::strcmp(optarg, "plus") ? 1 : !std::strcmp(optarg, "minus") ? 2 : !std::strcmp(optarg, "both") ? 3 : std::atol(optarg);
         break;
-      case 'p':
-        symtype = !std::strcmp(optarg, "blastn") ? 0 : !std::strcmp(optarg, "blastp") ? 1 : std::atol(optarg);
+      case 'p': {                                                      // swipe.cc:1010-1030
+        static const char* const names[] = {"blastn", "blastp", "blastx", "tblastn", "tblastx"};
+        symtype = std::atol(optarg);
+        for (int i = 0; i < 5; ++i) if (!std::strcmp(optarg, names[i])) symtype = i;
         break;
+      }
       default: usage(argv[0]); std::exit(1);
     }
   }
   FILE* out = stdout;
   if (!outfile.empty() && !(out = std::fopen(outfile.c_str(), "w"))) fatal("Unable to open output file for writing.");
   // argument rules of args_init (swipe.cc:1088-1161)
-  if (symtype != 0 && symtype != 1) fatal("Illegal symbol type.");   // translated searches: out of scope
-  const bool protein = symtype == 1;
-  if (!protein) {
+  if (symtype < 0 || symtype > 4) fatal("Illegal symbol type.");
+  const bool query_nt = symtype == 0 || symtype == 2 || symtype == 4;
+  const bool db_nt = symtype == 0 || symtype == 3 || symtype == 4;
+  if (symtype == 0) {
     if (gapopen == 0) gapopen = 5;
     if (gapextend == 0) gapextend = 2;
   } else {
@@ -298,10 +345,12 @@ int main(int argc, char** argv)
   if (alignments < 0) fatal("Illegal number of alignments specified.");
   if (gapopen < 0 || gapextend < 0 || gapopen + gapextend < 1) fatal("Illegal gap penalties.");
   if (strands < 1 || strands > 3) fatal("Illegal query strands specified.");
-  if (strands == 2 && protein) fatal("Illegal strand specified for protein query.");
+  if (strands == 2 && (symtype == 1 || symtype == 3 || symtype == 4)) fatal("Illegal strand specified for protein query.");
+  if (!swa_gencode_name(int(query_gencode))) fatal("Illegal query genetic code specified.");
+  if (!swa_gencode_name(int(db_gencode))) fatal("Illegal database genetic code specified.");
 
   int64_t M[1024];
-  if (!protein) check(swa_matrix_nucleotide(match, mismatch, M));
+  if (symtype == 0) check(swa_matrix_nucleotide(match, mismatch, M));
   else if (swa_matrix_builtin(matrixname.c_str(), M) != SWA_OK) {
     FILE* mf = std::fopen(matrixname.c_str(), "r");
     if (!mf) fatal("Cannot open score matrix file.");
@@ -312,12 +361,16 @@ int main(int argc, char** argv)
     std::fclose(mf);
     check(swa_matrix_parse(text.c_str(), M));
   }
+  std::vector<uint8_t> qtable(4096);
+  check(swa_translate_table(int(query_gencode), qtable.data()));
 
   swa_db* db = nullptr;
-  check(swa_db_open(dbname.c_str(), int(symtype), int(device), 0, -1, &db));
+  if (symtype >= 3) check(swa_db_open_translated(dbname.c_str(), int(db_gencode), int(device), 0, -1, &db));
+  else check(swa_db_open(dbname.c_str(), db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN, int(device), 0, -1, &db));
   swa_db_info_t info;
   check(swa_db_info(db, &info));
   check(swa_set_scoring(db, M, gapopen + gapextend, gapextend));
+  const int db_filetype = db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN;
 
   FILE* qf = queryname == "-" ? stdin : std::fopen(queryname.c_str(), "r");
   if (!qf) fatal("Cannot open query file.");
@@ -328,80 +381,120 @@ int main(int argc, char** argv)
 
   std::string pending;
   Query q;
-  while (read_query(qf, pending, protein, q)) {
+  while (read_query(qf, pending, !query_nt, q)) {
     const int64_t qlen = int64_t(q.seq.size());
+    const Mode mode{symtype, long(qlen)};
+    // the query frames search_chunk loops over (swipe.cc:277-337, 1403-1404), tag = 3 * qstrand + qframe
+    std::vector<std::vector<uint8_t>> frames;
+    std::vector<int32_t> tags;
+    if (symtype == 0) {
+      static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // query.cc:112
+      if (strands & 1) { frames.push_back(q.seq); tags.push_back(0); }
+      if (strands & 2) {
+        std::vector<uint8_t> rc(q.seq.size());
+        for (size_t i = 0; i < q.seq.size(); ++i) rc[i] = compl4[q.seq[q.seq.size() - 1 - i]];
+        frames.push_back(rc);
+        tags.push_back(3);
+      }
+    } else if (symtype == 2 || symtype == 4) {
+      for (int s = 0; s < 2; ++s)
+        if ((s + 1) & strands)
+          for (int f = 0; f < 3; ++f) {
+            std::vector<uint8_t> prot(size_t(qlen / 3 + 1));
+            int64_t plen = 0;
+            check(swa_translate(q.seq.data(), qlen, s, f, qtable.data(), prot.data(), &plen));
+            prot.resize(size_t(plen));
+            frames.push_back(prot);
+            tags.push_back(3 * s + f);
+          }
+    } else {
+      frames.push_back(q.seq);
+      tags.push_back(0);
+    }
     int64_t keep = std::max(maxmatches, alignments);                   // hits.cc:287-315
-    int64_t maxhits = info.seqcount * ((!protein && strands == 3) ? 2 : 1);
-    if (keep > maxhits) keep = maxhits;
+    const int64_t per_seq = symtype == 0 ? (strands == 3 ? 2 : 1) : symtype == 2 ? (strands == 3 ? 6 : 3)
+                            : symtype == 3 ? 6 : symtype == 4 ? (strands == 3 ? 36 : 18) : 1;
+    keep = std::min(keep, info.seqcount * per_seq);
     swa_stats_t st;
     check(swa_stats_init(int(symtype), matrixname.c_str(), match, mismatch, gapopen, gapextend, qlen,
                          info.total_seqcount, info.total_symcount, effdbsize, minscore, maxscore, minexpect, expect, &st));
-    std::vector<swa_hit_t> hits(size_t(keep > 0 ? keep : 1));
-    std::vector<int32_t> which(size_t(keep > 0 ? keep : 1), 0);
+    std::vector<swa_fhit_t> hits(size_t(keep > 0 ? keep : 1));
     int64_t nhits = 0, total = 0, obvious = 0;
     swa_counters_t cnt;
-    std::vector<uint8_t> rc;
-    if (!protein) {
-      static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // query.cc:112
-      rc.resize(q.seq.size());
-      for (size_t i = 0; i < q.seq.size(); ++i) rc[i] = compl4[q.seq[q.seq.size() - 1 - i]];
+    {
+      std::vector<const uint8_t*> ptr;
+      std::vector<int64_t> len;
+      for (const auto& f : frames) { ptr.push_back(f.data()); len.push_back(int64_t(f.size())); }
+      check(swa_search_frames_topk(db, int(frames.size()), ptr.data(), len.data(), tags.data(), keep, st.scorethreshold,
+                                   st.upperscorethreshold, hits.data(), &nhits, &total, &obvious, &cnt));
     }
-    if (protein || strands == 1) {
-      check(swa_search_topk(db, q.seq.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(), &nhits, &total, &obvious, &cnt));
-    } else if (strands == 2) {
-      check(swa_search_topk(db, rc.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(), &nhits, &total, &obvious, &cnt));
-      std::fill(which.begin(), which.end(), 1);
-    } else {
-      check(swa_search2_topk(db, q.seq.data(), rc.data(), qlen, keep, st.scorethreshold, st.upperscorethreshold, hits.data(),
-                             which.data(), &nhits, &total, &obvious, &cnt));
-    }
+    // the reverse-complemented nucleotide query enters its hits as (qstrand 0, dstrand 1), swipe.cc:1470-1471
+    if (symtype == 0)
+      for (int64_t i = 0; i < nhits; ++i)
+        if (hits[size_t(i)].qstrand) { hits[size_t(i)].qstrand = 0; hits[size_t(i)].dstrand = 1; }
+
     const int64_t showhits = std::min<int64_t>(nhits, maxmatches);       // hits_show, hits.cc:1996-2004
     const int64_t showalignments = std::min<int64_t>(nhits, alignments);
-    std::vector<int64_t> seqnos;
-    std::vector<int32_t> dstrands;
-    for (int64_t i = 0; i < nhits; ++i) {
-      seqnos.push_back(hits[size_t(i)].seqno);
-      dstrands.push_back(protein ? 0 : which[size_t(i)]);
-    }
     std::vector<std::string> deflines;
-    for (int64_t s : seqnos) {
+    for (int64_t i = 0; i < nhits; ++i) {
       std::vector<char> buf(4096);
       int64_t need = 0;
-      int rc = swa_blastdb_deflines(dbname.c_str(), int(symtype), s, buf.data(), int64_t(buf.size()), &need);
+      int rc = swa_blastdb_deflines(dbname.c_str(), db_filetype, hits[size_t(i)].seqno, buf.data(), int64_t(buf.size()), &need);
       if (rc == SWA_ERANGE) {
         buf.resize(size_t(need));
-        rc = swa_blastdb_deflines(dbname.c_str(), int(symtype), s, buf.data(), int64_t(buf.size()), &need);
+        rc = swa_blastdb_deflines(dbname.c_str(), db_filetype, hits[size_t(i)].seqno, buf.data(), int64_t(buf.size()), &need);
       }
       check(rc);
       deflines.push_back(buf.data());
     }
 
-    // alignment phase (align_threads, swipe.cc:628-647): always against the PLUS query; minus-strand
-    // hits take the reverse-complemented database sequence (swipe.cc:359-362, hits.cc:564-577)
+    // alignment phase (align_chunk, swipe.cc:339-414): hits grouped by query frame; nucleotide searches always
+    // align the PLUS query, minus-strand hits against the reverse-complemented database sequence
     std::vector<Shown> shown{size_t(showalignments)};
-    if (showalignments > 0) {
-      std::vector<swa_alignment_t> al{size_t(showalignments)};
+    for (size_t fi = 0; fi < frames.size() && showalignments > 0; ++fi) {
+      const int tag = symtype == 0 ? 0 : tags[fi];
+      if (symtype == 0 && fi > 0) break;
+      const std::vector<uint8_t>& qseq = symtype == 0 ? q.seq : frames[fi];
+      std::vector<int64_t> which, seqnos;
+      std::vector<int32_t> ds, df;
+      for (int64_t i = 0; i < showalignments; ++i) {
+        const swa_fhit_t& h = hits[size_t(i)];
+        if (3 * h.qstrand + h.qframe != tag) continue;
+        which.push_back(i); seqnos.push_back(h.seqno); ds.push_back(h.dstrand); df.push_back(h.dframe);
+      }
+      if (which.empty()) continue;
+      const int64_t n = int64_t(which.size());
+      std::vector<swa_alignment_t> al{size_t(n)};
       std::vector<char> text(1 << 16);
       int64_t used = 0;
-      int rc = swa_align_hits(db, q.seq.data(), qlen, seqnos.data(), dstrands.data(), showalignments, al.data(), text.data(),
-                              int64_t(text.size()), &used);
+      int rc = swa_align_hits(db, qseq.data(), int64_t(qseq.size()), seqnos.data(), ds.data(), df.data(), n, al.data(),
+                              text.data(), int64_t(text.size()), &used);
       if (rc == SWA_ERANGE) {
         text.resize(size_t(used));
-        rc = swa_align_hits(db, q.seq.data(), qlen, seqnos.data(), dstrands.data(), showalignments, al.data(), text.data(),
-                            int64_t(text.size()), &used);
+        rc = swa_align_hits(db, qseq.data(), int64_t(qseq.size()), seqnos.data(), ds.data(), df.data(), n, al.data(),
+                            text.data(), int64_t(text.size()), &used);
       }
       check(rc);
-      for (int64_t i = 0; i < showalignments; ++i) {
-        Shown& h = shown[size_t(i)];
-        h.a = al[size_t(i)];
+      for (int64_t k = 0; k < n; ++k) {
+        Shown& h = shown[size_t(which[size_t(k)])];
+        h.a = al[size_t(k)];
+        h.qstrand = tag / 3;
+        h.qframe = tag % 3;
+        h.qseq = &qseq;
         h.script.assign(text.data() + h.a.cigar_offset, size_t(h.a.cigar_len));
         h.dseq.resize(size_t(h.a.dlen > 0 ? h.a.dlen : 1));
         int64_t got = 0;
-        check(swa_db_sequence(db, h.a.seqno, h.a.dstrand, h.dseq.data(), h.a.dlen, &got));
-        display_positions(h, !protein);
+        check(swa_db_sequence(db, h.a.seqno, h.a.dstrand, h.a.dframe, h.dseq.data(), h.a.dlen, &got, nullptr));
+        display_positions(h, mode);
       }
     }
-    const char* sym = protein ? "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ####" : "-acmgrsvtwyhkdbn################";   // query.cc:176-178
+    const char* sym = symtype != 0 ? "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ####" : "-acmgrsvtwyhkdbn################";   // query.cc:176-178
+    auto frame_label = [&](FILE* o, const swa_fhit_t& h, bool sep) {          // hits.cc:1829-1842 / 1913-1924
+      if (symtype == 2) std::fprintf(o, "%c%d", h.qstrand ? '-' : '+', h.qframe + 1);
+      else if (symtype == 3) std::fprintf(o, "%c%d", h.dstrand ? '-' : '+', h.dframe + 1);
+      else if (symtype == 4)
+        std::fprintf(o, sep ? "%c%d / %c%d" : "%c%d/%c%d", h.qstrand ? '-' : '+', h.qframe + 1, h.dstrand ? '-' : '+', h.dframe + 1);
+    };
 
     std::string qid = q.description.substr(0, q.description.find(' '));
     if (view == 7) {                                                  // hits_show_xml, hits.cc:1660-1727
@@ -416,7 +509,7 @@ int main(int argc, char** argv)
         if (i < showalignments) {
           const Shown& h = shown[size_t(i)];
           std::string ql, al, dl;
-          whole_lines(h, q.seq, M, sym, ql, al, dl);
+          whole_lines(h, M, sym, ql, al, dl);
           std::fprintf(out, "      <alignment>%s</alignment>\n", h.script.c_str());
           std::fprintf(out, "      <qpos>%ld,%ld</qpos>\n      <dpos>%ld,%ld</dpos>\n", h.q_first, h.q_last, h.d_first, h.d_last);
           std::fprintf(out, "      <qseq>%s</qseq>\n      <aseq>%s</aseq>\n      <dseq>%s</dseq>\n", ql.c_str(), al.c_str(), dl.c_str());
@@ -447,21 +540,24 @@ int main(int argc, char** argv)
         std::fprintf(out, "\n");
       }
     } else {                                                          // args_show + hits_show_plain
+      static const char* const symnames[] = {"Nucleotide", "Amino acid", "Translated query", "Translated database", "Both translated"};
       std::fprintf(out, "Database file:     %s\n", dbname.c_str());
       std::fprintf(out, "Database size:     %ld residues in %ld sequences\n", long(info.total_symcount), long(info.total_seqcount));
       std::fprintf(out, "Longest db seq:    %ld residues\n", long(info.longest));
       std::fprintf(out, "Query file name:   %s\n", queryname.c_str());
       std::fprintf(out, "Query length:      %ld residues\n", long(qlen));
       std::fprintf(out, "Query description: %s\n", q.description.c_str());
-      if (protein) std::fprintf(out, "Score matrix:      %s\n", matrixname.c_str());
+      if (symtype != 0) std::fprintf(out, "Score matrix:      %s\n", matrixname.c_str());
       else std::fprintf(out, "Score matrix:      %ld/%ld\n", match, mismatch);
       std::fprintf(out, "Gap penalty:       %ld+%ldk\n", gapopen, gapextend);
       std::fprintf(out, "Max expect shown:  %-g\n", expect);
       std::fprintf(out, "Min score shown:   %ld\n", minscore);
       std::fprintf(out, "Max matches shown: %ld\n", maxmatches);
       std::fprintf(out, "Alignments shown:  %ld\n", alignments);
-      std::fprintf(out, "Symbol type:       %s\n\n", protein ? "Amino acid" : "Nucleotide");
-      std::fprintf(out, "Elapsed:           %.4fs (device)\n", cnt.total_ms * 1e-3);
+      std::fprintf(out, "Symbol type:       %s\n", symnames[symtype]);
+      if (symtype == 2 || symtype == 4) std::fprintf(out, "Query genetic code:%s (%ld)\n", swa_gencode_name(int(query_gencode)), query_gencode);
+      if (symtype == 3 || symtype == 4) std::fprintf(out, "DB genetic code:   %s (%ld)\n", swa_gencode_name(int(db_gencode)), db_gencode);
+      std::fprintf(out, "\nElapsed:           %.4fs (device)\n", cnt.total_ms * 1e-3);
       std::fprintf(out, "Speed:             %.3f GCUPS\n\n", cnt.total_ms > 0 ? double(cnt.cells) / (cnt.total_ms * 1e-3) / 1e9 : 0.0);
       if (nhits == 0) {
         std::fprintf(out, "\nNo hits.\n");
@@ -472,11 +568,13 @@ int main(int argc, char** argv)
         } else {
           std::fprintf(out, "Sequences producing significant alignments:                         Score\n\n");
         }
-        const long width = protein ? 67 : 65;                         // hits.cc:1814-1820
+        const long width = symtype == 0 ? 65 : (symtype == 2 || symtype == 3) ? 64 : symtype == 4 ? 61 : 67;   // hits.cc:1814-1820
         for (int64_t i = 0; i < showhits; ++i) {
           show_deflines(out, deflines[size_t(i)], 0, size_t(width), width, 1, true);
-          const long score = long(hits[size_t(i)].score);
-          if (!protein) std::fprintf(out, " %c", which[size_t(i)] ? '-' : '+');
+          const swa_fhit_t& h = hits[size_t(i)];
+          const long score = long(h.score);
+          if (symtype == 0) std::fprintf(out, " %c", h.dstrand ? '-' : '+');
+          else if (symtype >= 2) { std::fputc(' ', out); frame_label(out, h, false); }
           if (st.available) {
             const long bits = long(std::floor(st.lambda_d_log2 * score - st.logK_d_log2 + 0.5));   // hits.cc:1846
             std::fprintf(out, " %5ld", bits);
@@ -491,7 +589,7 @@ int main(int argc, char** argv)
           const Shown& h = shown[size_t(i)];
           std::fprintf(out, "\n");
           show_deflines(out, deflines[size_t(i)], 10, 0, 79, LONG_MAX, true);
-          std::fprintf(out, "          Length = %ld\n\n", long(h.a.dlen));
+          std::fprintf(out, "          Length = %ld\n\n", long(symtype >= 3 ? h.a.dlennt : h.a.dlen));
           const long score = long(hits[size_t(i)].score);
           if (st.available) {
             std::fprintf(out, " Score = %.1lf bits (%ld), Expect = ", swa_bits(&st, score), score);
@@ -501,13 +599,14 @@ int main(int argc, char** argv)
           }
           std::fputc('\n', out);
           std::fprintf(out, " Identities = %ld/%ld (%ld%%)", long(h.a.identities), long(h.a.aligned), long(h.a.identities * 100 / h.a.aligned));
-          if (protein)
+          if (symtype > 0)
             std::fprintf(out, ", Positives = %ld/%ld (%ld%%)", long(h.a.positives), long(h.a.aligned), long(h.a.positives * 100 / h.a.aligned));
           if (h.a.indels)
             std::fprintf(out, ", Gaps = %ld/%ld (%ld%%)", long(h.a.indels), long(h.a.aligned), long(h.a.indels * 100 / h.a.aligned));
           std::fprintf(out, "\n");
-          if (!protein) std::fprintf(out, " Strand = %s\n", h.a.dstrand ? "Plus / Minus" : "Plus / Plus");
-          show_pairwise(out, h, q.seq, M, !protein, sym);
+          if (symtype == 0) std::fprintf(out, " Strand = %s\n", h.a.dstrand ? "Plus / Minus" : "Plus / Plus");
+          else if (symtype >= 2) { std::fprintf(out, " Frame = "); frame_label(out, hits[size_t(i)], true); std::fputc('\n', out); }
+          show_pairwise(out, h, mode, M, sym);
           std::fprintf(out, "\n");
         }
       }

@@ -184,10 +184,15 @@ extern "C" int swa_stats_init(int symtype, const char* matrixname, int64_t match
   std::memset(out, 0, sizeof *out);
   out->scorethreshold = minscore;                                                         // hits.cc:486-487
   out->upperscorethreshold = maxscore;
+  if (symtype < 0 || symtype > 4) return swa::fail(SWA_EINVAL, "swa_stats_init: symtype must be 0..4");
   ka_params ka{};
-  const bool ok = symtype == SWA_SYMTYPE_NUCLEOTIDE
-                      ? lookup_nucleotide(match, mismatch, gapopen, gapextend, ka)
-                      : (matrixname && lookup_protein(matrixname, gapopen, gapextend, ka));
+  // translated against translated (-p 4) uses the matrix's ungapped row (hits.cc:401-410)
+  const bool ok = symtype == SWA_SYMTYPE_NUCLEOTIDE ? lookup_nucleotide(match, mismatch, gapopen, gapextend, ka)
+                  : symtype == SWA_SYMTYPE_TRANSLATED_BOTH ? (matrixname && lookup_protein(matrixname, 32767, 32767, ka))
+                                                           : (matrixname && lookup_protein(matrixname, gapopen, gapextend, ka));
+  // lengths in codons where the query / database is nucleotide (hits.cc:436-449)
+  if (symtype == SWA_SYMTYPE_TRANSLATED_QUERY || symtype == SWA_SYMTYPE_TRANSLATED_BOTH) qlen /= 3;
+  if ((symtype == SWA_SYMTYPE_TRANSLATED_DB || symtype == SWA_SYMTYPE_TRANSLATED_BOTH) && effdbsize <= 0) db_symcount /= 3;
   out->available = ok ? 1 : 0;
   if (!ok) return SWA_OK;
   out->lambda = ka.lambda; out->K = ka.K; out->H = ka.H; out->alpha = ka.alpha; out->beta = ka.beta;
@@ -218,4 +223,65 @@ extern "C" double swa_evalue(const swa_stats_t* st, int64_t score)
 extern "C" double swa_bits(const swa_stats_t* st, int64_t score)
 {
   return st->lambda_d_log2 * score - st->logK_d_log2;                                     // hits.cc:1779
+}
+
+// ---- translated searches: genetic codes (query.cc:118-170) and six-frame translation --------------
+extern "C" const char* swa_gencode_name(int gencode)
+{
+  if (gencode < 1 || gencode > 23 || !refdata_gencode[gencode - 1][0]) return nullptr;
+  return refdata_gencode_names[gencode - 1];
+}
+
+extern "C" int swa_translate_table(int gencode, uint8_t* table)
+{
+  if (!table) return swa::fail(SWA_EINVAL, "swa_translate_table: null output");
+  if (!swa_gencode_name(gencode)) return swa::fail(SWA_EINVAL, "Illegal genetic code specified.");
+  const char* code = refdata_gencode[gencode - 1];           // 64 letters, codon positions in T,C,A,G order
+  static const char stdaa[] = "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ";
+  // the set of amino acids each of the 4096 nibble triples can stand for, then translate_createtable's
+  // merging rule (query.cc:377-455): one letter -> itself, {D,N,B} -> B, {E,Q,Z} -> Z, anything else -> X
+  for (int t = 0; t < 4096; ++t) {
+    const int n[3] = {t >> 8, (t >> 4) & 15, t & 15};
+    unsigned seen = 0;                                       // bit per stdaa code
+    static const int tcag[4] = {2, 1, 3, 0};                 // nibble bit (A,C,G,T) -> index in T,C,A,G
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < 4; ++k)
+          if (((n[0] >> i) & 1) && ((n[1] >> j) & 1) && ((n[2] >> k) & 1)) {
+            const char* p = std::strchr(stdaa, code[16 * tcag[i] + 4 * tcag[j] + tcag[k]]);
+            seen |= 1u << (p ? int(p - stdaa) : 21);
+          }
+    auto bit = [](char c) { return 1u << int(std::strchr(stdaa, c) - stdaa); };
+    int out;
+    if (seen == 0) out = 21;                                  // X
+    else if ((seen & (seen - 1)) == 0) out = __builtin_ctz(seen);
+    else if ((seen & ~(bit('D') | bit('N') | bit('B'))) == 0) out = 2;    // B
+    else if ((seen & ~(bit('E') | bit('Q') | bit('Z'))) == 0) out = 23;   // Z
+    else out = 21;
+    table[t] = uint8_t(out);
+  }
+  return SWA_OK;
+}
+
+extern "C" int swa_translate(const uint8_t* dna, int64_t dlen, int strand, int frame, const uint8_t* table,
+                             uint8_t* prot, int64_t* plen)
+{
+  if (!table || !plen || dlen < 0 || (dlen > 0 && !dna) || frame < 0 || frame > 2 || strand < 0 || strand > 1)
+    return swa::fail(SWA_EINVAL, "swa_translate: bad argument");
+  const int64_t n = dlen - frame > 0 ? (dlen - frame) / 3 : 0;
+  *plen = n;
+  if (n > 0 && !prot) return swa::fail(SWA_EINVAL, "swa_translate: null output");
+  static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  for (int64_t k = 0; k < n; ++k) {
+    int a, b, c;
+    if (!strand) {
+      const uint8_t* p = dna + frame + 3 * k;
+      a = p[0] & 15; b = p[1] & 15; c = p[2] & 15;
+    } else {
+      const uint8_t* p = dna + dlen - 1 - frame - 3 * k;
+      a = compl4[p[0] & 15]; b = compl4[p[-1] & 15]; c = compl4[p[-2] & 15];
+    }
+    prot[k] = table[256 * a + 16 * b + c];
+  }
+  return SWA_OK;
 }

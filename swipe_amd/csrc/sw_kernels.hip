@@ -92,6 +92,43 @@ swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restric
   (void)unpack2bit;
 }
 
+// Six-frame translation of a nucleotide shard into the protein residues the DP kernels consume - the
+// pre-pass for translated-database searches (-p 3 / -p 4).  db_translate (database.cc:1182-1218): virtual
+// sequence v = 6*s + 3*strand + frame holds (len_s - frame) / 3 residues, table[256a + 16b + c] over the
+// three IUPAC nibbles of a codon, strand 1 reading the reverse complement.  One thread per output residue
+// (located by binary search in the virtual offsets, which stay L2 resident), so a chromosome-sized
+// sequence and a thousand short reads load the GPU alike; writes are coalesced, each nucleotide line is
+// read by six frames out of L2.  HBM-bound: 1 B read + 2 B written per base.
+extern "C" __global__ void __launch_bounds__(256)
+swa_translate_frames(const uint8_t* __restrict__ nt, const int64_t* __restrict__ ntoff,
+                     const int64_t* __restrict__ voff, int64_t nv, const uint8_t* __restrict__ table,
+                     uint8_t* __restrict__ prot, int64_t total)
+{
+  __shared__ uint8_t tab[4096];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) tab[i] = table[i];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += stride) {
+    int64_t lo = 0, hi = nv;                              // largest v with voff[v] <= r
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (voff[mid] <= r) lo = mid; else hi = mid;
+    }
+    const int64_t s = lo / 6, k = r - voff[lo];
+    const int t = (int)(lo - 6 * s), f = t % 3;
+    const int64_t o = ntoff[s], len = ntoff[s + 1] - o;
+    u32 a, b, c;
+    if (t < 3) {
+      const uint8_t* p = nt + o + f + 3 * k;
+      a = p[0] & 15; b = p[1] & 15; c = p[2] & 15;
+    } else {                                              // complement of a nibble = its 4 bits reversed
+      const uint8_t* p = nt + o + len - 1 - f - 3 * k;
+      a = __brev((u32)p[0]) >> 28; b = __brev((u32)p[-1]) >> 28; c = __brev((u32)p[-2]) >> 28;
+    }
+    prot[r] = tab[256 * a + 16 * b + c];
+  }
+}
+
 // ------------------------------------------------------------------ profile tables in LDS
 // f16 table, 16-byte unit index = (d*C + c)*16 + l, unit holds rows l*K + c*8 + 0..7
 template <int K>
@@ -481,6 +518,15 @@ extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* 
 {
   if (nbatches <= 0) return hipSuccess;
   hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
+                                           const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st)
+{
+  if (total <= 0) return hipSuccess;
+  const int64_t want = (total + 255) / 256;
+  const int blocks = (int)(want < 16384 ? want : 16384);
+  hipLaunchKernelGGL(swa_translate_frames, dim3(blocks), dim3(256), 0, st, nt, ntoff, voff, nv, table, prot, total);
   return hipGetLastError();
 }
 extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,

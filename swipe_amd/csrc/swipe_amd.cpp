@@ -29,6 +29,8 @@ int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
                                 const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                 long long* Hs, long long* Es, long long* out, hipStream_t st);
+hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
+                                const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
@@ -95,6 +97,12 @@ struct swa_db {
   int symtype = SWA_SYMTYPE_PROTEIN;
   int cus = 256;
   int64_t nseq = 0, nsym = 0, longest = 0, first_seqno = 0, total_seq = 0, total_sym = 0;
+  // a translated shard (frames == 6) holds 6 virtual protein sequences per nucleotide sequence, virtual
+  // index 6 * (seqno - first_seqno) + 3 * dstrand + dframe; nseq / nsym / h_offsets then describe the
+  // virtual sequences, nt_* the nucleotide sequences they came from
+  int frames = 1;
+  std::vector<int64_t> h_ntlen;
+  int64_t nt_sym = 0, nt_longest = 0;
   std::vector<int64_t> h_offsets;
   std::vector<int32_t> h_order;            // sequence indices by descending length
   hipStream_t stream = nullptr;
@@ -221,6 +229,7 @@ void order_by_length(const std::vector<int64_t>& off, const int32_t* ids, int64_
   }
 }
 
+// residues == nullptr: db->residues already holds them on the device (translated shards)
 int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t nseq)
 {
   if (nseq > 0x7ffffff0) return fail(SWA_EINVAL, "more than 2^31 sequences in one shard; shard the database");
@@ -236,14 +245,18 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
     db->longest = std::max(db->longest, len);
   }
   HIP_TRY(hipSetDevice(db->device));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, db->device));
-  db->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIP_TRY(hipStreamCreate(&db->stream));
-  for (hipEvent_t& e : db->ev) HIP_TRY(hipEventCreate(&e));
-  HIP_TRY(db->residues.reserve(size_t(db->nsym) + 16));
+  if (!db->stream) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, db->device));
+    db->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreate(&db->stream));
+    for (hipEvent_t& e : db->ev) HIP_TRY(hipEventCreate(&e));
+  }
   HIP_TRY(db->offsets.reserve(size_t(nseq) + 1));
-  if (db->nsym) HIP_TRY(hipMemcpyAsync(db->residues.p, residues + base, size_t(db->nsym), hipMemcpyHostToDevice, db->stream));
+  if (residues) {
+    HIP_TRY(db->residues.reserve(size_t(db->nsym) + 16));
+    if (db->nsym) HIP_TRY(hipMemcpyAsync(db->residues.p, residues + base, size_t(db->nsym), hipMemcpyHostToDevice, db->stream));
+  }
   HIP_TRY(hipMemcpyAsync(db->offsets.p, db->h_offsets.data(), (size_t(nseq) + 1) * sizeof(int64_t), hipMemcpyHostToDevice, db->stream));
   HIP_TRY(db->scores.reserve(size_t(nseq)));
   HIP_TRY(db->ovf_list.reserve(size_t(nseq)));
@@ -654,6 +667,90 @@ extern "C" int swa_db_open(const char* basename, int symtype, int device, int64_
                             h.first_seqno, h.total_seqcount, h.total_symcount, out);
 }
 
+extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
+                                             int db_gencode, int device, int64_t first_seqno,
+                                             int64_t total_seqcount, int64_t total_symcount, swa_db** out)
+{
+  if (!out) return fail(SWA_EINVAL, "null output handle");
+  *out = nullptr;
+  if (nseq < 0 || !offsets || (!nt_residues && nseq > 0 && offsets[nseq] > offsets[0]))
+    return fail(SWA_EINVAL, "bad database arrays");
+  if (nseq > 0x7ffffff0 / 6) return fail(SWA_EINVAL, "too many sequences for one translated shard; shard the database");
+  uint8_t table[4096];
+  int rc = swa_translate_table(db_gencode, table);
+  if (rc != SWA_OK) return fail(SWA_EINVAL, "Illegal database genetic code specified.");
+  if (device < 0 || device >= swa_device_count())
+    return fail(SWA_ENODEV, "no such HIP device (swipe_amd has no CPU fallback)");
+  swa_db* db = new (std::nothrow) swa_db;
+  if (!db) return fail(SWA_ENOMEM, "out of host memory");
+  struct Guard { swa_db* d; ~Guard() { delete d; } } guard{db};
+  db->device = device;
+  db->symtype = SWA_SYMTYPE_PROTEIN;
+  db->frames = 6;
+  if (const char* v = std::getenv("SWA_NARROW_VARIANT")) db->narrow_variant = std::atoi(v);
+  db->first_seqno = first_seqno;
+  // virtual offsets: frame f of either strand holds (len - f) / 3 residues (database.cc:1188)
+  const int64_t base = offsets[0];
+  std::vector<int64_t> ntoff(size_t(nseq) + 1), voff(size_t(6 * nseq) + 1);
+  db->h_ntlen.resize(size_t(nseq));
+  voff[0] = 0;
+  for (int64_t s = 0; s < nseq; ++s) {
+    const int64_t len = offsets[s + 1] - offsets[s];
+    if (len < 0) return fail(SWA_EINVAL, "sequence offsets must be non-decreasing");
+    ntoff[size_t(s)] = offsets[s] - base;
+    db->h_ntlen[size_t(s)] = len;
+    db->nt_longest = std::max(db->nt_longest, len);
+    for (int t = 0; t < 6; ++t) {
+      const int64_t plen = len - t % 3 > 0 ? (len - t % 3) / 3 : 0;
+      voff[size_t(6 * s + t) + 1] = voff[size_t(6 * s + t)] + plen;
+    }
+  }
+  ntoff[size_t(nseq)] = offsets[nseq] - base;
+  db->nt_sym = ntoff[size_t(nseq)];
+  const int64_t total = voff[size_t(6 * nseq)];
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  db->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipStreamCreate(&db->stream));
+  for (hipEvent_t& e : db->ev) HIP_TRY(hipEventCreate(&e));
+  {
+    // the nucleotide form lives on the device only for the duration of the translation pre-pass
+    DevBuf<uint8_t> d_nt, d_table;
+    DevBuf<int64_t> d_ntoff, d_voff;
+    HIP_TRY(d_nt.reserve(size_t(db->nt_sym) + 16));
+    HIP_TRY(d_table.reserve(4096));
+    HIP_TRY(d_ntoff.reserve(ntoff.size()));
+    HIP_TRY(d_voff.reserve(voff.size()));
+    HIP_TRY(db->residues.reserve(size_t(total) + 16));
+    if (db->nt_sym) HIP_TRY(hipMemcpyAsync(d_nt.p, nt_residues + base, size_t(db->nt_sym), hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(hipMemcpyAsync(d_table.p, table, 4096, hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(hipMemcpyAsync(d_ntoff.p, ntoff.data(), ntoff.size() * sizeof(int64_t), hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(hipMemcpyAsync(d_voff.p, voff.data(), voff.size() * sizeof(int64_t), hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(swa_launch_translate(d_nt.p, d_ntoff.p, d_voff.p, 6 * nseq, d_table.p, db->residues.p, total, db->stream));
+    HIP_TRY(hipStreamSynchronize(db->stream));
+  }
+  rc = ingest(db, nullptr, voff.data(), 6 * nseq);
+  if (rc != SWA_OK) return rc;
+  db->total_seq = total_seqcount > 0 ? total_seqcount : nseq;
+  db->total_sym = total_symcount > 0 ? total_symcount : db->nt_sym;
+  guard.d = nullptr;
+  *out = db;
+  return SWA_OK;
+}
+
+extern "C" int swa_db_open_translated(const char* basename, int db_gencode, int device, int64_t first_seqno,
+                                      int64_t last_seqno, swa_db** out)
+{
+  if (!out) return fail(SWA_EINVAL, "null output handle");
+  *out = nullptr;
+  swa::HostDb h;
+  const int rc = swa::read_blast_db(basename, SWA_SYMTYPE_NUCLEOTIDE, first_seqno, last_seqno, h);
+  if (rc != SWA_OK) return rc;
+  return swa_db_from_memory_translated(h.residues.data(), h.offsets.data(), int64_t(h.offsets.size()) - 1, db_gencode,
+                                       device, h.first_seqno, h.total_seqcount, h.total_symcount, out);
+}
+
 extern "C" int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
                                 uint8_t** residues, int64_t** offsets, int64_t* nseq, int64_t* total_seqcount,
                                 int64_t* total_symcount, int64_t* longest)
@@ -704,9 +801,10 @@ extern "C" int swa_blastdb_deflines(const char* basename, int symtype, int64_t s
 extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
 {
   if (!db || !info) return fail(SWA_EINVAL, "null argument");
-  info->seqcount = db->nseq;
-  info->symcount = db->nsym;
-  info->longest = db->longest;
+  info->seqcount = db->nseq / db->frames;
+  info->symcount = db->frames == 1 ? db->nsym : db->nt_sym;
+  info->longest = db->frames == 1 ? db->longest : db->nt_longest;
+  info->frames = db->frames;
   info->first_seqno = db->first_seqno;
   info->total_seqcount = db->total_seq;
   info->total_symcount = db->total_sym;
@@ -747,7 +845,7 @@ extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapope
 extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters);
 
 namespace {
-struct Cand { int64_t seqno, score; int32_t which; };
+struct Cand { int64_t seqno, score; int32_t which, dtag; };
 
 // hits_enter acceptance test over one score array on the device; appends the survivors
 int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t keep, int64_t minscore,
@@ -775,7 +873,8 @@ int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t
       HIP_TRY(hipMemcpy(idx.data(), db->cand_idx.p, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(sc.data(), db->cand_score.p, sc.size() * sizeof(long long), hipMemcpyDeviceToHost));
     }
-    for (int i = 0; i < ncand; ++i) cand.push_back({db->first_seqno + idx[size_t(i)], sc[size_t(i)], which});
+    for (int i = 0; i < ncand; ++i)
+      cand.push_back({db->first_seqno + idx[size_t(i)] / db->frames, sc[size_t(i)], which, idx[size_t(i)] % db->frames});
     return SWA_OK;
   }
   // more candidates than the compaction buffer: take every score to the host instead
@@ -791,7 +890,7 @@ int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t
       }
       v = s64[size_t(i)];
     }
-    if (v >= minscore && v <= maxscore) cand.push_back({db->first_seqno + i, v, which});
+    if (v >= minscore && v <= maxscore) cand.push_back({db->first_seqno + i / db->frames, v, which, int32_t(i % db->frames)});
   }
   return SWA_OK;
 }
@@ -802,7 +901,8 @@ bool cand_before(const Cand& a, const Cand& b)
 {
   if (a.score != b.score) return a.score > b.score;
   if (a.seqno != b.seqno) return a.seqno > b.seqno;
-  return a.which < b.which;
+  if (a.which != b.which) return a.which < b.which;
+  return a.dtag < b.dtag;      // frames of one sequence are entered in start_list order (swipe.cc:1379-1384)
 }
 
 int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
@@ -837,6 +937,7 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
                                int64_t* obvious, swa_counters_t* counters)
 {
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
+  if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
   int rc = run_search(db, query, qlen, counters);
   if (rc != SWA_OK) return rc;
   *nhits = 0;
@@ -870,6 +971,7 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
                                 int64_t* totalhits, int64_t* obvious, swa_counters_t* counters)
 {
   if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
+  if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
   int rc = run_search2(db, query1, query2, qlen, counters);
   if (rc != SWA_OK) return rc;
   *nhits = 0;
@@ -889,22 +991,80 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
   return SWA_OK;
 }
 
+extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* queries, const int64_t* qlens,
+                                      const int32_t* qtags, int64_t keep, int64_t minscore, int64_t maxscore,
+                                      swa_fhit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
+                                      swa_counters_t* counters)
+{
+  if (!db) return fail(SWA_EINVAL, "null database handle");
+  if (nq < 1 || nq > 6 || !queries || !qlens) return fail(SWA_EINVAL, "between 1 and 6 query frames expected");
+  if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
+  *nhits = 0;
+  int64_t tot = 0, obv = 0;
+  std::vector<Cand> cand;
+  swa_counters_t sum{};
+  // one pass over the shard per query frame, in the order search_chunk loops them (swipe.cc:1403-1404);
+  // frames of equal length share a pass in the two halves of the packed lanes
+  for (int i = 0; i < nq;) {
+    swa_counters_t c{};
+    const bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
+    int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c) : run_search(db, queries[i], qlens[i], &c);
+    if (rc != SWA_OK) return rc;
+    if (db->nseq) {
+      rc = collect_candidates(db, db->scores.p, i, keep, minscore, maxscore, cand, &tot, &obv);
+      if (rc == SWA_OK && pair) rc = collect_candidates(db, db->scores2.p, i + 1, keep, minscore, maxscore, cand, &tot, &obv);
+      if (rc != SWA_OK) return rc;
+    }
+    sum.narrow += c.narrow; sum.wide += c.wide; sum.full += c.full; sum.cells += c.cells;
+    sum.kernel_ms += c.kernel_ms; sum.total_ms += c.total_ms;
+    sum.narrow_rows = c.narrow_rows; sum.narrow_shifted = c.narrow_shifted;
+    i += pair ? 2 : 1;
+  }
+  if (counters) *counters = sum;
+  if (totalhits) *totalhits = tot;
+  if (obvious) *obvious = obv;
+  const size_t k = std::min<size_t>(size_t(keep), cand.size());
+  std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), cand_before);
+  for (size_t i = 0; i < k; ++i) {
+    const int tag = qtags ? qtags[cand[i].which] : 0;
+    hits[i] = {cand[i].seqno, cand[i].score, tag / 3, tag % 3, cand[i].dtag / 3, cand[i].dtag % 3};
+  }
+  *nhits = int64_t(k);
+  return SWA_OK;
+}
+
 namespace {
-// search16s over the listed (sequence, strand) pairs: out = scores | bestpos | bestq, n entries each
+// index of (seqno, dstrand, dframe) among the sequences the shard holds; *minus = reverse-complement on the fly
+int locate(const swa_db* db, int64_t seqno, int dstrand, int dframe, int64_t* local, bool* minus)
+{
+  const int64_t real = seqno - db->first_seqno;
+  if (real < 0 || real >= db->nseq / db->frames) return fail(SWA_EINVAL, "sequence number outside this shard");
+  if (dstrand < 0 || dstrand > 1 || dframe < 0 || dframe > 2) return fail(SWA_EINVAL, "database strand / frame out of range");
+  *minus = false;
+  if (db->frames == 6) { *local = 6 * real + 3 * dstrand + dframe; return SWA_OK; }
+  if (dframe) return fail(SWA_EINVAL, "database frames need a translated shard");
+  if (dstrand) {
+    if (db->symtype != SWA_SYMTYPE_NUCLEOTIDE) return fail(SWA_EINVAL, "database strand 1 needs a nucleotide database");
+    *minus = true;
+  }
+  *local = real;
+  return SWA_OK;
+}
+
+// search16s over the listed (sequence, strand, frame) triples: out = scores | bestpos | bestq, n entries each
 int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, const int32_t* dstrands,
-                        int64_t n, std::vector<long long>& out)
+                        const int32_t* dframes, int64_t n, std::vector<long long>& out)
 {
   if (n > (1 << 20)) return fail(SWA_EINVAL, "too many sequences for the alignment phase");
   std::vector<int32_t> ids((size_t(n)));
   std::vector<uint8_t> minus((size_t(n)), 0);
   for (int64_t i = 0; i < n; ++i) {
-    const int64_t local = seqnos[i] - db->first_seqno;
-    if (local < 0 || local >= db->nseq) return fail(SWA_EINVAL, "sequence number outside this shard");
+    int64_t local = 0;
+    bool rc_flag = false;
+    const int rc = locate(db, seqnos[i], dstrands ? dstrands[i] : 0, dframes ? dframes[i] : 0, &local, &rc_flag);
+    if (rc != SWA_OK) return rc;
     ids[size_t(i)] = int32_t(local);
-    if (dstrands && dstrands[i]) {
-      if (db->symtype != SWA_SYMTYPE_NUCLEOTIDE) return fail(SWA_EINVAL, "database strand 1 needs a nucleotide database");
-      minus[size_t(i)] = 1;
-    }
+    minus[size_t(i)] = rc_flag ? 1 : 0;
   }
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
@@ -929,19 +1089,20 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
   return SWA_OK;
 }
 
-// db_getsequence (database.cc:1237-1401) for symtype 0/1 out of the resident shard
-int fetch_sequence(swa_db* db, int64_t seqno, int dstrand, std::vector<uint8_t>& seq)
+// db_getsequence (database.cc:1237-1401) out of the resident shard
+int fetch_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, std::vector<uint8_t>& seq)
 {
-  const int64_t local = seqno - db->first_seqno;
-  if (local < 0 || local >= db->nseq) return fail(SWA_EINVAL, "sequence number outside this shard");
-  if (dstrand && db->symtype != SWA_SYMTYPE_NUCLEOTIDE) return fail(SWA_EINVAL, "database strand 1 needs a nucleotide database");
+  int64_t local = 0;
+  bool minus = false;
+  const int rc = locate(db, seqno, dstrand, dframe, &local, &minus);
+  if (rc != SWA_OK) return rc;
   const int64_t o = db->h_offsets[size_t(local)], len = db->h_offsets[size_t(local) + 1] - o;
   seq.resize(size_t(len));
   if (len) {
     HIP_TRY(hipSetDevice(db->device));
     HIP_TRY(hipMemcpy(seq.data(), db->residues.p + o, size_t(len), hipMemcpyDeviceToHost));
   }
-  if (dstrand) {
+  if (minus) {
     static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // database.cc ntcompl
     std::reverse(seq.begin(), seq.end());
     for (uint8_t& c : seq) c = compl4[c & 15];
@@ -951,15 +1112,15 @@ int fetch_sequence(swa_db* db, int64_t seqno, int dstrand, std::vector<uint8_t>&
 }  // namespace
 
 extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
-                                           const int32_t* dstrands, int64_t n, int64_t* scores, int64_t* bestpos,
-                                           int64_t* bestq)
+                                           const int32_t* dstrands, const int32_t* dframes, int64_t n, int64_t* scores,
+                                           int64_t* bestpos, int64_t* bestq)
 {
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
   if (n < 0 || (n > 0 && (!seqnos || !scores || !bestpos || !bestq))) return fail(SWA_EINVAL, "bad argument");
   if (n == 0) return SWA_OK;
   std::vector<long long> out;
-  rc = endpoints_on_device(db, query, qlen, seqnos, dstrands, n, out);
+  rc = endpoints_on_device(db, query, qlen, seqnos, dstrands, dframes, n, out);
   if (rc != SWA_OK) return rc;
   for (int64_t i = 0; i < n; ++i) {
     scores[i] = out[size_t(i)];
@@ -972,15 +1133,17 @@ extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int
 extern "C" int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
                                     int64_t* scores, int64_t* bestpos, int64_t* bestq)
 {
-  return swa_search_endpoints_strand(db, query, qlen, seqnos, nullptr, n, scores, bestpos, bestq);
+  return swa_search_endpoints_strand(db, query, qlen, seqnos, nullptr, nullptr, n, scores, bestpos, bestq);
 }
 
-extern "C" int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, uint8_t* buf, int64_t cap, int64_t* len)
+extern "C" int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, uint8_t* buf, int64_t cap,
+                               int64_t* len, int64_t* ntlen)
 {
   if (!db || !len || cap < 0 || (cap > 0 && !buf)) return fail(SWA_EINVAL, "bad argument");
   std::vector<uint8_t> seq;
-  const int rc = fetch_sequence(db, seqno, dstrand, seq);
+  const int rc = fetch_sequence(db, seqno, dstrand, dframe, seq);
   if (rc != SWA_OK) return rc;
+  if (ntlen) *ntlen = db->frames == 6 ? db->h_ntlen[size_t(seqno - db->first_seqno)] : 0;
   *len = int64_t(seq.size());
   if (int64_t(seq.size()) > cap) return fail(SWA_ERANGE, "sequence buffer too small");
   if (!seq.empty()) std::memcpy(buf, seq.data(), seq.size());
@@ -1043,8 +1206,8 @@ extern "C" int swa_traceback(const uint8_t* query, int64_t qlen, const uint8_t* 
 // align_chunk + hits_align (swipe.cc:339-414, hits.cc:546-618): end points on the GPU, start point and edit
 // script on the host
 extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
-                              const int32_t* dstrands, int64_t n, swa_alignment_t* out, char* text, int64_t text_cap,
-                              int64_t* text_used)
+                              const int32_t* dstrands, const int32_t* dframes, int64_t n, swa_alignment_t* out,
+                              char* text, int64_t text_cap, int64_t* text_used)
 {
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
@@ -1053,7 +1216,7 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   *text_used = 0;
   if (n == 0) return SWA_OK;
   std::vector<long long> ends;
-  rc = endpoints_on_device(db, query, qlen, seqnos, dstrands, n, ends);
+  rc = endpoints_on_device(db, query, qlen, seqnos, dstrands, dframes, n, ends);
   if (rc != SWA_OK) return rc;
   const int64_t gapopen = db->goe - db->ge, gapextend = db->ge;
   const int64_t limit16 = 65536 - db->hi;                           // SCORELIMIT_16, matrices.cc:578
@@ -1061,8 +1224,8 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   std::vector<uint8_t> dseq;
   std::vector<swa::EditOp> ops;
   for (int64_t i = 0; i < n; ++i) {
-    const int strand = dstrands ? (dstrands[i] ? 1 : 0) : 0;
-    rc = fetch_sequence(db, seqnos[i], strand, dseq);
+    const int strand = dstrands ? (dstrands[i] ? 1 : 0) : 0, frame = dframes ? dframes[i] : 0;
+    rc = fetch_sequence(db, seqnos[i], strand, frame, dseq);
     if (rc != SWA_OK) return rc;
     swa_alignment_t& a = out[i];
     std::memset(&a, 0, sizeof a);
@@ -1075,6 +1238,8 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
     if (rc != SWA_OK) return rc;
     a.seqno = seqnos[i];
     a.dstrand = strand;
+    a.dframe = frame;
+    a.dlennt = db->frames == 6 ? db->h_ntlen[size_t(seqnos[i] - db->first_seqno)] : 0;
     a.cigar_offset = int64_t(all.size());
     for (const swa::EditOp& op : ops) { all += op.kind; all += std::to_string(op.count); }
     a.cigar_len = int64_t(all.size()) - a.cigar_offset;

@@ -397,6 +397,101 @@ def test_alignment_phase_matches_reference(name):
     db.close()
 
 
+TNAMES = [f.__name__[5:] for f in cases.TRANSLATED]
+
+
+def open_translated_case(case):
+    if case.sym in (3, 4):
+        res, off = oracle.pack(case.seqs)
+        db = swipe_amd.Database.from_arrays(res, off, translate_gencode=case.db_gencode)
+    else:
+        db = swipe_amd.Database.from_sequences(case.seqs, symtype=1)
+    db.set_scoring(case_matrix(case, swipe_amd), case.gapopen, case.gapextend)
+    return db
+
+
+def query_frames(case):
+    if case.sym in (2, 4):
+        t = swipe_amd.translate_table(case.query_gencode)
+        return [swipe_amd.translate(case.query, k // 3, k % 3, t) for k in range(6)]
+    return [case.query]
+
+
+@pytest.mark.parametrize("name", TNAMES)
+def test_translated_scores_equal_reference(name):
+    """-p 2/3/4: the GPU's six-frame translation of the database (swa_translate_frames) and the DP over every
+    (query frame, database frame) pair against the reference's own 63-bit scores for all of them."""
+    case, g = cases.get(name), load_golden(name)
+    db = open_translated_case(case)
+    info = db.info()
+    nd = 6 if case.sym in (3, 4) else 1
+    assert info["frames"] == nd and info["seqcount"] == len(case.seqs)
+    assert info["symcount"] == sum(len(s) for s in case.seqs)
+    dt = oracle.translate_table(case.db_gencode)
+    for seqno in range(len(case.seqs)):
+        for tag in range(nd):
+            want = oracle.translate(case.seqs[seqno], tag // 3, tag % 3, dt) if nd == 6 else case.seqs[seqno]
+            assert np.array_equal(db.sequence(seqno, tag // 3, tag % 3), want), (seqno, tag)
+    for qt, q in enumerate(query_frames(case)):
+        scores, c = db.search(q)
+        want = np.zeros(len(case.seqs) * nd, dtype=np.int64)
+        for r in g["raw"]:
+            if r[1] == qt:
+                want[r[0] * nd + r[2]] = r[8]
+        assert np.array_equal(scores, want), qt
+    db.close()
+
+
+@pytest.mark.parametrize("name", TNAMES)
+def test_translated_hit_list_and_alignments_equal_reference(name):
+    case, g = cases.get(name), load_golden(name)
+    db = open_translated_case(case)
+    nsym = int(sum(len(s) for s in case.seqs))
+    st = swipe_amd.stats_init(symtype=case.sym, matrix=case.matrix, gapopen=case.gapopen, gapextend=case.gapextend,
+                              qlen=len(case.query), db_seqcount=len(case.seqs), db_symcount=nsym)
+    qf = query_frames(case)
+    per_seq = {2: 6, 3: 6, 4: 36}[case.sym]
+    hits, tot, obv, c = db.search_frames_topk(qf, keep=min(case.keep, per_seq * len(case.seqs)),
+                                              minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
+    cli = g["cli"]["1"]
+    assert [h[0] for h in hits] == cli["seqno"] and [h[1] for h in hits] == cli["score"]
+    lab = lambda s, f: "%s%d" % ("-" if s else "+", f + 1)
+    got = [lab(h[2], h[3]) if case.sym == 2 else lab(h[4], h[5]) if case.sym == 3 else lab(h[2], h[3]) + "/" + lab(h[4], h[5])
+           for h in hits]
+    assert got == cli["strand"]
+    # alignment phase for every positive pair of the fixture, grouped by query frame as align_chunk does
+    for qt, q in enumerate(qf):
+        rows = [r for r in g["align"] if r[1] == qt]
+        if not rows:
+            continue
+        al = db.align(q, [r[0] for r in rows], [r[2] // 3 for r in rows], [r[2] % 3 for r in rows])
+        for a, (seqno, _, dtag, s16s, bp, bq, score, qs, dst, qe, de, cigar, hinted) in zip(al, rows):
+            want = hinted if hinted is not None else [score, qs, dst, qe, de, cigar]
+            assert [a["score"], a["q_start"], a["d_start"], a["q_end"], a["d_end"], a["cigar"]] == want, (seqno, qt, dtag)
+            assert a["dlennt"] == (len(case.seqs[seqno]) if case.sym in (3, 4) else 0)
+    db.close()
+
+
+@pytest.mark.parametrize("name", TNAMES)
+def test_translated_cli_output_equals_reference_cli(tmp_path, name):
+    import subprocess
+    from conftest import ROOT
+    case, g = cases.get(name), load_golden(name)
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    alpha = blastdb.NCBI4NA if case.query_is_nt else blastdb.NCBISTDAA
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    args = [exe, "-d", base, "-i", qf, "-p", str(case.sym), "-G", str(case.gapopen), "-E", str(case.gapextend),
+            "-v", str(case.keep), "-e", "10", "-M", case.matrix, "-Q", str(case.query_gencode), "-D", str(case.db_gencode)]
+    run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
+    assert run(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]
+    assert run(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
+    plain = run(["-m", "0", "-b", str(g["nalign"])])
+    assert plain[plain.index("Sequences producing"):] == g["plain_align"]
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     import subprocess
     from conftest import ROOT

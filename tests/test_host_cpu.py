@@ -199,3 +199,40 @@ def test_host_traceback_counts_and_errors():
         swipe_amd.traceback(q, np.zeros(0, np.uint8), M, 11, 1)      # score 0: the reference's internal error
     with pytest.raises(swipe_amd.SwaError):
         swipe_amd.traceback(q, np.full(5, 40, np.uint8), M, 11, 1)  # symbol code out of range
+
+
+def test_translation_tables_and_frames_equal_oracle():
+    """genetic-code tables for every assigned code and all six frames of awkward sequences (lengths 0..8,
+    ambiguity codes) - product host helpers against the oracle (itself pinned on the reference's frames)."""
+    L = _lib.load()
+    for code in range(1, 24):
+        name = L.swa_gencode_name(code)
+        if name is None:
+            with pytest.raises(swipe_amd.SwaError):
+                swipe_amd.translate_table(code)
+            with pytest.raises(ValueError):
+                oracle.translate_table(code)
+            continue
+        assert np.array_equal(swipe_amd.translate_table(code), oracle.translate_table(code)), code
+    t = swipe_amd.translate_table(1)
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 9)) + [100, 301]:
+        d = rng.integers(0, 16, n).astype(np.uint8)
+        for tag in range(6):
+            assert np.array_equal(swipe_amd.translate(d, tag // 3, tag % 3, t), oracle.translate(d, tag // 3, tag % 3, t))
+    assert swipe_amd.translate(blastdb.encode_nucleotide("ATGGCNTAA"), 0, 0, t).tolist() == [12, 1, 25]      # M A *
+
+
+@pytest.mark.parametrize("name", [f.__name__[5:] for f in cases.TRANSLATED])
+def test_translated_statistics_equal_oracle_and_cli(name):
+    from conftest import load_golden
+    case, g = cases.get(name), load_golden(name)
+    nsym = int(sum(len(s) for s in case.seqs))
+    st = swipe_amd.stats_init(symtype=case.sym, matrix=case.matrix, gapopen=case.gapopen, gapextend=case.gapextend,
+                              qlen=len(case.query), db_seqcount=len(case.seqs), db_symcount=nsym)
+    h = oracle.HitList(descriptions=case.keep, alignments=0, symtype=case.sym, matrix=case.matrix, gapopen=case.gapopen,
+                       gapextend=case.gapextend, qlen=len(case.query), dbseqs=len(case.seqs), dbsyms=nsym)
+    assert (st.available, st.lenadj, st.m, st.n, st.scorethreshold) == (1, h.c.lenadj, h.c.m, h.c.n, h.c.scorethreshold)
+    cli = g["cli"]["1"]
+    assert ["%.2g" % st.evalue(s) for s in cli["score"]] == cli["evalue"]
+    assert ["%.1f" % st.bits(s) for s in cli["score"]] == cli["bits"]
