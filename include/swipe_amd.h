@@ -123,6 +123,27 @@ SWA_API int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno
    *needed = bytes incl. NUL; SWA_ERANGE when buflen is smaller. */
 SWA_API int swa_blastdb_deflines(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
                          int64_t* needed);
+/* Definition lines and inclusion filters of a database, host only (db_open's alias / mask / taxid handling,
+   database.cc:670-772, 1403-1481; header rendering, asnparse.cc).  taxidfile may be NULL (-x, one taxid per
+   line).  A MEMB_BIT alias with its OIDLIST mask is honoured automatically, as in the reference. */
+typedef struct swa_headers swa_headers;
+#define SWA_HEADERS_SHOW_GIS   1   /* -I: include gi|N ids */
+#define SWA_HEADERS_SHOW_TAXID 2   /* -H: append |taxid|N|link|N|memb|N */
+SWA_API int swa_headers_open(const char* basename, int symtype, const char* taxidfile, swa_headers** out);
+SWA_API void swa_headers_close(swa_headers* h);
+/* volume totals, the masked alias's NSEQ / LENGTH (equal to the totals when unmasked: what statistics and
+   the "Database size" line use, hits.cc:333-342), longest sequence, title */
+SWA_API int swa_headers_info(const swa_headers* h, int64_t* seqcount, int64_t* symcount, int64_t* masked_seqcount,
+                     int64_t* masked_symcount, int64_t* longest, char* title, int64_t title_cap);
+/* the definition lines of `seqno` that pass the membership / taxid filters, one per line; *needed = bytes
+   incl. NUL, SWA_ERANGE when buflen is smaller */
+SWA_API int swa_headers_get(const swa_headers* h, int64_t seqno, int flags, char* buf, int64_t buflen, int64_t* needed);
+/* db_check_inclusion for sequences [first_seqno, first_seqno + n): include[i] = 1 if it is searched */
+SWA_API int swa_headers_inclusion(const swa_headers* h, int64_t first_seqno, int64_t n, uint8_t* include);
+/* Restrict a resident shard to a subset (include[i] != 0 for sequence first_seqno + i; NULL = all).  Excluded
+   sequences are skipped by every search and report score -1.  swa_db_open applies a masked alias's OID mask
+   by itself; a taxid list goes through swa_headers_inclusion + this call. */
+SWA_API int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t n);
 SWA_API void swa_db_close(swa_db* db);
 
 /* ---- scoring ------------------------------------------------------------------------------ */

@@ -51,6 +51,8 @@ EXPORTS = [
     "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
     "swa_db_open_translated", "swa_db_from_memory_translated", "swa_search_frames_topk",
     "swa_gencode_name", "swa_translate_table", "swa_translate",
+    "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_get", "swa_headers_inclusion",
+    "swa_db_set_inclusion",
     "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
     "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
@@ -96,6 +98,13 @@ def load():
     L.swa_db_from_memory_translated.argtypes = [vp, vp, i64, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp)]
     L.swa_search_frames_topk.argtypes = [vp, C.c_int, C.POINTER(vp), i64p, C.POINTER(C.c_int32), i64, i64, i64,
                                          C.POINTER(FrameHit), i64p, i64p, i64p, C.POINTER(Counters)]
+    L.swa_headers_open.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.swa_headers_close.argtypes = [vp]
+    L.swa_headers_close.restype = None
+    L.swa_headers_info.argtypes = [vp, i64p, i64p, i64p, i64p, i64p, C.c_char_p, i64]
+    L.swa_headers_get.argtypes = [vp, i64, C.c_int, C.c_char_p, i64, i64p]
+    L.swa_headers_inclusion.argtypes = [vp, i64, i64, vp]
+    L.swa_db_set_inclusion.argtypes = [vp, vp, i64]
     L.swa_gencode_name.argtypes = [C.c_int]
     L.swa_gencode_name.restype = C.c_char_p
     L.swa_translate_table.argtypes = [C.c_int, vp]

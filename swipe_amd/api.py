@@ -139,6 +139,15 @@ class Database:
         res = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if len(seqs) else np.zeros(0, np.uint8)
         return cls.from_arrays(res, off, **kw)
 
+    def set_inclusion(self, include=None):
+        """Search only the sequences with include[i] != 0 (i counted from the shard's first sequence); None = all.
+        Excluded sequences report score -1."""
+        if include is None:
+            _check(_lib.load().swa_db_set_inclusion(self._h, None, 0))
+            return
+        inc = np.ascontiguousarray(include, dtype=np.uint8)
+        _check(_lib.load().swa_db_set_inclusion(self._h, inc.ctypes.data, len(inc)))
+
     def info(self):
         i = _lib.DbInfo()
         _check(_lib.load().swa_db_info(self._h, C.byref(i)))
@@ -296,6 +305,51 @@ def traceback(query, dseq, matrix, gapopen: int, gapextend: int, hint=None) -> d
     _check(L.swa_traceback(q.ctypes.data, len(q), d.ctypes.data, len(d), M.ctypes.data, gapopen, gapextend, hs, hq, hd,
                            C.byref(a), text, cap, C.byref(used)))
     return _alignment_dict(a, text.raw)
+
+
+class Headers:
+    """Definition lines, OID mask and taxid filter of a BLAST v4 database (host only)."""
+    SHOW_GIS, SHOW_TAXID = 1, 2
+
+    def __init__(self, basename: str, *, symtype: int = 1, taxidfile: Optional[str] = None):
+        self._h = C.c_void_p()
+        _check(_lib.load().swa_headers_open(os.fsencode(basename), symtype, os.fsencode(taxidfile) if taxidfile else None,
+                                            C.byref(self._h)))
+
+    def info(self) -> dict:
+        v = [C.c_int64() for _ in range(5)]
+        title = C.create_string_buffer(4096)
+        _check(_lib.load().swa_headers_info(self._h, *[C.byref(x) for x in v], title, 4096))
+        keys = ("seqcount", "symcount", "masked_seqcount", "masked_symcount", "longest")
+        return dict(zip(keys, (x.value for x in v)), title=title.value.decode())
+
+    def get(self, seqno: int, flags: int = 0):
+        """the definition lines of `seqno` that pass the membership / taxid filters"""
+        need = C.c_int64()
+        buf = C.create_string_buffer(4096)
+        rc = _lib.load().swa_headers_get(self._h, seqno, flags, buf, 4096, C.byref(need))
+        if rc == _lib.SWA_ERANGE:
+            buf = C.create_string_buffer(need.value)
+            rc = _lib.load().swa_headers_get(self._h, seqno, flags, buf, need.value, C.byref(need))
+        _check(rc)
+        text = buf.value.decode()
+        return text.split("\n") if text else []
+
+    def inclusion(self, first_seqno: int, n: int) -> np.ndarray:
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        _check(_lib.load().swa_headers_inclusion(self._h, first_seqno, n, out.ctypes.data))
+        return out[:n]
+
+    def close(self):
+        if self._h:
+            _lib.load().swa_headers_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def translate_table(gencode: int) -> np.ndarray:

@@ -91,6 +91,104 @@ def ber_defline(local_id: str, title: str) -> bytes:
     return out
 
 
+_EOC = b"\x00\x00"
+_TEXTSEQ_TAGS = {"gb": 0xA4, "emb": 0xA5, "pir": 0xA6, "sp": 0xA7, "ref": 0xA9, "dbj": 0xAC, "prf": 0xAD,
+                 "tpg": 0xAF, "tpe": 0xB0, "tpd": 0xB1, "gpp": 0xB2, "nat": 0xB3}
+
+
+def _ber_int(v: int) -> bytes:
+    n = max(1, (int(v).bit_length() + 7) // 8)
+    return b"\x02" + bytes([n]) + int(v).to_bytes(n, "big")
+
+
+def _ctx(tag: int, body: bytes) -> bytes:
+    """context-tagged constructed element, indefinite length (the only form the reference's parser reads)"""
+    return bytes([tag, 0x80]) + body + _EOC
+
+
+def _seq(body: bytes) -> bytes:
+    return b"\x30\x80" + body + _EOC
+
+
+def ber_seq_id(sid: tuple) -> bytes:
+    """One Seq-id in the binary ASN.1 of BLAST v4 headers (NCBI seqloc.asn; reference asnparse.cc:640-751).
+    Forms: ("lcl", str|int)  ("bbs"|"bbm", int)  ("gim", int)  ("gi", int)  ("gnl", db, str|int)
+    ("pdb", mol, chain_code)  ("pat", country, number, seqno, granted)  and the Textseq-ids
+    (db, accession, name[, version[, release]]) for gb emb pir sp ref dbj prf tpg tpe tpd gpp nat."""
+    kind = sid[0]
+    vs = lambda x: _ber_visible_string(str(x).encode())
+    obj = lambda x: _ctx(0xA0, _ber_int(x)) if isinstance(x, int) else _ctx(0xA1, vs(x))
+    if kind == "lcl":
+        return _ctx(0xA0, obj(sid[1]))
+    if kind in ("bbs", "bbm"):
+        return _ctx(0xA1 if kind == "bbs" else 0xA2, _ber_int(sid[1]))
+    if kind == "gim":
+        return _ctx(0xA3, _seq(_ctx(0xA0, _ber_int(sid[1]))))
+    if kind == "gi":
+        return _ctx(0xAB, _ber_int(sid[1]))
+    if kind == "gnl":
+        return _ctx(0xAA, _seq(_ctx(0xA0, vs(sid[1])) + _ctx(0xA1, obj(sid[2]))))
+    if kind == "pdb":
+        body = _ctx(0xA0, vs(sid[1]))
+        if len(sid) > 2 and sid[2] is not None:
+            body += _ctx(0xA1, _ber_int(sid[2]))
+        return _ctx(0xAE, _seq(body))
+    if kind == "pat":
+        _, country, number, seqno, granted = sid
+        idpat = _seq(_ctx(0xA0, vs(country)) + _ctx(0xA1, _ctx(0xA0 if granted else 0xA1, vs(number))))
+        return _ctx(0xA8, _seq(_ctx(0xA0, _ber_int(seqno)) + _ctx(0xA1, idpat)))
+    if kind in _TEXTSEQ_TAGS:
+        acc, name = sid[1], sid[2]
+        version = sid[3] if len(sid) > 3 else 0
+        release = sid[4] if len(sid) > 4 else None
+        body = b""
+        if name:
+            body += _ctx(0xA0, vs(name))
+        if acc:
+            body += _ctx(0xA1, vs(acc))
+        if release:
+            body += _ctx(0xA2, vs(release))
+        if version:
+            body += _ctx(0xA3, _ber_int(version))
+        return _ctx(_TEXTSEQ_TAGS[kind], _seq(body))
+    raise ValueError(f"unknown Seq-id kind {kind!r}")
+
+
+def ber_defline_set(deflines: Sequence[dict]) -> bytes:
+    """A Blast-def-line-set: one dict per definition line with optional keys title, ids (tuples for
+    ber_seq_id), taxid, memb, links (reference asnparse.cc:753-856)."""
+    out = b""
+    for d in deflines:
+        body = b""
+        if d.get("title") is not None:
+            body += _ctx(0xA0, _ber_visible_string(d["title"].encode()))
+        if d.get("ids"):
+            body += _ctx(0xA1, _seq(b"".join(ber_seq_id(i) for i in d["ids"])))
+        if d.get("taxid") is not None:
+            body += _ctx(0xA2, _ber_int(d["taxid"]))
+        if d.get("memb") is not None:
+            body += _ctx(0xA3, _seq(_ber_int(d["memb"])))
+        if d.get("links") is not None:
+            body += _ctx(0xA4, _seq(_ber_int(d["links"])))
+        out += _seq(body)
+    return _seq(out)
+
+
+def write_mask_alias(alias_basename: str, volume_basename: str, include: Sequence[bool], *, memb_bit: int = 1,
+                     length: int = 0, title: str = "masked subset", protein: bool = True) -> None:
+    """A masked database as NCBI ships swissprot/pdbaa: an alias naming ONE volume plus an OID mask file
+    (bit 7-(s&7) of byte 4+(s>>3) set = sequence s is a member; reference database.cc:687-706, 775-870)."""
+    inc = np.asarray(include, dtype=bool)
+    maxoid = int(np.nonzero(inc)[0].max()) if inc.any() else 0
+    bits = np.packbits(inc.astype(np.uint8))            # MSB first, as db_check_msk reads it
+    msk = os.path.basename(alias_basename) + ".msk"
+    with open(os.path.join(os.path.dirname(alias_basename), msk), "wb") as f:
+        f.write(struct.pack(">I", maxoid) + bits.tobytes())
+    with open(f"{alias_basename}.{'pal' if protein else 'nal'}", "w") as f:
+        f.write(f"#\n# Alias file created by swipe_amd\n#\nTITLE {title}\nDBLIST {os.path.basename(volume_basename)}\n"
+                f"OIDLIST {msk}\nLENGTH {length}\nNSEQ {int(inc.sum())}\nMAXOID {maxoid}\nMEMB_BIT {memb_bit}\n")
+
+
 def pack_nucleotide(codes: np.ndarray):
     """4-bit masks -> (2-bit packed bytes incl. remainder byte, ambiguity table bytes)."""
     codes = np.asarray(codes, dtype=np.uint8)
@@ -133,14 +231,19 @@ def pack_nucleotide(codes: np.ndarray):
 
 def write_volume(basename: str, seqs: Sequence[np.ndarray], *, protein: bool = True,
                  ids: Optional[Sequence[str]] = None, titles: Optional[Sequence[str]] = None,
-                 title: str = "swipe_amd synthetic", date: str = "Jan 1, 2026  0:00 AM") -> None:
-    """Write one v4 volume (``.pin/.psq/.phr`` or ``.nin/.nsq/.nhr``)."""
+                 title: str = "swipe_amd synthetic", date: str = "Jan 1, 2026  0:00 AM",
+                 headers: Optional[Sequence[Sequence[dict]]] = None) -> None:
+    """Write one v4 volume (``.pin/.psq/.phr`` or ``.nin/.nsq/.nhr``).  headers[i] (a list of defline dicts
+    for ber_defline_set) overrides the plain ``lcl|id title`` header of sequence i."""
     ext = ("pin", "psq", "phr") if protein else ("nin", "nsq", "nhr")
     n = len(seqs)
     hdr_off = [0]
     hdr = bytearray()
     for i in range(n):
-        hdr += ber_defline(ids[i] if ids else f"s{i}", titles[i] if titles else f"seq{i}")
+        if headers is not None and headers[i] is not None:
+            hdr += ber_defline_set(headers[i])
+        else:
+            hdr += ber_defline(ids[i] if ids else f"s{i}", titles[i] if titles else f"seq{i}")
         hdr_off.append(len(hdr))
     seq_off = []
     amb_off = []

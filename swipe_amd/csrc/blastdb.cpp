@@ -4,12 +4,15 @@
 // nesting, database.cc:406-489 and 775-925), index files (.pin/.nin, database.cc:566-601:
 // everything big-endian except the little-endian residue total at 595) and sequence files
 // (.psq: NCBIstdaa bytes, NUL-terminated entries; .nsq: 2 bits per base, remainder count in
-// the last byte, optional ambiguity runs, database.cc:1237-1323).  OID masks, taxid filters
-// and translated (6-frame) access are outside this path.
+// the last byte, optional ambiguity runs, database.cc:1237-1323), OID masks behind a MEMB_BIT alias
+// (database.cc:670-716), taxid lists (718-772) and the binary ASN.1 definition lines (asnparse.cc).
 #include "../../include/swipe_amd.h"
 #include "host_util.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -79,26 +82,50 @@ bool open_volume(const std::string& base, bool protein, Volume& v, std::string& 
   return true;
 }
 
-// DBLIST entries of an alias file, or empty if there is no alias
-std::vector<std::string> read_alias(const std::string& base, bool protein, std::string* title)
+// One alias file (database.cc:406-489): TITLE, DBLIST, OIDLIST, LENGTH, NSEQ, MAXOID, MEMB_BIT
+struct Alias {
+  bool present = false;
+  std::string title;
+  std::vector<std::string> dblist, oidlist;
+  int64_t length = 0, nseq = 0, maxoid = 0, memb_bit = 0;
+};
+
+std::vector<std::string> words(const char* text)
 {
-  std::vector<std::string> names;
+  std::vector<std::string> out;
+  std::string cur;
+  for (const char* p = text; *p; ++p) {
+    if (std::strchr(" \t\r\n", *p)) { if (!cur.empty()) out.push_back(cur), cur.clear(); }
+    else cur += *p;
+  }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+
+Alias read_alias(const std::string& base, bool protein, std::string* error)
+{
+  Alias a;
   FILE* f = std::fopen((base + (protein ? ".pal" : ".nal")).c_str(), "r");
-  if (!f) return names;
-  char line[4096];
+  if (!f) return a;
+  a.present = true;
+  char line[10000];
   while (std::fgets(line, sizeof line, f)) {
-    if (std::strncmp(line, "TITLE", 5) == 0 && title) {
-      std::string t(line + 5);
-      while (!t.empty() && (t.back() == '\n' || t.back() == '\r')) t.pop_back();
-      size_t b = t.find_first_not_of(" \t");
-      *title = b == std::string::npos ? "" : t.substr(b);
-    } else if (std::strncmp(line, "DBLIST", 6) == 0) {
-      char* tok = std::strtok(line + 6, " \t\r\n");
-      while (tok) { names.emplace_back(tok); tok = std::strtok(nullptr, " \t\r\n"); }
-    }
+    if (std::strncmp(line, "TITLE ", 6) == 0) {
+      std::string t(line + 6);
+      const size_t b = t.find_first_not_of(" \t");
+      t = b == std::string::npos ? std::string() : t.substr(b);
+      a.title = t.substr(0, t.find_first_of("\r\n"));
+    } else if (std::strncmp(line, "DBLIST", 6) == 0) a.dblist = words(line + 6);
+    else if (std::strncmp(line, "OIDLIST", 7) == 0) a.oidlist = words(line + 7);
+    else if (std::strncmp(line, "GILIST", 6) == 0) { if (error) *error = "GILIST in database alias files not implemented."; }
+    else if (std::strncmp(line, "LENGTH ", 7) == 0) a.length = std::atol(line + 7);
+    else if (std::strncmp(line, "NSEQ ", 5) == 0) a.nseq = std::atol(line + 5);
+    else if (std::strncmp(line, "MAXOID ", 7) == 0) a.maxoid = std::atol(line + 7);
+    else if (std::strncmp(line, "MEMB_BIT ", 9) == 0) a.memb_bit = std::atol(line + 9);
   }
   std::fclose(f);
-  return names;
+  if (a.title.empty()) a.title = base;
+  return a;
 }
 
 std::string dir_of(const std::string& base)
@@ -106,38 +133,132 @@ std::string dir_of(const std::string& base)
   const size_t s = base.rfind('/');
   return s == std::string::npos ? std::string() : base.substr(0, s + 1);
 }
+
+// taxid list file -> bitmap (db_read_taxid_file, database.cc:733-772)
+bool read_taxid_bitmap(const char* path, std::vector<uint8_t>& bitmap, std::string& err)
+{
+  FILE* f = std::fopen(path, "r");
+  if (!f) { err = std::string("Unable to open taxid file ") + path + "."; return false; }
+  bitmap.assign(64 * 1024, 0);
+  unsigned long taxid;
+  while (std::fscanf(f, "%lu\n", &taxid) > 0) {
+    const size_t byte = taxid / 8;
+    if (byte >= bitmap.size()) bitmap.resize(byte + 1, 0);
+    bitmap[byte] = uint8_t(bitmap[byte] | (1u << (taxid & 7)));
+  }
+  std::fclose(f);
+  return true;
+}
+
+// A database as db_open leaves it (database.cc:775-911): volumes behind at most two alias levels, an OID
+// mask per volume when the top alias names a membership bit, optional taxid list.
+struct BlastDb {
+  bool protein = true;
+  std::vector<Volume> vols;
+  std::vector<Mapped> masks;            // one per volume when memb_bit != 0
+  std::vector<int64_t> maxoid;
+  std::string title;
+  int64_t memb_bit = 0;
+  int64_t nseq = 0, nsym = 0, longest = 0, masked_nseq = 0, masked_nsym = 0;
+  bool have_taxids = false;
+  std::vector<uint8_t> taxids;
+
+  int open(const char* basename, int symtype, const char* taxidfile, bool want_headers)
+  {
+    if (!basename) return swa::fail(SWA_EINVAL, "null database name");
+    if (symtype != SWA_SYMTYPE_PROTEIN && symtype != SWA_SYMTYPE_NUCLEOTIDE)
+      return swa::fail(SWA_EINVAL, "database files are nucleotide (0) or protein (1)");
+    protein = symtype == SWA_SYMTYPE_PROTEIN;
+    const std::string base(basename), dir = dir_of(base);
+    std::string err;
+    struct Entry { std::string base, msk; int64_t mnseq, mlen, maxoid; };
+    std::vector<Entry> entries;
+    Alias top = read_alias(base, protein, &err);
+    if (!err.empty()) return swa::fail(SWA_EIO, err);
+    if (!top.present) {
+      entries.push_back({base, "", 0, 0, 0});
+    } else {
+      title = top.title;
+      memb_bit = top.memb_bit;
+      for (size_t i = 0; i < top.dblist.size(); ++i) {
+        Alias sub = read_alias(dir + top.dblist[i], protein, &err);
+        if (!err.empty()) return swa::fail(SWA_EIO, err);
+        if (sub.present) {
+          if (top.memb_bit && (sub.oidlist.size() != 1 || sub.dblist.size() != 1)) return swa::fail(SWA_EIO, "Illegal alias file (2).");
+          for (size_t j = 0; j < sub.dblist.size(); ++j)
+            entries.push_back({dir + sub.dblist[j], top.memb_bit ? dir + sub.oidlist[j] : "", sub.nseq, sub.length, sub.maxoid});
+        } else {
+          if (top.oidlist.empty()) { top.memb_bit = 0; memb_bit = 0; }                 // database.cc:838-842
+          if (top.memb_bit && (top.oidlist.size() != 1 || top.dblist.size() != 1)) return swa::fail(SWA_EIO, "Illegal alias file (1).");
+          entries.push_back({dir + top.dblist[i], top.memb_bit ? dir + top.oidlist[i] : "", top.nseq, top.length, top.maxoid});
+        }
+      }
+    }
+    if (entries.empty()) return swa::fail(SWA_EIO, "alias file lists no volumes");
+    if (entries.size() > 256) return swa::fail(SWA_EIO, "too many database volumes");   // database.cc:216
+    vols.resize(entries.size());
+    masks.resize(memb_bit ? entries.size() : 0);
+    maxoid.assign(entries.size(), 0);
+    for (size_t i = 0; i < entries.size(); ++i) {
+      if (!open_volume(entries[i].base, protein, vols[i], err)) return swa::fail(SWA_EIO, err);
+      if (want_headers && !vols[i].hdr.open(entries[i].base + (protein ? ".phr" : ".nhr")))
+        return swa::fail(SWA_EIO, "Unable to open file " + entries[i].base + (protein ? ".phr." : ".nhr."));
+      nseq += vols[i].nseq;
+      nsym += vols[i].nsym;
+      longest = std::max(longest, vols[i].longest);
+      if (memb_bit) {
+        if (!masks[i].open(entries[i].msk)) return swa::fail(SWA_EIO, "Unable to open msk file " + entries[i].msk + ".");
+        maxoid[i] = entries[i].maxoid;
+        masked_nseq += entries[i].mnseq;
+        masked_nsym += entries[i].mlen;
+      }
+    }
+    if (!memb_bit) { masked_nseq = nseq; masked_nsym = nsym; }
+    if (title.empty()) title = vols[0].title;
+    if (taxidfile && *taxidfile) {
+      if (!read_taxid_bitmap(taxidfile, taxids, err)) return swa::fail(SWA_EIO, err);
+      have_taxids = true;
+    }
+    return SWA_OK;
+  }
+
+  bool locate(int64_t seqno, size_t* vol, int64_t* local) const
+  {
+    if (seqno < 0) return false;
+    for (size_t i = 0; i < vols.size(); ++i) {
+      if (seqno < vols[i].nseq) { *vol = i; *local = seqno; return true; }
+      seqno -= vols[i].nseq;
+    }
+    return false;
+  }
+  bool taxid_ok(unsigned long taxid) const                       // db_check_taxid, database.cc:718-731
+  {
+    if (!have_taxids) return true;
+    const size_t byte = taxid / 8;
+    return byte < taxids.size() && ((taxids[byte] >> (taxid & 7)) & 1);
+  }
+  bool in_mask(size_t vol, int64_t local) const                  // db_check_msk, database.cc:687-706
+  {
+    if (!memb_bit) return true;
+    if (local > maxoid[vol]) return false;
+    const size_t at = 4 + size_t(local >> 3);
+    return at < masks[vol].n && ((masks[vol].p[at] >> (7 - (local & 7))) & 1);
+  }
+};
 }  // namespace
 
 int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out)
 {
-  if (!basename) return fail(SWA_EINVAL, "null database name");
-  if (symtype != SWA_SYMTYPE_PROTEIN && symtype != SWA_SYMTYPE_NUCLEOTIDE)
-    return fail(SWA_EINVAL, "only symtype 0 (nucleotide) and 1 (protein) databases are supported");
-  const bool protein = symtype == SWA_SYMTYPE_PROTEIN;
-  const std::string base(basename);
-  std::vector<std::string> vols;
-  std::string title;
-  const std::vector<std::string> top = read_alias(base, protein, &title);
-  if (top.empty()) {
-    vols.push_back(base);
-  } else {
-    const std::string dir = dir_of(base);
-    for (const std::string& n : top) {
-      const std::vector<std::string> nested = read_alias(dir + n, protein, nullptr);
-      if (nested.empty()) vols.push_back(dir + n);
-      else for (const std::string& m : nested) vols.push_back(dir + m);
-    }
-  }
-  if (vols.size() > 256) return fail(SWA_EIO, "too many database volumes");    // database.cc:216
-  std::vector<Volume> V(vols.size());
-  std::string err;
-  int64_t nseq = 0, nsym = 0, longest = 0;
-  for (size_t i = 0; i < vols.size(); ++i) {
-    if (!open_volume(vols[i], protein, V[i], err)) return fail(SWA_EIO, err);
-    nseq += V[i].nseq;
-    nsym += V[i].nsym;
-    if (V[i].longest > longest) longest = V[i].longest;
-  }
+  BlastDb bd;
+  const int rc_open = bd.open(basename, symtype, nullptr, false);
+  if (rc_open != SWA_OK) return rc_open;
+  const bool protein = bd.protein;
+  const std::vector<Volume>& V = bd.vols;
+  const int64_t nseq = bd.nseq, nsym = bd.nsym, longest = bd.longest;
+  const std::string& title = bd.title;
+  out.masked = bd.memb_bit != 0;
+  out.masked_seqcount = bd.masked_nseq;
+  out.masked_symcount = bd.masked_nsym;
   out.total_seqcount = nseq;
   out.total_symcount = nsym;
   out.longest = longest;
@@ -147,6 +268,7 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
   out.first_seqno = first_seqno;
   out.offsets.assign(1, 0);
   out.residues.clear();
+  out.included.clear();
   if (last_seqno < first_seqno) return SWA_OK;
   out.offsets.reserve(size_t(last_seqno - first_seqno + 2));
 
@@ -193,6 +315,7 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
         }
       }
       out.offsets.push_back(int64_t(out.residues.size()));
+      if (out.masked) out.included.push_back(bd.in_mask(size_t(&v - V.data()), s) ? 1 : 0);
     }
     vbase += v.nseq;
   }
@@ -200,15 +323,16 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
 }
 
 // ---- definition lines -----------------------------------------------------------------------
-// Minimal BER walker for Blast-def-line-set (reference asnparse.cc:652-887): renders the first
-// def-line of an entry as "<seqids joined by |> <title>".  Seq-id choices follow the tag table at
-// asnparse.cc:657-658.
+// BER walker for Blast-def-line-set (reference asnparse.cc:94-1095).  Every element of these headers is
+// context-tagged with indefinite length, primitives are short definite; the walker accepts both forms.
 namespace {
 struct Ber {
   const uint8_t* p;
   const uint8_t* end;
   bool eoc() const { return p + 1 < end && p[0] == 0 && p[1] == 0; }
-  // reads tag + length; returns content length or -1 for the indefinite form
+  bool more(const uint8_t* stop) const { return p < end && (stop ? p < stop : !eoc()); }
+  int peek() const { return p < end ? *p : -1; }
+  // reads tag + length; content length or -1 for the indefinite form
   bool head(int& tag, long& len)
   {
     if (p >= end) return false;
@@ -225,7 +349,7 @@ struct Ber {
     }
     return true;
   }
-  // skips one complete element
+  const uint8_t* stop_of(long len) const { return len >= 0 ? p + len : nullptr; }
   void skip()
   {
     int tag; long len;
@@ -234,158 +358,319 @@ struct Ber {
     while (p < end && !eoc()) skip();
     p += 2;
   }
-  std::string str(long len) { std::string s(reinterpret_cast<const char*>(p), size_t(len)); p += len; return s; }
-  long integer(long len) { long v = 0; for (long i = 0; i < len && p < end; ++i) v = (v << 8) | *p++; return v; }
-  void close(long len) { if (len < 0 && eoc()) p += 2; }
+  // leaves a constructed element entered with head(): to its end, past the end-of-contents octets if indefinite
+  void leave(const uint8_t* stop)
+  {
+    if (stop) { p = stop; return; }
+    while (p < end && !eoc()) skip();
+    p += 2;
+  }
+  std::string str() { int t; long l; if (!head(t, l) || l < 0) return std::string(); std::string s(reinterpret_cast<const char*>(p), size_t(std::min<long>(l, end - p))); p += l; return s; }
+  unsigned long integer() { int t; long l; unsigned long v = 0; if (!head(t, l) || l < 0) return 0; for (long i = 0; i < l && p < end; ++i) v = (v << 8) | *p++; return v; }
+  // [tag] EXPLICIT string / integer if it is the next element
+  bool opt_str(int tag, std::string& out)
+  {
+    if (peek() != tag) return false;
+    int t; long l;
+    head(t, l);
+    const uint8_t* stop = stop_of(l);
+    out = str();
+    leave(stop);
+    return true;
+  }
+  bool opt_int(int tag, unsigned long& out)
+  {
+    if (peek() != tag) return false;
+    int t; long l;
+    head(t, l);
+    const uint8_t* stop = stop_of(l);
+    out = integer();
+    leave(stop);
+    return true;
+  }
 };
 
-std::string object_id(Ber& b)                       // CHOICE { id [0] INTEGER, str [1] VisibleString }
+// Object-id ::= CHOICE { id [0] INTEGER, str [1] VisibleString }  (parse_object_id, asnparse.cc:236-256)
+std::string object_id(Ber& b)
 {
-  int tag; long len;
-  std::string out;
-  if (!b.head(tag, len)) return out;
-  int t2; long l2;
-  if (b.head(t2, l2)) out = (tag == 0xA0) ? std::to_string(b.integer(l2)) : b.str(l2);
-  b.close(len);
-  return out;
+  std::string s;
+  unsigned long v = 0;
+  if (b.opt_str(0xA1, s)) return s;
+  if (b.opt_int(0xA0, v)) return std::to_string(v);
+  return "0";
 }
 
-std::string seq_id(Ber& b)
+// One Seq-id rendered as the reference prints it (parse_seq_id + show_*, asnparse.cc:615-751); empty for a gi
+// when gi's are not shown
+std::string seq_id(Ber& b, bool show_gis)
 {
   static const char* const names[] = {"lcl", "bbs", "bbm", "gim", "gb", "emb", "pir", "sp", "pat", "ref",
                                       "gnl", "gi", "dbj", "prf", "pdb", "tpg", "tpe", "tpd", "gpp", "nat"};
   int tag; long len;
   if (!b.head(tag, len)) return std::string();
+  const uint8_t* stop = b.stop_of(len);
   const int choice = tag - 0xA0;
-  const std::string db = (choice >= 0 && choice < 20) ? names[choice] : "unk";
+  const std::string db = (choice >= 0 && choice < 20) ? names[choice] : "";
   std::string out;
-  const uint8_t* stop = len >= 0 ? b.p + len : nullptr;
-  if (choice == 0) {
-    out = db + "|" + object_id(b);
-  } else if (choice == 11 || choice == 1 || choice == 2 || choice == 3) {
-    int t; long l;
-    if (b.head(t, l)) out = db + "|" + std::to_string(b.integer(l));
-  } else if (choice == 10) {                        // Dbtag { db VisibleString, tag Object-id }
-    int t; long l;
-    if (b.head(t, l)) {                             // SEQUENCE
-      int t1; long l1, l1b; int t1b;
-      std::string dbname, tagv;
-      if (b.head(t1, l1)) { if (b.head(t1b, l1b)) dbname = b.str(l1b); b.close(l1); }
-      if (b.head(t1, l1)) { tagv = object_id(b); b.close(l1); }
-      b.close(l);
-      out = db + "|" + dbname + "|" + tagv;
+  int t; long l;
+  switch (choice) {
+    case 0: out = db + "|" + object_id(b); break;                                   // local
+    case 1: case 2: out = db + "|" + std::to_string(b.integer()); break;            // gibbsq, gibbmt
+    case 3: {                                                                        // giim: SEQUENCE { id, db?, release? }
+      unsigned long id = 0;
+      if (b.head(t, l)) { const uint8_t* s2 = b.stop_of(l); b.opt_int(0xA0, id); b.leave(s2); }
+      out = db + "|" + std::to_string(id);
+      break;
     }
-  } else {                                          // Textseq-id { name, accession, release, version }
-    int t; long l;
-    std::string name, acc;
-    long version = 0;
-    if (b.head(t, l)) {
-      const uint8_t* sstop = l >= 0 ? b.p + l : nullptr;
-      while (b.p < b.end && (sstop ? b.p < sstop : !b.eoc())) {
-        int ft; long fl;
-        if (!b.head(ft, fl)) break;
-        int it; long il;
-        if (!b.head(it, il)) break;
-        if (ft == 0xA0) name = b.str(il);
-        else if (ft == 0xA1) acc = b.str(il);
-        else if (ft == 0xA3) version = b.integer(il);
-        else b.p += il;
-        b.close(fl);
+    case 8: {                                                                        // patent
+      unsigned long seqno = 0;
+      std::string country, number, doctype;
+      bool granted = true;
+      if (b.head(t, l)) {
+        const uint8_t* s2 = b.stop_of(l);
+        b.opt_int(0xA0, seqno);
+        if (b.peek() == 0xA1 && b.head(t, l)) {                                      // cit Id-pat
+          const uint8_t* s3 = b.stop_of(l);
+          if (b.head(t, l)) {
+            const uint8_t* s4 = b.stop_of(l);
+            b.opt_str(0xA0, country);
+            if (b.peek() == 0xA1 && b.head(t, l)) {                                  // id CHOICE { number [0], app-number [1] }
+              const uint8_t* s5 = b.stop_of(l);
+              if (b.opt_str(0xA0, number)) granted = true;
+              else if (b.opt_str(0xA1, number)) granted = false;
+              b.leave(s5);
+            }
+            b.opt_str(0xA2, doctype);
+            b.leave(s4);
+          }
+          b.leave(s3);
+        }
+        b.leave(s2);
       }
-      b.close(l);
+      out = std::string(granted ? "pat" : "pgp") + "|" + country + "|" + number + "|" + std::to_string(seqno);
+      break;
     }
-    out = db + "|" + acc + (version ? "." + std::to_string(version) : std::string()) + "|" + name;
+    case 10: {                                                                       // general: Dbtag { db, tag Object-id }
+      std::string dbname, tagv = "0";
+      if (b.head(t, l)) {
+        const uint8_t* s2 = b.stop_of(l);
+        b.opt_str(0xA0, dbname);
+        if (b.peek() == 0xA1 && b.head(t, l)) { const uint8_t* s3 = b.stop_of(l); tagv = object_id(b); b.leave(s3); }
+        b.leave(s2);
+      }
+      out = db + "|" + dbname + "|" + tagv;
+      break;
+    }
+    case 11: {                                                                       // gi
+      const unsigned long gi = b.integer();
+      if (show_gis) out = db + "|" + std::to_string(gi);
+      break;
+    }
+    case 14: {                                                                       // pdb { mol, chain DEFAULT 32, rel? }
+      std::string mol;
+      unsigned long chain = 32;
+      if (b.head(t, l)) { const uint8_t* s2 = b.stop_of(l); b.opt_str(0xA0, mol); b.opt_int(0xA1, chain); b.leave(s2); }
+      std::string ch;
+      if (chain > 95) { ch += char(chain - 32); ch += char(chain - 32); } else ch += char(chain);   // asnparse.cc:741-744
+      out = db + "|" + mol + "|" + ch;
+      break;
+    }
+    default:                                                                         // Textseq-id
+      if (!db.empty()) {
+        std::string name, acc, release;
+        unsigned long version = 0;
+        if (b.head(t, l)) {
+          const uint8_t* s2 = b.stop_of(l);
+          b.opt_str(0xA0, name); b.opt_str(0xA1, acc); b.opt_str(0xA2, release); b.opt_int(0xA3, version);
+          b.leave(s2);
+        }
+        const std::string shown = (db == "sp" && release == "unreviewed") ? "tr" : db;   // show_seq_id, asnparse.cc:596-604
+        out = shown + "|" + acc + (version ? "." + std::to_string(version) : std::string()) + "|" + name;
+      }
   }
-  if (stop) b.p = stop; else { while (b.p < b.end && !b.eoc()) b.skip(); b.p += 2; }
+  b.leave(stop);
   return out;
 }
 
-// every Blast-def-line of the set (one per identical sequence merged into this entry), each rendered
-// "ids title" as parse_blast_def_line does (asnparse.cc:753-887), joined by '\n'
-std::string all_deflines(const uint8_t* p, size_t n)
+struct DeflineFilter {
+  bool show_gis = false, show_taxid = false;
+  unsigned long memb = 0;                      // the alias's MEMB_BIT, used as a mask (asnparse.cc:990)
+  const BlastDb* db = nullptr;                 // taxid list
+};
+
+// every Blast-def-line of the set that passes the membership / taxid filter (parse_blast_def_line_set_new,
+// asnparse.cc:970-1013), each rendered "ids[|taxid|..] title" (parse_blast_def_line, 753-887), joined by '\n'.
+// *count = number of passing lines.
+std::string render_deflines(const uint8_t* p, size_t n, const DeflineFilter& f, long* count)
 {
   Ber b{p, p + n};
   int tag; long len;
   std::string out;
+  long passed = 0;
+  if (count) *count = 0;
   if (!b.head(tag, len) || tag != 0x30) return out;                   // Blast-def-line-set
-  const uint8_t* set_stop = len >= 0 ? b.p + len : nullptr;
-  bool first = true;
-  while (b.p < b.end && (set_stop ? b.p < set_stop : !b.eoc())) {
+  const uint8_t* set_stop = b.stop_of(len);
+  while (b.more(set_stop)) {
     int t2; long l2;
     if (!b.head(t2, l2) || t2 != 0x30) break;                          // one Blast-def-line
-    std::string title, ids;
-    const uint8_t* stop = l2 >= 0 ? b.p + l2 : nullptr;
-    while (b.p < b.end && (stop ? b.p < stop : !b.eoc())) {
-      int ft; long fl;
-      if (!b.head(ft, fl)) break;
-      if (ft == 0xA0) {                                                // title
-        int it; long il;
-        if (b.head(it, il)) title = b.str(il);
-        b.close(fl);
-      } else if (ft == 0xA1) {                                         // seqid SEQUENCE OF Seq-id
-        int st; long sl;
-        if (b.head(st, sl)) {
-          const uint8_t* sstop = sl >= 0 ? b.p + sl : nullptr;
-          while (b.p < b.end && (sstop ? b.p < sstop : !b.eoc())) {
-            const std::string id = seq_id(b);
-            if (!ids.empty()) ids += "|";
-            ids += id;
-          }
-          b.close(sl);
+    const uint8_t* stop = b.stop_of(l2);
+    std::string title = "unnamed protein product", ids;               // asnparse.cc:768
+    unsigned long taxid = 0, memb = 0, links = 0;
+    b.opt_str(0xA0, title);
+    int t; long l;
+    if (b.peek() == 0xA1 && b.head(t, l)) {                            // seqid SEQUENCE OF Seq-id
+      const uint8_t* s1 = b.stop_of(l);
+      if (b.head(t, l)) {
+        const uint8_t* s2 = b.stop_of(l);
+        while (b.more(s2)) {
+          const std::string id = seq_id(b, f.show_gis);
+          if (!ids.empty()) ids += "|";                                // asnparse.cc:793-796: even before an empty id
+          ids += id;
         }
-        b.close(fl);
-      } else {
-        if (fl >= 0) b.p += fl; else { while (b.p < b.end && !b.eoc()) b.skip(); b.p += 2; }
+        b.leave(s2);
       }
+      b.leave(s1);
     }
-    b.close(l2);
-    if (!first) out += '\n';
-    first = false;
-    out += ids + ((ids.empty() || title.empty()) ? "" : " ") + title;
+    b.opt_int(0xA2, taxid);
+    for (int which = 0; which < 2; ++which) {                          // memberships [3], links [4]: SEQUENCE OF INTEGER, last wins
+      if (b.peek() != 0xA3 + which || !b.head(t, l)) continue;
+      const uint8_t* s1 = b.stop_of(l);
+      if (b.head(t, l)) {
+        const uint8_t* s2 = b.stop_of(l);
+        while (b.more(s2)) (which ? links : memb) = b.integer();
+        b.leave(s2);
+      }
+      b.leave(s1);
+    }
+    b.leave(stop);
+    if (f.db && !f.db->taxid_ok(taxid)) continue;
+    if ((memb & f.memb) != f.memb) continue;
+    std::string line = ids;
+    if (f.show_taxid) {                                                // asnparse.cc:859-878
+      if (taxid) line += "|taxid|" + std::to_string(taxid);
+      if (links) line += "|link|" + std::to_string(links);
+      if (memb) line += "|memb|" + std::to_string(memb);
+    }
+    if (!line.empty() && !title.empty()) line += " ";
+    line += title;
+    if (passed++) out += '\n';
+    out += line;
   }
+  if (count) *count = passed;
   return out;
 }
 }  // namespace
 
+struct swa_headers {
+  BlastDb db;
+};
+
+extern "C" int swa_headers_open(const char* basename, int symtype, const char* taxidfile, swa_headers** out)
+{
+  if (!out) return swa::fail(SWA_EINVAL, "null output handle");
+  *out = nullptr;
+  swa_headers* h = new (std::nothrow) swa_headers;
+  if (!h) return swa::fail(SWA_ENOMEM, "out of host memory");
+  const int rc = h->db.open(basename, symtype, taxidfile, true);
+  if (rc != SWA_OK) { delete h; return rc; }
+  *out = h;
+  return SWA_OK;
+}
+
+extern "C" void swa_headers_close(swa_headers* h) { delete h; }
+
+extern "C" int swa_headers_info(const swa_headers* h, int64_t* seqcount, int64_t* symcount, int64_t* masked_seqcount,
+                                int64_t* masked_symcount, int64_t* longest, char* title, int64_t title_cap)
+{
+  if (!h) return swa::fail(SWA_EINVAL, "null handle");
+  if (seqcount) *seqcount = h->db.nseq;
+  if (symcount) *symcount = h->db.nsym;
+  if (masked_seqcount) *masked_seqcount = h->db.masked_nseq;
+  if (masked_symcount) *masked_symcount = h->db.masked_nsym;
+  if (longest) *longest = h->db.longest;
+  if (title && title_cap > 0) std::snprintf(title, size_t(title_cap), "%s", h->db.title.c_str());
+  return SWA_OK;
+}
+
+namespace {
+int header_bytes(const swa_headers* h, int64_t seqno, const uint8_t** p, size_t* n, size_t* vol, int64_t* local)
+{
+  if (!h->db.locate(seqno, vol, local)) return swa::fail(SWA_EINVAL, "Cant find database volume.");
+  const Volume& v = h->db.vols[*vol];
+  const uint64_t h1 = be32(v.hdr_off + 4 * *local), h2 = be32(v.hdr_off + 4 * (*local + 1));
+  if (h2 < h1 || h2 > v.hdr.n) return swa::fail(SWA_EIO, "corrupt header offsets in " + v.base);
+  *p = v.hdr.p + h1;
+  *n = size_t(h2 - h1);
+  return SWA_OK;
+}
+}  // namespace
+
+extern "C" int swa_headers_get(const swa_headers* h, int64_t seqno, int flags, char* buf, int64_t buflen, int64_t* needed)
+{
+  if (!h || buflen < 0 || (buflen > 0 && !buf) || !needed) return swa::fail(SWA_EINVAL, "bad argument");
+  const uint8_t* p; size_t n, vol; int64_t local;
+  const int rc = header_bytes(h, seqno, &p, &n, &vol, &local);
+  if (rc != SWA_OK) return rc;
+  DeflineFilter f;
+  f.show_gis = flags & SWA_HEADERS_SHOW_GIS;
+  f.show_taxid = flags & SWA_HEADERS_SHOW_TAXID;
+  f.memb = (unsigned long)h->db.memb_bit;
+  f.db = &h->db;
+  const std::string d = render_deflines(p, n, f, nullptr);
+  *needed = int64_t(d.size()) + 1;
+  if (*needed > buflen) return swa::fail(SWA_ERANGE, "defline buffer too small");
+  std::memcpy(buf, d.c_str(), d.size() + 1);
+  return SWA_OK;
+}
+
+// db_check_inclusion (database.cc:1465-1481) for the sequences [first_seqno, first_seqno + n)
+extern "C" int swa_headers_inclusion(const swa_headers* h, int64_t first_seqno, int64_t n, uint8_t* include)
+{
+  if (!h || n < 0 || (n > 0 && !include)) return swa::fail(SWA_EINVAL, "bad argument");
+  DeflineFilter f;
+  f.memb = (unsigned long)h->db.memb_bit;
+  f.db = &h->db;
+  for (int64_t i = 0; i < n; ++i) {
+    const uint8_t* p; size_t len, vol; int64_t local;
+    const int rc = header_bytes(h, first_seqno + i, &p, &len, &vol, &local);
+    if (rc != SWA_OK) return rc;
+    bool ok = h->db.in_mask(vol, local);
+    if (ok && h->db.have_taxids) {
+      long count = 0;
+      render_deflines(p, len, f, &count);
+      ok = count > 0;
+    }
+    include[i] = ok ? 1 : 0;
+  }
+  return SWA_OK;
+}
+
 int swa::read_blast_deflines(const char* basename, int symtype, const std::vector<int64_t>& seqnos,
                              std::vector<std::string>& deflines, std::vector<int64_t>& lengths)
 {
-  const bool protein = symtype == SWA_SYMTYPE_PROTEIN;
-  const std::string base(basename);
-  std::vector<std::string> vols;
-  const std::vector<std::string> top = read_alias(base, protein, nullptr);
-  if (top.empty()) vols.push_back(base);
-  else {
-    const std::string dir = dir_of(base);
-    for (const std::string& n : top) {
-      const std::vector<std::string> nested = read_alias(dir + n, protein, nullptr);
-      if (nested.empty()) vols.push_back(dir + n);
-      else for (const std::string& m : nested) vols.push_back(dir + m);
-    }
-  }
-  std::vector<Volume> V(vols.size());
-  std::string err;
-  for (size_t i = 0; i < vols.size(); ++i) {
-    if (!open_volume(vols[i], protein, V[i], err)) return fail(SWA_EIO, err);
-    if (!V[i].hdr.open(vols[i] + (protein ? ".phr" : ".nhr"))) return fail(SWA_EIO, "Unable to open file " + vols[i] + (protein ? ".phr." : ".nhr."));
-  }
+  swa_headers* h = nullptr;
+  int rc = swa_headers_open(basename, symtype, nullptr, &h);
+  if (rc != SWA_OK) return rc;
   deflines.clear();
   lengths.clear();
+  DeflineFilter f;
+  f.memb = (unsigned long)h->db.memb_bit;
+  f.db = &h->db;
+  const bool protein = h->db.protein;
   for (int64_t s : seqnos) {
-    int64_t local = s;
-    const Volume* v = nullptr;
-    for (const Volume& x : V) { if (local < x.nseq) { v = &x; break; } local -= x.nseq; }
-    if (!v || local < 0) return fail(SWA_EINVAL, "Cant find database volume.");
-    const uint64_t h1 = be32(v->hdr_off + 4 * local), h2 = be32(v->hdr_off + 4 * (local + 1));
-    if (h2 < h1 || h2 > v->hdr.n) return fail(SWA_EIO, "corrupt header offsets in " + v->base);
-    deflines.push_back(all_deflines(v->hdr.p + h1, size_t(h2 - h1)));
-    const uint64_t o1 = be32(v->seq_off + 4 * local), o2 = be32(v->seq_off + 4 * (local + 1));
+    const uint8_t* p; size_t n, vol; int64_t local;
+    rc = header_bytes(h, s, &p, &n, &vol, &local);
+    if (rc != SWA_OK) break;
+    deflines.push_back(render_deflines(p, n, f, nullptr));
+    const Volume& v = h->db.vols[vol];
+    const uint64_t o1 = be32(v.seq_off + 4 * local), o2 = be32(v.seq_off + 4 * (local + 1));
     if (protein) lengths.push_back(o2 > o1 ? int64_t(o2 - o1 - 1) : 0);
     else {
-      const uint64_t o3 = be32(v->amb_off + 4 * local);
+      const uint64_t o3 = be32(v.amb_off + 4 * local);
       const size_t packed = size_t(o3 - o1);
-      lengths.push_back(int64_t(4 * (packed - 1) + (v->seq.p[o1 + packed - 1] & 3)));
+      lengths.push_back(int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3)));
     }
   }
-  return SWA_OK;
+  swa_headers_close(h);
+  return rc;
 }

@@ -263,6 +263,9 @@ void usage(const char* prog)
   std::printf("  -a, --num_threads=NUM      accepted and ignored (one GPU)\n");
   std::printf("  -m, --outfmt=NUM           output format [0,7-9=plain,xml,tsv,tsv+] (0)\n");
   std::printf("  -p, --symtype=NAME/NUM     symbol type/translation [0-4] (1)\n");
+  std::printf("  -I, --show_gis             show gi numbers in results (no)\n");
+  std::printf("  -H, --show_taxid           show taxid etc in results (no)\n");
+  std::printf("  -x, --taxidlist=FILE       taxid list filename (none)\n");
   std::printf("  -Q, --query_gencode=NUM    query genetic code [1-23] (1)\n");
   std::printf("  -D, --db_gencode=NUM       database genetic code [1-23] (1)\n");
   std::printf("  -S, --strand=NAME/NUM      query strands to search [1-3] (3)\n");
@@ -274,7 +277,8 @@ void usage(const char* prog)
 
 int main(int argc, char** argv)
 {
-  std::string dbname, queryname = "-", matrixname, outfile;
+  std::string dbname, queryname = "-", matrixname, outfile, taxidfile;
+  bool show_gis = false, show_taxid = false;
   long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
   long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100, query_gencode = 1, db_gencode = 1;
   double expect = 10.0, minexpect = 0.0;
@@ -283,10 +287,11 @@ int main(int argc, char** argv)
       {"gapopen", 1, 0, 'G'}, {"gapextend", 1, 0, 'E'}, {"num_descriptions", 1, 0, 'v'}, {"num_alignments", 1, 0, 'b'},
       {"evalue", 1, 0, 'e'}, {"minevalue", 1, 0, 'k'}, {"min_score", 1, 0, 'c'}, {"max_score", 1, 0, 'u'},
       {"num_threads", 1, 0, 'a'}, {"outfmt", 1, 0, 'm'}, {"symtype", 1, 0, 'p'}, {"strand", 1, 0, 'S'}, {"out", 1, 0, 'o'},
-      {"dbsize", 1, 0, 'z'}, {"gpu", 1, 0, 'g'}, {"query_gencode", 1, 0, 'Q'}, {"db_gencode", 1, 0, 'D'}, {"help", 0, 0, 'h'},
+      {"dbsize", 1, 0, 'z'}, {"gpu", 1, 0, 'g'}, {"query_gencode", 1, 0, 'Q'}, {"db_gencode", 1, 0, 'D'}, {"show_gis", 0, 0, 'I'},
+      {"show_taxid", 0, 0, 'H'}, {"taxidlist", 1, 0, 'x'}, {"help", 0, 0, 'h'},
       {0, 0, 0, 0}};
   int c;
-  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:Q:D:h", longopts, nullptr)) != -1) {
+  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:Q:D:IHx:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'd': dbname = optarg; break;
       case 'i': queryname = optarg; break;
@@ -306,6 +311,9 @@ int main(int argc, char** argv)
       case 'o': outfile = optarg; break;
       case 'z': effdbsize = std::atol(optarg); break;
       case 'g': device = std::atol(optarg); break;
+      case 'I': show_gis = true; break;
+      case 'H': show_taxid = true; break;
+      case 'x': taxidfile = optarg; break;
       case 'Q': query_gencode = std::atol(optarg); break;
       case 'D': db_gencode = std::atol(optarg); break;
       case 'S':
@@ -371,6 +379,18 @@ int main(int argc, char** argv)
   check(swa_db_info(db, &info));
   check(swa_set_scoring(db, M, gapopen + gapextend, gapextend));
   const int db_filetype = db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN;
+  // definition lines, the alias's OID mask (applied by swa_db_open) and the -x taxid list (applied here):
+  // db_check_inclusion, database.cc:1465-1481
+  swa_headers* headers = nullptr;
+  check(swa_headers_open(dbname.c_str(), db_filetype, taxidfile.empty() ? nullptr : taxidfile.c_str(), &headers));
+  if (!taxidfile.empty()) {
+    std::vector<uint8_t> include(size_t(info.seqcount > 0 ? info.seqcount : 1));
+    check(swa_headers_inclusion(headers, info.first_seqno, info.seqcount, include.data()));
+    check(swa_db_set_inclusion(db, include.data(), info.seqcount));
+  }
+  char dbtitle[1024] = "";
+  check(swa_headers_info(headers, nullptr, nullptr, nullptr, nullptr, nullptr, dbtitle, sizeof dbtitle));
+  const int hflags = (show_gis ? SWA_HEADERS_SHOW_GIS : 0) | (show_taxid ? SWA_HEADERS_SHOW_TAXID : 0);
 
   FILE* qf = queryname == "-" ? stdin : std::fopen(queryname.c_str(), "r");
   if (!qf) fatal("Cannot open query file.");
@@ -414,7 +434,7 @@ int main(int argc, char** argv)
     int64_t keep = std::max(maxmatches, alignments);                   // hits.cc:287-315
     const int64_t per_seq = symtype == 0 ? (strands == 3 ? 2 : 1) : symtype == 2 ? (strands == 3 ? 6 : 3)
                             : symtype == 3 ? 6 : symtype == 4 ? (strands == 3 ? 36 : 18) : 1;
-    keep = std::min(keep, info.seqcount * per_seq);
+    keep = std::min(keep, info.total_seqcount * per_seq);             // db_getseqcount_masked()
     swa_stats_t st;
     check(swa_stats_init(int(symtype), matrixname.c_str(), match, mismatch, gapopen, gapextend, qlen,
                          info.total_seqcount, info.total_symcount, effdbsize, minscore, maxscore, minexpect, expect, &st));
@@ -435,18 +455,23 @@ int main(int argc, char** argv)
 
     const int64_t showhits = std::min<int64_t>(nhits, maxmatches);       // hits_show, hits.cc:1996-2004
     const int64_t showalignments = std::min<int64_t>(nhits, alignments);
-    std::vector<std::string> deflines;
-    for (int64_t i = 0; i < nhits; ++i) {
-      std::vector<char> buf(4096);
-      int64_t need = 0;
-      int rc = swa_blastdb_deflines(dbname.c_str(), db_filetype, hits[size_t(i)].seqno, buf.data(), int64_t(buf.size()), &need);
-      if (rc == SWA_ERANGE) {
-        buf.resize(size_t(need));
-        rc = swa_blastdb_deflines(dbname.c_str(), db_filetype, hits[size_t(i)].seqno, buf.data(), int64_t(buf.size()), &need);
+    // hit lists, XML names and alignment headers follow -I; the tab-separated views always show gi's (hits.cc:1753)
+    auto fetch_deflines = [&](int flags) {
+      std::vector<std::string> d;
+      for (int64_t i = 0; i < nhits; ++i) {
+        std::vector<char> buf(4096);
+        int64_t need = 0;
+        int rc = swa_headers_get(headers, hits[size_t(i)].seqno, flags, buf.data(), int64_t(buf.size()), &need);
+        if (rc == SWA_ERANGE) {
+          buf.resize(size_t(need));
+          rc = swa_headers_get(headers, hits[size_t(i)].seqno, flags, buf.data(), int64_t(buf.size()), &need);
+        }
+        check(rc);
+        d.push_back(buf.data());
       }
-      check(rc);
-      deflines.push_back(buf.data());
-    }
+      return d;
+    };
+    const std::vector<std::string> deflines = fetch_deflines((view == 8 || view == 9) ? (hflags | SWA_HEADERS_SHOW_GIS) : hflags);
 
     // alignment phase (align_chunk, swipe.cc:339-414): hits grouped by query frame; nucleotide searches always
     // align the PLUS query, minus-strand hits against the reverse-complemented database sequence
@@ -542,6 +567,7 @@ int main(int argc, char** argv)
     } else {                                                          // args_show + hits_show_plain
       static const char* const symnames[] = {"Nucleotide", "Amino acid", "Translated query", "Translated database", "Both translated"};
       std::fprintf(out, "Database file:     %s\n", dbname.c_str());
+      std::fprintf(out, "Database title:    %s\n", dbtitle);
       std::fprintf(out, "Database size:     %ld residues in %ld sequences\n", long(info.total_symcount), long(info.total_seqcount));
       std::fprintf(out, "Longest db seq:    %ld residues\n", long(info.longest));
       std::fprintf(out, "Query file name:   %s\n", queryname.c_str());
@@ -613,6 +639,7 @@ int main(int argc, char** argv)
     }
   }
   if (qf != stdin) std::fclose(qf);
+  swa_headers_close(headers);
   swa_db_close(db);
   if (out != stdout) std::fclose(out);
   return 0;

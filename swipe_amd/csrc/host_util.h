@@ -17,6 +17,11 @@ struct HostDb {
   int64_t first_seqno = 0;
   int64_t total_seqcount = 0, total_symcount = 0, longest = 0;
   std::string title;
+  // OID mask of a masked alias (database.cc:687-706): included[s] per loaded sequence, and the alias's own
+  // NSEQ / LENGTH, which the reference uses for statistics instead of the volume totals (hits.cc:333-342)
+  bool masked = false;
+  std::vector<uint8_t> included;
+  int64_t masked_seqcount = 0, masked_symcount = 0;
 };
 // Mirrors db_open (alias + volumes, database.cc:775-925) and db_getsequence
 // (database.cc:1237-1401) for symtype 0 and 1.  Returns SWA_OK or records an error.

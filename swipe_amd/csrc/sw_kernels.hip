@@ -520,6 +520,18 @@ extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* 
   hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
   return hipGetLastError();
 }
+// excluded sequences (OID mask / taxid filter) report -1 so that no score threshold >= 0 ever accepts them
+extern "C" __global__ void swa_mark_excluded(int* __restrict__ scores, const int* __restrict__ ids, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scores[ids[i]] = -1;
+}
+extern "C" hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swa_mark_excluded, dim3((n + 255) / 256), dim3(256), 0, st, scores, ids, n);
+  return hipGetLastError();
+}
 extern "C" hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                            const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st)
 {

@@ -29,6 +29,7 @@ int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
                                 const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                 long long* Hs, long long* Es, long long* out, hipStream_t st);
+hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
 hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
@@ -101,6 +102,9 @@ struct swa_db {
   // index 6 * (seqno - first_seqno) + 3 * dstrand + dframe; nseq / nsym / h_offsets then describe the
   // virtual sequences, nt_* the nucleotide sequences they came from
   int frames = 1;
+  // sequences left out by an OID mask / taxid list (swa_db_set_inclusion): not in any batch, score -1
+  DevBuf<int32_t> excluded;
+  int64_t n_excluded = 0, active_sym = 0;
   std::vector<int64_t> h_ntlen;
   int64_t nt_sym = 0, nt_longest = 0;
   std::vector<int64_t> h_offsets;
@@ -238,6 +242,7 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   const int64_t base = db->h_offsets[0];
   for (int64_t& o : db->h_offsets) o -= base;
   db->nsym = db->h_offsets[size_t(nseq)];
+  db->active_sym = db->nsym;
   db->longest = 0;
   for (int64_t s = 0; s < nseq; ++s) {
     const int64_t len = db->h_offsets[s + 1] - db->h_offsets[s];
@@ -278,7 +283,7 @@ uint32_t f16_pair(float v)
 int ensure_single(swa_db* db)
 {
   if (db->single_built) return SWA_OK;
-  const int rc = build_batches(db, db->h_order.data(), db->nseq, 1, db->single);
+  const int rc = build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 1, db->single);
   if (rc == SWA_OK) db->single_built = true;
   return rc;
 }
@@ -440,7 +445,9 @@ int finish_empty(swa_db* db, swa_counters_t& c, swa_counters_t* counters, bool t
     if (two) {
       HIP_TRY(db->scores2.reserve(size_t(db->nseq)));
       HIP_TRY(hipMemsetAsync(db->scores2.p, 0, size_t(db->nseq) * sizeof(int32_t), st));
+      HIP_TRY(swa_launch_mark_excluded(db->scores2.p, db->excluded.p, int(db->n_excluded), st));
     }
+    HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   }
   HIP_TRY(hipStreamSynchronize(st));
   if (counters) *counters = c;
@@ -455,8 +462,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
   swa_counters_t c{};
-  c.cells = db->nsym * qlen;
-  if (qlen == 0 || db->nseq == 0) return finish_empty(db, c, counters, false, st);
+  c.cells = db->active_sym * qlen;
+  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, c, counters, false, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
   HIP_TRY(db->qseq.reserve(size_t(qlen)));
   HIP_TRY(hipMemcpyAsync(db->qseq.p, query, size_t(qlen), hipMemcpyHostToDevice, st));
@@ -536,6 +543,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   }
   rc = run_wide(db, requeue, db->qseq.p, qlen, db->scores.p, &c.wide, &c.full, st);
   if (rc != SWA_OK) return rc;
+  HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(hipEventRecord(db->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));
   float ms = 0;
@@ -558,8 +566,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
   swa_counters_t c{};
-  c.cells = 2 * db->nsym * qlen;
-  if (qlen == 0 || db->nseq == 0) return finish_empty(db, c, counters, true, st);
+  c.cells = 2 * db->active_sym * qlen;
+  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, c, counters, true, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
   HIP_TRY(db->qseq.reserve(size_t(qlen)));
   HIP_TRY(db->qseq2.reserve(size_t(qlen)));
@@ -602,7 +610,9 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   rc = run_wide(db, rq1, db->qseq.p, qlen, db->scores.p, &c.wide, &c.full, st);
   if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2.p, qlen, db->scores2.p, &c.wide, &full2, st);
   if (rc != SWA_OK) return rc;
-  if (full2) return fail(SWA_EINVAL, "second query needs the 64-bit kernel; search the two queries separately");
+  if (full2) return fail(SWA_ERANGE, "second query needs the 64-bit kernel; search the two queries separately");
+  HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
+  HIP_TRY(swa_launch_mark_excluded(db->scores2.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(hipEventRecord(db->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));
   float ms = 0;
@@ -661,10 +671,17 @@ extern "C" int swa_db_open(const char* basename, int symtype, int device, int64_
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   swa::HostDb h;
-  const int rc = swa::read_blast_db(basename, symtype, first_seqno, last_seqno, h);
+  int rc = swa::read_blast_db(basename, symtype, first_seqno, last_seqno, h);
   if (rc != SWA_OK) return rc;
-  return swa_db_from_memory(h.residues.data(), h.offsets.data(), int64_t(h.offsets.size()) - 1, symtype, device,
-                            h.first_seqno, h.total_seqcount, h.total_symcount, out);
+  // a masked alias searches only its members and computes statistics on its own NSEQ / LENGTH (hits.cc:333-342)
+  rc = swa_db_from_memory(h.residues.data(), h.offsets.data(), int64_t(h.offsets.size()) - 1, symtype, device,
+                          h.first_seqno, h.masked ? h.masked_seqcount : h.total_seqcount,
+                          h.masked ? h.masked_symcount : h.total_symcount, out);
+  if (rc == SWA_OK && h.masked) {
+    rc = swa_db_set_inclusion(*out, h.included.data(), int64_t(h.included.size()));
+    if (rc != SWA_OK) { swa_db_close(*out); *out = nullptr; }
+  }
+  return rc;
 }
 
 extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
@@ -745,10 +762,16 @@ extern "C" int swa_db_open_translated(const char* basename, int db_gencode, int 
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   swa::HostDb h;
-  const int rc = swa::read_blast_db(basename, SWA_SYMTYPE_NUCLEOTIDE, first_seqno, last_seqno, h);
+  int rc = swa::read_blast_db(basename, SWA_SYMTYPE_NUCLEOTIDE, first_seqno, last_seqno, h);
   if (rc != SWA_OK) return rc;
-  return swa_db_from_memory_translated(h.residues.data(), h.offsets.data(), int64_t(h.offsets.size()) - 1, db_gencode,
-                                       device, h.first_seqno, h.total_seqcount, h.total_symcount, out);
+  rc = swa_db_from_memory_translated(h.residues.data(), h.offsets.data(), int64_t(h.offsets.size()) - 1, db_gencode,
+                                     device, h.first_seqno, h.masked ? h.masked_seqcount : h.total_seqcount,
+                                     h.masked ? h.masked_symcount : h.total_symcount, out);
+  if (rc == SWA_OK && h.masked) {
+    rc = swa_db_set_inclusion(*out, h.included.data(), int64_t(h.included.size()));
+    if (rc != SWA_OK) { swa_db_close(*out); *out = nullptr; }
+  }
+  return rc;
 }
 
 extern "C" int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
@@ -810,6 +833,30 @@ extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
   info->total_symcount = db->total_sym;
   info->hbm_bytes = int64_t(db->hbm_bytes());
   return SWA_OK;
+}
+
+extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t n)
+{
+  if (!db) return fail(SWA_EINVAL, "null database handle");
+  const int64_t real = db->nseq / db->frames;
+  if (include && n != real) return fail(SWA_EINVAL, "inclusion array must have one entry per sequence of the shard");
+  HIP_TRY(hipSetDevice(db->device));
+  std::vector<int32_t> in, ex;
+  db->active_sym = 0;
+  for (int64_t v = 0; v < db->nseq; ++v) {
+    if (!include || include[v / db->frames]) {
+      in.push_back(int32_t(v));
+      db->active_sym += db->h_offsets[size_t(v) + 1] - db->h_offsets[size_t(v)];
+    } else {
+      ex.push_back(int32_t(v));
+    }
+  }
+  order_by_length(db->h_offsets, in.data(), int64_t(in.size()), db->h_order);
+  db->n_excluded = int64_t(ex.size());
+  HIP_TRY(db->excluded.reserve(ex.size()));
+  if (!ex.empty()) HIP_TRY(hipMemcpy(db->excluded.p, ex.data(), ex.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  db->single_built = false;
+  return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 2, db->main);
 }
 
 extern "C" void swa_db_close(swa_db* db)
@@ -1007,8 +1054,12 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
   // frames of equal length share a pass in the two halves of the packed lanes
   for (int i = 0; i < nq;) {
     swa_counters_t c{};
-    const bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
+    bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
     int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c) : run_search(db, queries[i], qlens[i], &c);
+    if (pair && rc == SWA_ERANGE) {          // scores beyond 32 bits in the second half: one frame at a time
+      pair = false;
+      rc = run_search(db, queries[i], qlens[i], &c);
+    }
     if (rc != SWA_OK) return rc;
     if (db->nseq) {
       rc = collect_candidates(db, db->scores.p, i, keep, minscore, maxscore, cand, &tot, &obv);

@@ -194,12 +194,54 @@ def case_tblastx() -> Case:
     return Case("tblastx", False, seqs, q, keep=40, symtype=4, query_gencode=1, db_gencode=2)
 
 
+def case_headers() -> Case:
+    """Real-database header features: every Seq-id flavour the reference renders, several
+    definition lines per entry, missing titles, taxids / membership bits / links, an OID mask behind an alias
+    (as NCBI ships swissprot) and a taxid list."""
+    ltab, rtab = synth.length_table(), synth.residue_table_protein()
+    seqs = [synth.make_sequence(6, s, ltab, rtab, None)[:300] for s in range(48)]
+    frag = [Q375[20 * k: 20 * k + 150] for k in range(12)]
+    seqs += frag
+    n = len(seqs)
+    flavours = [
+        lambda i: [("gi", 1000 + i), ("sp", "P%05d" % i, "PROT%d_HUMAN" % i, 2)],
+        lambda i: [("gi", 2000 + i), ("ref", "NP_%06d" % i, "", 1)],
+        lambda i: [("gb", "AAA%05d" % i, "", 3)],
+        lambda i: [("emb", "CAA%05d" % i, "LOCUS%d" % i)],
+        lambda i: [("pdb", "1AB%d" % (i % 10), 65 + i % 26)],
+        lambda i: [("pdb", "2XY%d" % (i % 10), 97 + i % 26)],      # lower-case chain -> doubled upper case
+        lambda i: [("gnl", "mydb", "tag%d" % i)],
+        lambda i: [("gnl", "BL_ORD_ID", i)],
+        lambda i: [("lcl", i)],
+        lambda i: [("pat", "US", "650%04d" % i, i % 7 + 1, True)],
+        lambda i: [("pat", "EP", "11%04d" % i, 2, False)],
+        lambda i: [("sp", "Q%05d" % i, "UNREV%d" % i, 0, "unreviewed")],
+        lambda i: [("bbs", 70000 + i)],
+        lambda i: [("gim", 5 + i)],
+        lambda i: [("dbj", "BAA%05d" % i, "", 1), ("gi", 3000 + i)],
+        lambda i: [("pir", "", "S%05d" % i)],
+    ]
+    headers = []
+    for i in range(n):
+        ids = flavours[i % len(flavours)](i)
+        d = dict(title=None if i % 11 == 5 else "protein number %d with a description long enough to be cut in the hit list and wrapped above the alignment, repeated: protein number %d" % (i, i) if i % 5 == 0 else "protein %d" % i,
+                 ids=ids, taxid=9600 + i % 7, memb=(1 if i % 2 == 0 else 2) if i % 3 else None, links=4 if i % 13 == 0 else None)
+        entry = [d]
+        if i % 4 == 1:        # a second, merged definition line with another taxid and membership
+            entry.append(dict(title="identical twin of %d" % i, ids=[("gi", 9000 + i), ("gb", "TWIN%04d" % i, "", 1)],
+                              taxid=9700 + i % 3, memb=1))
+        headers.append(entry)
+    include = [any(((d.get("memb") or 0) & 1) == 1 for d in h) for h in headers]
+    extra = dict(headers=headers, include=include, taxids=[9601, 9603, 9700, 12345])
+    return Case("headers", True, seqs, Q375, keep=30, extra=extra)
+
+
 ALL = [case_p1k, case_edges, case_limit16, case_asym, case_nt, case_multivol]
 TRANSLATED = [case_blastx, case_tblastn, case_tblastx]
 
 
 def get(name: str) -> Case:
-    for f in ALL + TRANSLATED:
+    for f in ALL + TRANSLATED + [case_headers]:
         if f.__name__ == "case_" + name:
             return f()
     raise KeyError(name)

@@ -492,6 +492,55 @@ def test_translated_cli_output_equals_reference_cli(tmp_path, name):
     assert plain[plain.index("Sequences producing"):] == g["plain_align"]
 
 
+@pytest.mark.parametrize("variant", ["plain", "plain_gis", "plain_taxid", "plain_gis_taxid", "masked", "masked_gis_taxid",
+                                     "taxlist", "taxlist_gis_taxid", "masked_taxlist"])
+def test_cli_real_database_features_equal_reference_cli(tmp_path, variant):
+    """an OID-mask alias (searches only members, statistics on the alias's NSEQ/LENGTH), a
+    -x taxid list, -I / -H rendering of every Seq-id flavour and merged definition lines - output of
+    -m 0 / 7 / 8 byte for byte against the reference CLI."""
+    import subprocess
+    from conftest import ROOT
+    from test_host_cpu import build_headers_db, HEADER_VARIANTS
+    case, vol, masked, tx = build_headers_db(tmp_path)
+    ref = load_golden("headers")["variants"][variant]
+    dbn, flags, taxlist = HEADER_VARIANTS[variant]
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(blastdb.NCBISTDAA[c] for c in case.query) + "\n")
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    args = [exe, "-d", vol if dbn == "vol" else masked, "-i", qf, "-v", str(case.keep), "-e", "1e6"]
+    args += (["-I"] if flags & 1 else []) + (["-H"] if flags & 2 else []) + (["-x", tx] if taxlist else [])
+    run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
+    assert run(["-m", "7", "-b", "5"]) == ref["m7"]
+    assert run(["-m", "8", "-b", str(case.keep)]) == ref["m8"]
+    plain = run(["-m", "0", "-b", "5"])
+    assert plain[plain.index("Sequences producing"):] == ref["m0"]
+    for line in ref["db_lines"]:
+        assert line in plain.splitlines()
+
+
+def test_inclusion_subset_scores(tmp_path):
+    """swa_db_set_inclusion: excluded sequences are skipped (score -1), the rest score as before, and the
+    subset can be changed and lifted again."""
+    case = cases.get("p1k")
+    db = open_case(case)
+    full, _ = db.search(case.query)
+    inc = (np.arange(len(case.seqs)) % 3 != 1).astype(np.uint8)
+    db.set_inclusion(inc)
+    part, c = db.search(case.query)
+    assert np.array_equal(part[inc == 1], full[inc == 1]) and np.all(part[inc == 0] == -1)
+    assert c["cells"] == len(case.query) * sum(len(s) for s, k in zip(case.seqs, inc) if k)
+    hits, tot, obv, _ = db.search_topk(case.query, keep=50, minscore=30)
+    want = sorted([(int(full[i]), i) for i in range(len(full)) if inc[i] and full[i] >= 30], reverse=True)[:50]
+    assert [(h[1], h[0]) for h in hits] == want and tot == sum(1 for i in range(len(full)) if inc[i] and full[i] >= 30)
+    db.set_inclusion(np.zeros(len(case.seqs), np.uint8))
+    none, _ = db.search(case.query)
+    assert np.all(none == -1)
+    db.set_inclusion(None)
+    again, _ = db.search(case.query)
+    assert np.array_equal(again, full)
+    db.close()
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     import subprocess
     from conftest import ROOT

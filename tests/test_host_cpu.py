@@ -236,3 +236,54 @@ def test_translated_statistics_equal_oracle_and_cli(name):
     cli = g["cli"]["1"]
     assert ["%.2g" % st.evalue(s) for s in cli["score"]] == cli["evalue"]
     assert ["%.1f" % st.bits(s) for s in cli["score"]] == cli["bits"]
+
+
+def build_headers_db(tmp_path):
+    case = cases.get("headers")
+    vol = str(tmp_path / "vol")
+    blastdb.write_volume(vol, case.seqs, protein=True, headers=case.extra["headers"], title="headers volume")
+    inc = case.extra["include"]
+    length = int(sum(len(s) for s, k in zip(case.seqs, inc) if k))
+    blastdb.write_mask_alias(str(tmp_path / "masked"), vol, inc, memb_bit=1, length=length, title="masked subset")
+    tx = str(tmp_path / "taxids.txt")
+    open(tx, "w").write("".join("%d\n" % t for t in case.extra["taxids"]))
+    return case, vol, str(tmp_path / "masked"), tx
+
+
+HEADER_VARIANTS = {"plain": ("vol", 0, False), "plain_gis": ("vol", 1, False), "plain_taxid": ("vol", 2, False),
+                   "plain_gis_taxid": ("vol", 3, False), "masked": ("masked", 0, False), "masked_gis_taxid": ("masked", 3, False),
+                   "taxlist": ("vol", 0, True), "taxlist_gis_taxid": ("vol", 3, True), "masked_taxlist": ("masked", 2, True)}
+
+
+@pytest.mark.parametrize("variant", sorted(HEADER_VARIANTS))
+def test_definition_lines_masks_and_taxid_filters_match_reference(tmp_path, variant):
+    """Every Seq-id flavour, merged entries, default titles, -I / -H, an OID-mask alias and a taxid list: the names
+    the reference CLI printed (XML <name>: first passing defline; TSV: its first word, gi's always shown) for the
+    hits it reported, and the set of sequences it was allowed to report."""
+    import re
+    from conftest import load_golden
+    case, vol, masked, tx = build_headers_db(tmp_path)
+    g = load_golden("headers")
+    assert g["checksum"] == case.checksum()
+    dbn, flags, taxlist = HEADER_VARIANTS[variant]
+    h = swipe_amd.Headers(vol if dbn == "vol" else masked, taxidfile=tx if taxlist else None)
+    ref = g["variants"][variant]
+    tracks = [int(x) for x in re.findall(r"<track>(\d+)</track>", ref["m7"])]
+    names = re.findall(r"<name>(.*?)</name>", ref["m7"])
+    assert tracks and [h.get(s, flags)[0] for s in tracks] == names
+    subj = [l.split("\t")[1] for l in ref["m8"].splitlines() if l.strip()]
+    assert [h.get(s, flags | 1)[0].split(" ")[0] for s in tracks[: len(subj)]] == subj
+    # inclusion: OID mask and/or "some definition line carries a listed taxid and the membership bit"
+    hdrs, memb = case.extra["headers"], (1 if dbn == "masked" else 0)
+    want = []
+    for i, entry in enumerate(hdrs):
+        ok = case.extra["include"][i] if dbn == "masked" else True
+        if ok and taxlist:
+            ok = any((d.get("taxid") or 0) in case.extra["taxids"] and ((d.get("memb") or 0) & memb) == memb for d in entry)
+        want.append(1 if ok else 0)
+    assert h.inclusion(0, len(hdrs)).tolist() == want
+    assert set(tracks) <= {i for i, k in enumerate(want) if k}
+    info = h.info()
+    size = [l for l in ref["db_lines"] if l.startswith("Database size")][0]
+    assert size == "Database size:     %d residues in %d sequences" % (info["masked_symcount"], info["masked_seqcount"])
+    assert [l for l in ref["db_lines"] if l.startswith("Database title")][0] == "Database title:    " + info["title"]
