@@ -61,3 +61,27 @@ def gather_topk(local_hits: Sequence[Tuple[int, int]], keep: int, totalhits: int
         tot += int(t[2 * keep + 1])
         obv += int(t[2 * keep + 2])
     return merge_hits(lists, keep), tot, obv
+
+
+def align_sharded(db, query, hits: Sequence[Tuple[int, int]], first: int, last: int, dstrands=None, dframes=None,
+                  group=None):
+    """Alignment phase over shards: every rank holds the same merged hit list (gather_topk); the rank whose
+    shard [first, last) contains a hit's sequence aligns it on its own GPU (db.align: end points on the
+    device, traceback on its host) and ONE all_gather_object hands every rank the full list - the role of
+    the alignment messages the MPI master collects from its workers (swipe.cc:2060-2140).
+    Returns one alignment dict per hit, in hit order."""
+    import torch.distributed as dist
+    idx = [i for i, h in enumerate(hits) if first <= h[0] < last]
+    mine = {}
+    if idx:
+        pick = lambda a: None if a is None else [a[i] for i in idx]
+        for i, a in zip(idx, db.align(query, [hits[i][0] for i in idx], pick(dstrands), pick(dframes))):
+            mine[i] = a
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, mine, group=group)
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    if len(merged) != len(hits):
+        raise RuntimeError("a hit's sequence lies in no shard: shard bounds do not cover the database")
+    return [merged[i] for i in range(len(hits))]

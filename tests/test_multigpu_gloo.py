@@ -41,8 +41,24 @@ def _worker(rank, world, port, keep, q_out):
         minscore = 40
         mine = sorted(((int(s), lo + i) for i, s in enumerate(local) if s >= minscore), key=lambda t: (-t[0], -t[1]))[:keep]
         hits, tot, obv = parallel.gather_topk([(i, s) for s, i in mine], keep, totalhits=int((local >= minscore).sum()))
+
+        class HostShard:
+            """stands in for Database.align on a box without a GPU: end points from the oracle's search16s,
+            then the PRODUCT's host traceback (swa_traceback), as swa_align_hits combines them"""
+            def align(self, query, seqnos, dstrands=None, dframes=None):
+                Mp = swipe_amd.matrix_builtin("BLOSUM62")
+                out = []
+                for s in seqnos:
+                    assert lo <= s < hi
+                    sc, bp, bq = oracle.search16s_lane(seqs[s], query, M, 12, 1)
+                    a = swipe_amd.traceback(query, seqs[s], Mp, 11, 1, (sc, bq, bp) if (bq > 0 and bp != 0) else None)
+                    a["seqno"] = s
+                    out.append(a)
+                return out
+
+        al = parallel.align_sharded(HostShard(), q, hits[:20], lo, hi)
         if rank == 0:
-            q_out.put((hits, tot, (lo, hi)))
+            q_out.put((hits, tot, (lo, hi), [(a["seqno"], a["score"], a["q_start"], a["d_start"], a["q_end"], a["d_end"], a["cigar"]) for a in al]))
     finally:
         dist.destroy_process_group()
 
@@ -56,7 +72,7 @@ def test_sharded_topk_equals_single_list(keep):
     procs = [ctx.Process(target=_worker, args=(r, world, port, keep, out)) for r in range(world)]
     for p in procs:
         p.start()
-    hits, tot, bounds = out.get(timeout=120)
+    hits, tot, bounds, aligned = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -72,3 +88,9 @@ def test_sharded_topk_equals_single_list(keep):
     assert hits == [(x[0], x[1]) for x in h.hits()]
     assert tot == int((full >= 40).sum())
     assert 0 < bounds[1] < len(seqs)
+    # alignment phase across shards: each hit aligned by the rank that holds it, gathered in hit order
+    M = oracle.matrix_builtin("BLOSUM62")
+    assert [a[0] for a in aligned] == [x[0] for x in hits[:20]]
+    for seqno, score, qs, ds, qe, de, cigar in aligned:
+        sc, bp, bq = oracle.search16s_lane(seqs[seqno], q, M, 12, 1)
+        assert oracle.align(q, seqs[seqno], M, 11, 1, (sc, bq, bp) if (bq > 0 and bp != 0) else None) == (score, qs, ds, qe, de, cigar)
