@@ -452,6 +452,110 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
   out_score[t] = S; out_pos[t] = bp; out_q[t] = bq;
 }
 
+// The same end points, one WAVE per sequence (the kernel the alignment phase uses; the one-thread form above
+// remains as the 64-bit fallback for scoring systems whose scores could leave 32 bits).  Systolic like the
+// search kernels but in plain int32 with position tracking: lane g owns query rows [row0 + g*K, +K), works on
+// column t - g at step t, and hands H and F of its last row to lane g + 1 (ds_bpermute).  Database residues
+// are staged through a 128-entry LDS ring one 64-column block ahead of use; the substitution matrix sits in
+// LDS.  Queries longer than 64*K rows take several passes; the bottom row of a pass is handed over through
+// bh/bf (one int pair per column, in place: lane 63 writes column t - 63 long after lane 0 read it).
+// Ties as search16s.cc:391-405: among the cells holding the maximum, the smallest column, then the smallest row.
+template <int K>
+__global__ void __launch_bounds__(64)
+swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
+                          const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
+                          const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
+                          int* __restrict__ bh, int* __restrict__ bf, const int64_t* __restrict__ boff,
+                          long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q)
+{
+  __shared__ int M[1024];
+  __shared__ uint8_t ring[128];
+  const int w = blockIdx.x, g = threadIdx.x;
+  if (w >= n) return;
+  for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
+  const int64_t o = offsets[ids[w]];
+  const int len = (int)(offsets[ids[w] + 1] - o);
+  const bool rc = minus && minus[w];
+  int* mybh = bh ? bh + boff[w] : nullptr;
+  int* mybf = bf ? bf + boff[w] : nullptr;
+  auto residue = [&](int c) -> u32 {
+    if (c >= len) return 0;
+    return rc ? (__brev((u32)residues[o + len - 1 - c]) >> 28) : (u32)residues[o + c];
+  };
+  int best = 0, bcol = 0, brow = -1;
+  for (int row0 = 0; row0 < qlen; row0 += 64 * K) {
+    const bool first_pass = row0 == 0, more = row0 + 64 * K < qlen;
+    int qs[K], hp[K], ee[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int r = row0 + g * K + k;
+      qs[k] = r < qlen ? (int)qseq[r] : -1;
+      hp[k] = 0;
+      ee[k] = 0;
+    }
+    int pbest = 0, pcol = 0, prow = -1;
+    int hin = 0, fin = 0, diag = 0;             // from the row above this lane's rows: H, F of column c; H of column c-1
+    u32 nextd = residue(g);
+    __syncthreads();
+    const int steps = len + 63;
+    for (int t = 0; t < steps; ++t) {
+      if ((t & 63) == 0) {
+        __syncthreads();
+        ring[(t + g) & 127] = (uint8_t)nextd;
+        nextd = residue(t + 64 + g);
+        __syncthreads();
+      }
+      const int c = t - g;
+      const bool active = c >= 0 && c < len;
+      if (g == 0) {                              // top boundary: zeros, or the previous pass's bottom row
+        if (first_pass || !active) { hin = 0; fin = 0; }
+        else {                                   // agent-scope loads: written by lane 63 in the previous pass
+          hin = __hip_atomic_load(mybh + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fin = __hip_atomic_load(mybf + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      int hout = 0, fout = 0;
+      if (active) {
+        const int* mrow = M + ((int)ring[c & 127] << 5);
+        int hd = diag, f = fin;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int n0 = hp[k];
+          int e = ee[k];
+          int h = hd + (qs[k] >= 0 ? mrow[qs[k]] : -1);
+          h = max(max(h, f), max(e, 0));
+          if (qs[k] >= 0 && h > pbest) { pbest = h; pcol = c; prow = row0 + g * K + k; }
+          hp[k] = h;
+          const int tt = h - Q;
+          e = max(e - R, tt);
+          f = max(f - R, tt);
+          ee[k] = e;
+          hd = n0;
+        }
+        hout = hp[K - 1];
+        fout = f;
+        diag = hin;                              // H(row above, c) is the diagonal of column c + 1
+        if (g == 63 && more) {
+          __hip_atomic_store(mybh + c, hout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(mybf + c, fout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const int hnext = __shfl_up(hout, 1), fnext = __shfl_up(fout, 1);
+      if (g > 0) { hin = hnext; fin = fnext; }
+    }
+    if (pbest > best || (pbest == best && pbest > 0 && (pcol < bcol || (pcol == bcol && prow < brow)))) {
+      best = pbest; bcol = pcol; brow = prow;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    const int ob = __shfl_down(best, sh), oc = __shfl_down(bcol, sh), orow = __shfl_down(brow, sh);
+    if (ob > best || (ob == best && ob > 0 && (oc < bcol || (oc == bcol && orow < brow)))) { best = ob; bcol = oc; brow = orow; }
+  }
+  if (g == 0) { out_score[w] = best; out_pos[w] = bcol; out_q[w] = brow; }
+}
+
 // ------------------------------------------------------------------ launchers
 template <int K>
 static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStream_t st)
@@ -550,6 +654,25 @@ extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_
   const int blocks = (n + 63) / 64;
   hipLaunchKernelGGL(swa_endpoints_kernel, dim3(blocks), dim3(64), 0, st, residues, offsets, ids, minus, n, qseq, qlen, matrix, Q, R,
                      Hs, Es, out, out + n, out + 2 * (size_t)n);
+  return hipGetLastError();
+}
+// wave-per-sequence end points; bh/bf/boff may be null when qlen <= 64 * rows-per-lane(qlen) (single pass)
+extern "C" int swa_endpoints_rows_for(int qlen) { return qlen <= 256 ? 4 : qlen <= 512 ? 8 : qlen <= 1024 ? 16 : 32; }
+extern "C" hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
+                                                const uint8_t* minus, int n, const uint8_t* qseq, int qlen,
+                                                const int32_t* matrix, int Q, int R, int* bh, int* bf,
+                                                const int64_t* boff, long long* out, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+#define SWA_EPW(KK) hipLaunchKernelGGL(swa_endpoints_wave_kernel<KK>, dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
+                                       qseq, qlen, matrix, Q, R, bh, bf, boff, out, out + n, out + 2 * (size_t)n)
+  switch (swa_endpoints_rows_for(qlen)) {
+    case 4: SWA_EPW(4); break;
+    case 8: SWA_EPW(8); break;
+    case 16: SWA_EPW(16); break;
+    default: SWA_EPW(32); break;
+  }
+#undef SWA_EPW
   return hipGetLastError();
 }
 extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, long long minscore,

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -29,6 +30,10 @@ int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
                                 const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                 long long* Hs, long long* Es, long long* out, hipStream_t st);
+int swa_endpoints_rows_for(int qlen);
+hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
+                                     const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix,
+                                     int Q, int R, int* bh, int* bf, const int64_t* boff, long long* out, hipStream_t st);
 hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
 hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
@@ -1125,13 +1130,43 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
   DevBuf<long long> d_h, d_e, d_out;
   HIP_TRY(d_ids.reserve(size_t(n)));
   HIP_TRY(d_minus.reserve(size_t(n)));
-  HIP_TRY(d_h.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
-  HIP_TRY(d_e.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
   HIP_TRY(d_out.reserve(3 * size_t(n)));
   HIP_TRY(db->qseq.reserve(size_t(qlen > 0 ? qlen : 1)));
   if (qlen) HIP_TRY(hipMemcpyAsync(db->qseq.p, query, size_t(qlen), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_ids.p, ids.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_minus.p, minus.data(), size_t(n), hipMemcpyHostToDevice, st));
+  // one wave per sequence in int32 whenever no score can leave 32 bits; the one-thread 64-bit form otherwise
+  const int64_t span = std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1);
+  const char* force = std::getenv("SWA_ENDPOINTS");          // "thread": the 64-bit one-thread kernel (A/B, tests)
+  if (!(force && !std::strcmp(force, "thread")) && span < (int64_t(1) << 30) && db->goe < (int64_t(1) << 30) &&
+      db->ge < (int64_t(1) << 30)) {
+    const int rows = swa_endpoints_rows_for(int(qlen));
+    DevBuf<int> d_bh, d_bf;
+    DevBuf<int64_t> d_boff;
+    const bool passes = qlen > 64 * rows;
+    if (passes) {                                 // bottom-row hand-over between passes: one int pair per column
+      std::vector<int64_t> boff((size_t(n)));
+      int64_t total = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        boff[size_t(i)] = total;
+        total += db->h_offsets[size_t(ids[size_t(i)]) + 1] - db->h_offsets[size_t(ids[size_t(i)])];
+      }
+      HIP_TRY(d_bh.reserve(size_t(total) + 1));
+      HIP_TRY(d_bf.reserve(size_t(total) + 1));
+      HIP_TRY(d_boff.reserve(size_t(n)));
+      HIP_TRY(hipMemcpyAsync(d_boff.p, boff.data(), size_t(n) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));          // boff lives on this stack frame
+    }
+    HIP_TRY(swa_launch_endpoints_wave(db->residues.p, db->offsets.p, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
+                                      db->matrix.p, int(db->goe), int(db->ge), passes ? d_bh.p : nullptr,
+                                      passes ? d_bf.p : nullptr, passes ? d_boff.p : nullptr, d_out.p, st));
+    out.resize(3 * size_t(n));
+    HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SWA_OK;
+  }
+  HIP_TRY(d_h.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
+  HIP_TRY(d_e.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
   HIP_TRY(swa_launch_endpoints(db->residues.p, db->offsets.p, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
                                db->matrix.p, db->goe, db->ge, d_h.p, d_e.p, d_out.p, st));
   out.resize(3 * size_t(n));
@@ -1271,29 +1306,50 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   if (rc != SWA_OK) return rc;
   const int64_t gapopen = db->goe - db->ge, gapextend = db->ge;
   const int64_t limit16 = 65536 - db->hi;                           // SCORELIMIT_16, matrices.cc:578
-  std::string all;
-  std::vector<uint8_t> dseq;
-  std::vector<swa::EditOp> ops;
+  // sequences come back from the device on this thread; the tracebacks are independent and run on a few host
+  // threads (the reference spreads align_chunk over its worker threads the same way, swipe.cc:615-647)
+  std::vector<std::vector<uint8_t>> dseqs{size_t(n)};
   for (int64_t i = 0; i < n; ++i) {
-    const int strand = dstrands ? (dstrands[i] ? 1 : 0) : 0, frame = dframes ? dframes[i] : 0;
-    rc = fetch_sequence(db, seqnos[i], strand, frame, dseq);
+    rc = fetch_sequence(db, seqnos[i], dstrands ? (dstrands[i] ? 1 : 0) : 0, dframes ? dframes[i] : 0, dseqs[size_t(i)]);
     if (rc != SWA_OK) return rc;
-    swa_alignment_t& a = out[i];
-    std::memset(&a, 0, sizeof a);
-    const int64_t score = ends[size_t(i)], d_end = ends[size_t(n + i)], q_end = ends[size_t(2 * n + i)];
-    // the hint is honoured only if the 16-bit lanes did not saturate and neither coordinate is 0
-    // (swipe.cc:404, hits.cc:587); otherwise align() starts from scratch
-    const bool hinted = score < limit16 && q_end > 0 && d_end != 0;
-    rc = align_on_host(query, qlen, dseq.data(), int64_t(dseq.size()), db->h_matrix, gapopen, gapextend,
-                       hinted ? score : 0, q_end, d_end, a, ops);
-    if (rc != SWA_OK) return rc;
-    a.seqno = seqnos[i];
-    a.dstrand = strand;
-    a.dframe = frame;
-    a.dlennt = db->frames == 6 ? db->h_ntlen[size_t(seqnos[i] - db->first_seqno)] : 0;
-    a.cigar_offset = int64_t(all.size());
-    for (const swa::EditOp& op : ops) { all += op.kind; all += std::to_string(op.count); }
-    a.cigar_len = int64_t(all.size()) - a.cigar_offset;
+  }
+  std::vector<std::string> scripts{size_t(n)};
+  std::vector<int> status(size_t(n), SWA_OK);
+  auto work = [&](int64_t lo, int64_t hi) {
+    std::vector<swa::EditOp> ops;
+    for (int64_t i = lo; i < hi; ++i) {
+      const std::vector<uint8_t>& dseq = dseqs[size_t(i)];
+      swa_alignment_t& a = out[i];
+      std::memset(&a, 0, sizeof a);
+      const int64_t score = ends[size_t(i)], d_end = ends[size_t(n + i)], q_end = ends[size_t(2 * n + i)];
+      // the hint is honoured only if the 16-bit lanes did not saturate and neither coordinate is 0
+      // (swipe.cc:404, hits.cc:587); otherwise align() starts from scratch
+      const bool hinted = score < limit16 && q_end > 0 && d_end != 0;
+      status[size_t(i)] = align_on_host(query, qlen, dseq.data(), int64_t(dseq.size()), db->h_matrix, gapopen, gapextend,
+                                        hinted ? score : 0, q_end, d_end, a, ops);
+      if (status[size_t(i)] != SWA_OK) continue;
+      a.seqno = seqnos[i];
+      a.dstrand = dstrands ? (dstrands[i] ? 1 : 0) : 0;
+      a.dframe = dframes ? dframes[i] : 0;
+      a.dlennt = db->frames == 6 ? db->h_ntlen[size_t(seqnos[i] - db->first_seqno)] : 0;
+      std::string& sc = scripts[size_t(i)];
+      for (const swa::EditOp& op : ops) { sc += op.kind; sc += std::to_string(op.count); }
+    }
+  };
+  const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({n, int64_t(std::thread::hardware_concurrency()), 16}));
+  if (nthreads == 1) {
+    work(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
+    for (std::thread& t : pool) t.join();
+  }
+  std::string all;
+  for (int64_t i = 0; i < n; ++i) {
+    if (status[size_t(i)] != SWA_OK) return fail(status[size_t(i)], "Internal error in align function.");   // align.cc:156
+    out[i].cigar_offset = int64_t(all.size());
+    out[i].cigar_len = int64_t(scripts[size_t(i)].size());
+    all += scripts[size_t(i)];
     all += '\0';
   }
   *text_used = int64_t(all.size());

@@ -541,6 +541,27 @@ def test_inclusion_subset_scores(tmp_path):
     db.close()
 
 
+@pytest.mark.parametrize("qlen", [1, 63, 64, 257, 1025, 2048, 2049, 5000])
+def test_endpoints_wave_kernel_all_row_counts_and_passes(qlen, monkeypatch):
+    """search16s semantics from the wave-per-sequence kernel for every rows-per-lane instantiation, across the
+    64*K-row pass boundary (2048 / 2049 / 5000 rows = 1 / 2 / 3 passes), and from the one-thread 64-bit form."""
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(777, 1, qlen, rtab)
+    seqs = [synth._random_residues(800 + k, 2, n, rtab) for k, n in enumerate([0, 1, 2, 17, 64, 65, 127, 128, 129, 300, 1000, 2500])]
+    seqs += [q.copy(), q[: max(1, qlen // 2)].copy(), q[qlen // 3:].copy(), np.concatenate([seqs[9], q[: min(qlen, 600)], seqs[6]])]
+    M = oracle.matrix_builtin("BLOSUM62")
+    want = [oracle.search16s_lane(d, q, M, 12, 1) for d in seqs]
+    assert max(w[0] for w in want) < 65525
+    db = swipe_amd.Database.from_sequences(seqs, symtype=1)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    ids = list(range(len(seqs)))
+    for mode in ("wave", "thread"):
+        monkeypatch.setenv("SWA_ENDPOINTS", mode)
+        e = db.search_endpoints(q, ids)
+        assert [(int(e[0][k]), int(e[1][k]), int(e[2][k])) for k in ids] == want, mode
+    db.close()
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     import subprocess
     from conftest import ROOT
