@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <getopt.h>
+#include <strings.h>
 #include <string>
 #include <vector>
 
@@ -288,10 +289,11 @@ int main(int argc, char** argv)
       {"evalue", 1, 0, 'e'}, {"minevalue", 1, 0, 'k'}, {"min_score", 1, 0, 'c'}, {"max_score", 1, 0, 'u'},
       {"num_threads", 1, 0, 'a'}, {"outfmt", 1, 0, 'm'}, {"symtype", 1, 0, 'p'}, {"strand", 1, 0, 'S'}, {"out", 1, 0, 'o'},
       {"dbsize", 1, 0, 'z'}, {"gpu", 1, 0, 'g'}, {"query_gencode", 1, 0, 'Q'}, {"db_gencode", 1, 0, 'D'}, {"show_gis", 0, 0, 'I'},
-      {"show_taxid", 0, 0, 'H'}, {"taxidlist", 1, 0, 'x'}, {"help", 0, 0, 'h'},
+      {"show_taxid", 0, 0, 'H'}, {"taxidlist", 1, 0, 'x'}, {"taxid", 1, 0, 'x'}, {"comp_based_stats", 1, 0, 'C'},
+      {"filter", 1, 0, 'F'}, {"subalignments", 1, 0, 'K'}, {"dump", 1, 0, 'N'}, {"help", 0, 0, 'h'},
       {0, 0, 0, 0}};
   int c;
-  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:Q:D:IHx:h", longopts, nullptr)) != -1) {
+  while ((c = getopt_long(argc, argv, "d:i:M:q:r:G:E:S:v:b:c:u:e:k:a:m:p:o:z:g:Q:D:IHx:C:F:K:N:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'd': dbname = optarg; break;
       case 'i': queryname = optarg; break;
@@ -311,6 +313,17 @@ int main(int argc, char** argv)
       case 'o': outfile = optarg; break;
       case 'z': effdbsize = std::atol(optarg); break;
       case 'g': device = std::atol(optarg); break;
+      case 'C':                                                        // swipe.cc:921-926
+        if (strcasecmp(optarg, "F") != 0 && std::strcmp(optarg, "0") != 0) fatal("Composition-based score adjustments not supported.");
+        break;
+      case 'F':                                                        // swipe.cc:947-952
+        if (std::strlen(optarg) != 0 && strcasecmp(optarg, "F") != 0) fatal("Query sequence filtering not supported.");
+        break;
+      case 'K': break;                                                 // subalignments: read and never used by the reference
+      case 'N':
+        if (std::atol(optarg) != 0) fatal("Database dumping (-N) is not part of swipe_amd_cli.");
+        break;
+      case 'h': usage(argv[0]); std::exit(0);
       case 'I': show_gis = true; break;
       case 'H': show_taxid = true; break;
       case 'x': taxidfile = optarg; break;
