@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <thread>
 #include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -272,6 +273,10 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
   if (last_seqno < first_seqno) return SWA_OK;
   out.offsets.reserve(size_t(last_seqno - first_seqno + 2));
 
+  // pass 1: lengths -> offsets (and the OID mask); pass 2: the residues, copied / unpacked by a few threads
+  struct Src { const Volume* v; int64_t s; };
+  std::vector<Src> src;
+  src.reserve(size_t(last_seqno - first_seqno + 1));
   int64_t vbase = 0;
   for (const Volume& v : V) {
     const int64_t lo = first_seqno > vbase ? first_seqno - vbase : 0;
@@ -279,45 +284,76 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
     for (int64_t s = lo; s <= hi; ++s) {
       const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
       if (o2 < o1 || o2 > v.seq.n) return fail(SWA_EIO, "corrupt sequence offsets in " + v.base);
+      int64_t len;
       if (protein) {
-        const size_t len = o2 > o1 ? size_t(o2 - o1 - 1) : 0;        // entry includes its NUL terminator
-        out.residues.insert(out.residues.end(), v.seq.p + o1, v.seq.p + o1 + len);
+        len = o2 > o1 ? int64_t(o2 - o1 - 1) : 0;                    // entry includes its NUL terminator
       } else {
         const uint64_t o3 = be32(v.amb_off + 4 * s);
         if (o3 <= o1 || o3 > o2) return fail(SWA_EIO, "corrupt ambiguity offsets in " + v.base);
-        const uint8_t* body = v.seq.p + o1;
         const size_t packed = size_t(o3 - o1);
-        const size_t ntlen = 4 * (packed - 1) + (body[packed - 1] & 3);   // database.cc:1260-1261
-        const size_t at = out.residues.size();
-        out.residues.resize(at + ntlen);
-        uint8_t* dst = out.residues.data() + at;
-        for (size_t i = 0; i < ntlen; ++i)
-          dst[i] = uint8_t(1u << ((body[i >> 2] >> ((3 - (i & 3)) << 1)) & 3));  // A=1 C=2 G=4 T=8
-        if (o2 > o3) {                                               // ambiguity runs, database.cc:1284-1323
-          const uint8_t* a = v.seq.p + o3;
-          const size_t bytes = size_t(o2 - o3);
-          if (bytes >= 4) {
-            const uint32_t hdr = be32(a);
-            if (hdr >> 31) {
-              for (size_t k = 0; k + 8 <= bytes - 4; k += 8) {
-                const uint64_t e = be64(a + 4 + k);
-                const uint64_t code = e >> 60, run = ((e >> 48) & 0xfff) + 1, off = e & 0x0000fffffffffffULL;
-                for (uint64_t r = 0; r < run && off + r < ntlen; ++r) dst[off + r] = uint8_t(code);
-              }
-            } else {
-              for (size_t k = 0; k + 4 <= bytes - 4; k += 4) {
-                const uint32_t e = be32(a + 4 + k);
-                const uint32_t code = e >> 28, run = ((e >> 24) & 0xf) + 1, off = e & 0x00ffffff;
-                for (uint32_t r = 0; r < run && size_t(off) + r < ntlen; ++r) dst[off + r] = uint8_t(code);
-              }
+        len = int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3));   // database.cc:1260-1261
+      }
+      out.offsets.push_back(out.offsets.back() + len);
+      src.push_back({&v, s});
+      if (out.masked) out.included.push_back(bd.in_mask(size_t(&v - V.data()), s) ? 1 : 0);
+    }
+    vbase += v.nseq;
+  }
+  out.residues.resize(size_t(out.offsets.back()));
+  auto fill = [&](size_t from, size_t to) {
+    for (size_t i = from; i < to; ++i) {
+      const Volume& v = *src[i].v;
+      const int64_t s = src[i].s;
+      const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
+      uint8_t* dst = out.residues.data() + out.offsets[i];
+      const size_t n = size_t(out.offsets[i + 1] - out.offsets[i]);
+      if (protein) {
+        if (n) std::memcpy(dst, v.seq.p + o1, n);
+        continue;
+      }
+      const uint64_t o3 = be32(v.amb_off + 4 * s);
+      const uint8_t* body = v.seq.p + o1;
+      for (size_t k = 0; k < n; ++k)
+        dst[k] = uint8_t(1u << ((body[k >> 2] >> ((3 - (k & 3)) << 1)) & 3));  // A=1 C=2 G=4 T=8
+      if (o2 > o3) {                                                 // ambiguity runs, database.cc:1284-1323
+        const uint8_t* a = v.seq.p + o3;
+        const size_t bytes = size_t(o2 - o3);
+        if (bytes >= 4) {
+          const uint32_t hdr = be32(a);
+          if (hdr >> 31) {
+            for (size_t k = 0; k + 8 <= bytes - 4; k += 8) {
+              const uint64_t e = be64(a + 4 + k);
+              const uint64_t code = e >> 60, run = ((e >> 48) & 0xfff) + 1, off = e & 0x0000fffffffffffULL;
+              for (uint64_t r = 0; r < run && off + r < n; ++r) dst[off + r] = uint8_t(code);
+            }
+          } else {
+            for (size_t k = 0; k + 4 <= bytes - 4; k += 4) {
+              const uint32_t e = be32(a + 4 + k);
+              const uint32_t code = e >> 28, run = ((e >> 24) & 0xf) + 1, off = e & 0x00ffffff;
+              for (uint32_t r = 0; r < run && size_t(off) + r < n; ++r) dst[off + r] = uint8_t(code);
             }
           }
         }
       }
-      out.offsets.push_back(int64_t(out.residues.size()));
-      if (out.masked) out.included.push_back(bd.in_mask(size_t(&v - V.data()), s) ? 1 : 0);
     }
-    vbase += v.nseq;
+  };
+  const size_t total = src.size();
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({size_t(std::thread::hardware_concurrency()), size_t(32),
+                                                                 size_t(out.residues.size() >> 24) + 1}));
+  if (nthreads == 1) {
+    fill(0, total);
+  } else {                                                           // split by residues, not by sequence count
+    std::vector<std::thread> pool;
+    size_t from = 0;
+    for (size_t t = 0; t < nthreads; ++t) {
+      const int64_t target = out.offsets.back() * int64_t(t + 1) / int64_t(nthreads);
+      const size_t to = t + 1 == nthreads ? total
+                                          : size_t(std::lower_bound(out.offsets.begin(), out.offsets.end(), target) - out.offsets.begin());
+      const size_t end = std::min(std::max(to, from), total);
+      pool.emplace_back(fill, from, end);
+      from = end;
+    }
+    for (std::thread& th : pool) th.join();
   }
   return SWA_OK;
 }

@@ -2,6 +2,7 @@
 #ifndef SWA_HOST_UTIL_H
 #define SWA_HOST_UTIL_H
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -11,8 +12,20 @@ int fail(int code, const std::string& msg);
 
 // A database (or a range of one) read from BLAST v4 files into host memory:
 // sequence s = residues[offsets[s] .. offsets[s+1]) in reference symbol codes.
+// byte buffer that is NOT zero-filled on allocation (a 3 GB std::vector would spend 0.3 s on that)
+struct RawBytes {
+  std::unique_ptr<uint8_t[]> p;
+  size_t n = 0;
+  void resize(size_t bytes) { p.reset(new uint8_t[bytes ? bytes : 1]); n = bytes; }
+  void clear() { p.reset(); n = 0; }
+  uint8_t* data() { return p.get(); }
+  const uint8_t* data() const { return p.get(); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+};
+
 struct HostDb {
-  std::vector<uint8_t> residues;
+  RawBytes residues;
   std::vector<int64_t> offsets;       // nseq + 1
   int64_t first_seqno = 0;
   int64_t total_seqcount = 0, total_symcount = 0, longest = 0;
