@@ -562,6 +562,50 @@ def test_endpoints_wave_kernel_all_row_counts_and_passes(qlen, monkeypatch):
     db.close()
 
 
+def test_cli_multi_query_file_equals_reference_cli(tmp_path):
+    """query_read (query.cc:265-366) through the CLI: several queries per file - no description on the first,
+    wrapped and lower-case lines, blank lines, digits / '*' / CR LF inside, an empty query - and the
+    per-query output loop; -m 7 / 8 / 9 / 0 byte for byte."""
+    import subprocess
+    from conftest import ROOT
+    g = load_golden("multiquery")
+    case = cases.get("edges")
+    assert g["checksum"] == case.checksum()
+    base = str(tmp_path / "db")
+    blastdb.write_db(base, case.seqs, protein=True)
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(g["query_text"])
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    for m, b in (("7", "3"), ("8", "10"), ("9", "10"), ("0", "2")):
+        r = subprocess.run([exe, "-d", base, "-i", qf, "-m", m, "-b", b, "-v", "12", "-e", "1000"], capture_output=True, text=True)
+        assert r.returncode == g["rc" + m], r.stderr
+        if m == "8":
+            assert r.stdout == g["m8"]
+        elif m == "7":
+            # <len> of a hit WITHOUT an alignment is uninitialised memory in the reference (hits.cc:566 only fills
+            # dlen for aligned hits; the list is re-malloc'ed per query, so later queries show stale values there)
+            def norm(t):
+                hits = t.split("<hit>")
+                return "<hit>".join(h if "<alignment>" in h else re.sub(r"<len>\d+</len>", "<len>?</len>", h) for h in hits)
+            import re
+            assert norm(r.stdout) == norm(g["m7"])
+        elif m == "9":        # first comment line of every query block names the program; the database path differs
+            strip = lambda t: [l for l in t.split("\n") if not l.startswith("# SWIPE") and not l.startswith("# swipe_amd") and not l.startswith("# Database:")]
+            assert strip(r.stdout) == strip(g["m9"])
+        else:                 # everything from each hit-list heading to the next query's parameter block
+            def blocks(t):
+                out, keep = [], False
+                for l in t.split("\n"):
+                    if l.startswith("Sequences producing") or l.startswith("No hits") or l.strip() == "No hits.":
+                        keep = True
+                    elif l.startswith("Database file:") or l.startswith("Query file name") or l.startswith("Searching"):
+                        keep = False
+                    if keep:
+                        out.append(l)
+                return out
+            assert blocks(r.stdout) == blocks(g["m0"])
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     import subprocess
     from conftest import ROOT
