@@ -135,6 +135,7 @@ SWA_API void swa_headers_close(swa_headers* h);
    the "Database size" line use, hits.cc:333-342), longest sequence, title */
 SWA_API int swa_headers_info(const swa_headers* h, int64_t* seqcount, int64_t* symcount, int64_t* masked_seqcount,
                      int64_t* masked_symcount, int64_t* longest, char* title, int64_t title_cap);
+SWA_API int swa_headers_time(const swa_headers* h, char* buf, int64_t cap);   /* creation stamp of the first volume */
 /* the definition lines of `seqno` that pass the membership / taxid filters, one per line; *needed = bytes
    incl. NUL, SWA_ERANGE when buflen is smaller */
 SWA_API int swa_headers_get(const swa_headers* h, int64_t seqno, int flags, char* buf, int64_t buflen, int64_t* needed);

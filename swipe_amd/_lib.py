@@ -51,7 +51,7 @@ EXPORTS = [
     "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
     "swa_db_open_translated", "swa_db_from_memory_translated", "swa_search_frames_topk",
     "swa_gencode_name", "swa_translate_table", "swa_translate",
-    "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_get", "swa_headers_inclusion",
+    "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_time", "swa_headers_get", "swa_headers_inclusion",
     "swa_db_set_inclusion",
     "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
     "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge",
@@ -102,6 +102,7 @@ def load():
     L.swa_headers_close.argtypes = [vp]
     L.swa_headers_close.restype = None
     L.swa_headers_info.argtypes = [vp, i64p, i64p, i64p, i64p, i64p, C.c_char_p, i64]
+    L.swa_headers_time.argtypes = [vp, C.c_char_p, i64]
     L.swa_headers_get.argtypes = [vp, i64, C.c_int, C.c_char_p, i64, i64p]
     L.swa_headers_inclusion.argtypes = [vp, i64, i64, vp]
     L.swa_db_set_inclusion.argtypes = [vp, vp, i64]

@@ -52,7 +52,7 @@ struct Volume {
   int64_t nseq = 0, nsym = 0, longest = 0;
   const uint8_t* seq_off = nullptr;    // big-endian u32 [nseq + 1]
   const uint8_t* amb_off = nullptr;    // nucleotide only
-  std::string title;
+  std::string title, time;
 };
 
 bool open_volume(const std::string& base, bool protein, Volume& v, std::string& err)
@@ -67,7 +67,9 @@ bool open_volume(const std::string& base, bool protein, Volume& v, std::string& 
   const uint32_t tl = be32(p + o); o += 4;
   if (o + tl + 4 > v.index.n) { err = "Truncated database index."; return false; }
   v.title.assign(reinterpret_cast<const char*>(p + o), tl); o += tl;
-  const uint32_t dl = be32(p + o); o += 4 + dl;
+  const uint32_t dl = be32(p + o); o += 4;
+  if (o + dl + 4 > v.index.n) { err = "Truncated database index."; return false; }
+  v.time.assign(reinterpret_cast<const char*>(p + o), dl); o += dl;
   o = (o + 3) & ~size_t(3);                                          // database.cc:587-592
   if (o + 16 > v.index.n) { err = "Truncated database index."; return false; }
   v.nseq = be32(p + o); o += 4;
@@ -614,6 +616,13 @@ extern "C" int swa_headers_open(const char* basename, int symtype, const char* t
 }
 
 extern "C" void swa_headers_close(swa_headers* h) { delete h; }
+
+extern "C" int swa_headers_time(const swa_headers* h, char* buf, int64_t cap)      // db_gettime: the first volume's stamp
+{
+  if (!h || !buf || cap < 1) return swa::fail(SWA_EINVAL, "bad argument");
+  std::snprintf(buf, size_t(cap), "%s", h->db.vols[0].time.c_str());
+  return SWA_OK;
+}
 
 extern "C" int swa_headers_info(const swa_headers* h, int64_t* seqcount, int64_t* symcount, int64_t* masked_seqcount,
                                 int64_t* masked_symcount, int64_t* longest, char* title, int64_t title_cap)

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <getopt.h>
 #include <strings.h>
 #include <string>
@@ -282,6 +283,7 @@ int main(int argc, char** argv)
   bool show_gis = false, show_taxid = false;
   long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
   long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100, query_gencode = 1, db_gencode = 1;
+  long threads = 1;
   double expect = 10.0, minexpect = 0.0;
   static const option longopts[] = {
       {"db", 1, 0, 'd'}, {"query", 1, 0, 'i'}, {"matrix", 1, 0, 'M'}, {"penalty", 1, 0, 'q'}, {"reward", 1, 0, 'r'},
@@ -304,7 +306,7 @@ int main(int argc, char** argv)
       case 'E': gapextend = std::atol(optarg); break;
       case 'v': maxmatches = std::atol(optarg); break;
       case 'b': alignments = std::atol(optarg); break;
-      case 'a': break;
+      case 'a': threads = std::atol(optarg); break;                   // shown, otherwise unused: one GPU does the work
       case 'e': expect = std::atof(optarg); break;
       case 'k': minexpect = std::atof(optarg); break;
       case 'c': minscore = std::atol(optarg); break;
@@ -401,8 +403,9 @@ int main(int argc, char** argv)
     check(swa_headers_inclusion(headers, info.first_seqno, info.seqcount, include.data()));
     check(swa_db_set_inclusion(db, include.data(), info.seqcount));
   }
-  char dbtitle[1024] = "";
+  char dbtitle[1024] = "", dbtime[256] = "";
   check(swa_headers_info(headers, nullptr, nullptr, nullptr, nullptr, nullptr, dbtitle, sizeof dbtitle));
+  check(swa_headers_time(headers, dbtime, sizeof dbtime));
   const int hflags = (show_gis ? SWA_HEADERS_SHOW_GIS : 0) | (show_taxid ? SWA_HEADERS_SHOW_TAXID : 0);
 
   FILE* qf = queryname == "-" ? stdin : std::fopen(queryname.c_str(), "r");
@@ -577,27 +580,58 @@ int main(int argc, char** argv)
         else std::fprintf(out, "\t%ld", score);
         std::fprintf(out, "\n");
       }
-    } else {                                                          // args_show + hits_show_plain
+    } else {                                                          // args_show + work() + hits_show_plain
       static const char* const symnames[] = {"Nucleotide", "Amino acid", "Translated query", "Translated database", "Both translated"};
-      std::fprintf(out, "Database file:     %s\n", dbname.c_str());
+      std::fprintf(out, "Database file:     %s\n", dbname.c_str());       // swipe.cc:665-783
       std::fprintf(out, "Database title:    %s\n", dbtitle);
+      std::fprintf(out, "Database time:     %s\n", dbtime);
       std::fprintf(out, "Database size:     %ld residues in %ld sequences\n", long(info.total_symcount), long(info.total_seqcount));
       std::fprintf(out, "Longest db seq:    %ld residues\n", long(info.longest));
+      if (effdbsize > 0) std::fprintf(out, "Effecive db size:  %ld\n", effdbsize);
       std::fprintf(out, "Query file name:   %s\n", queryname.c_str());
       std::fprintf(out, "Query length:      %ld residues\n", long(qlen));
-      std::fprintf(out, "Query description: %s\n", q.description.c_str());
-      if (symtype != 0) std::fprintf(out, "Score matrix:      %s\n", matrixname.c_str());
-      else std::fprintf(out, "Score matrix:      %ld/%ld\n", match, mismatch);
+      for (size_t i = 0; i == 0 || i < q.description.size(); i += 60) {    // query_show, query.cc:509-518
+        if (q.description.empty()) break;
+        std::fprintf(out, i == 0 ? "Query description: %-60.60s\n" : "                   %-60.60s\n", q.description.c_str() + i);
+      }
+      if (symtype == 0) {
+        std::fprintf(out, "Query strands:     %s\n", strands == 1 ? "Plus" : strands == 2 ? "Minus" : "Plus and minus");
+        std::fprintf(out, "Score matrix:      %ld/%ld\n", match, mismatch);
+      } else {
+        std::fprintf(out, "Score matrix:      %s\n", matrixname.c_str());
+      }
       std::fprintf(out, "Gap penalty:       %ld+%ldk\n", gapopen, gapextend);
       std::fprintf(out, "Max expect shown:  %-g\n", expect);
       std::fprintf(out, "Min score shown:   %ld\n", minscore);
       std::fprintf(out, "Max matches shown: %ld\n", maxmatches);
       std::fprintf(out, "Alignments shown:  %ld\n", alignments);
+      std::fprintf(out, "Show gi's:         %d\n", show_gis ? 1 : 0);
+      std::fprintf(out, "Show taxid's:      %d\n", show_taxid ? 1 : 0);
+      std::fprintf(out, "Threads:           %ld\n", threads);
       std::fprintf(out, "Symbol type:       %s\n", symnames[symtype]);
       if (symtype == 2 || symtype == 4) std::fprintf(out, "Query genetic code:%s (%ld)\n", swa_gencode_name(int(query_gencode)), query_gencode);
       if (symtype == 3 || symtype == 4) std::fprintf(out, "DB genetic code:   %s (%ld)\n", swa_gencode_name(int(db_gencode)), db_gencode);
-      std::fprintf(out, "\nElapsed:           %.4fs (device)\n", cnt.total_ms * 1e-3);
-      std::fprintf(out, "Speed:             %.3f GCUPS\n\n", cnt.total_ms > 0 ? double(cnt.cells) / (cnt.total_ms * 1e-3) / 1e9 : 0.0);
+      if (!taxidfile.empty()) std::fprintf(out, "Taxid filename:    %s\n", taxidfile.c_str());
+      std::fprintf(out, "\n");
+      if (!st.available)                                               // hits.cc:503-507
+        std::fprintf(out, "Statistical parameters are not available for the scoring system specified.\nBit scores and E-values will not be computed.\n\n");
+      std::fprintf(out, "Searching..................................................done\n\n");
+      {                                                                // clock_stop, swipe.cc:1722-1784
+        char stamp[32];
+        const time_t now = std::time(nullptr);
+        struct tm tms;
+        gmtime_r(&now, &tms);
+        std::strftime(stamp, sizeof stamp, "%a, %e %b %Y %T UTC", &tms);
+        double cells = double(info.total_symcount) * double(qlen);
+        if (symtype == 0 || symtype == 2) cells *= strands == 3 ? 2 : 1;
+        if (symtype == 3) cells *= 2;
+        if (symtype == 4) cells *= strands == 3 ? 4 : 2;
+        std::fprintf(out, "Search started:    %s\n", stamp);
+        std::fprintf(out, "Search completed:  %s\n", stamp);
+        std::fprintf(out, "Elapsed:           %.2fs\n", cnt.total_ms * 1e-3);
+        std::fprintf(out, "Speed:             %.3f GCUPS\n", cnt.total_ms > 0 ? cells / (cnt.total_ms * 1e-3) / 1e9 : 0.0);
+        std::fprintf(out, "\n");
+      }
       if (nhits == 0) {
         std::fprintf(out, "\nNo hits.\n");
       } else {
