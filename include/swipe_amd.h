@@ -250,6 +250,10 @@ SWA_API int swa_traceback(const uint8_t* query, int64_t qlen, const uint8_t* dse
 SWA_API int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
                    int64_t keep, swa_hit_t* out, int64_t* nout);
 
+/* Same for the frame-tagged lists of swa_search_frames_topk (each shard's list ordered, shards disjoint). */
+SWA_API int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, int nlists, int64_t stride,
+                    int64_t keep, swa_fhit_t* out, int64_t* nout);
+
 /* ---- statistics (host arithmetic, bit-exact with hits.cc/stats.cc) ------------------------- */
 typedef struct {
   int available;                       /* 0: no K-A parameters for this scoring system */

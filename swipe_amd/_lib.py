@@ -54,7 +54,7 @@ EXPORTS = [
     "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_time", "swa_headers_get", "swa_headers_inclusion",
     "swa_db_set_inclusion",
     "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
-    "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge",
+    "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge", "swa_fhits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
     "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
@@ -112,6 +112,7 @@ def load():
     L.swa_translate.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, i64p]
     L.swa_traceback.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, C.POINTER(Alignment), C.c_char_p, i64, i64p]
     L.swa_hits_merge.argtypes = [C.POINTER(Hit), i64p, C.c_int, i64, i64, C.POINTER(Hit), i64p]
+    L.swa_fhits_merge.argtypes = [C.POINTER(FrameHit), i64p, C.c_int, i64, i64, C.POINTER(FrameHit), i64p]
     L.swa_stats_init.argtypes = [C.c_int, C.c_char_p, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                                  C.c_double, C.c_double, C.POINTER(Stats)]
     L.swa_evalue.argtypes = [C.POINTER(Stats), i64]

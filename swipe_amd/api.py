@@ -93,6 +93,22 @@ def merge_hits(lists: Sequence[Sequence[tuple]], keep: int):
     return [(out[i].seqno, out[i].score) for i in range(nout.value)]
 
 
+def merge_frame_hits(lists: Sequence[Sequence[tuple]], keep: int):
+    """merge_hits for (seqno, score, qstrand, qframe, dstrand, dframe) tuples"""
+    n = len(lists)
+    stride = max((len(l) for l in lists), default=0)
+    buf = (_lib.FrameHit * max(1, n * stride))()
+    counts = (C.c_int64 * max(1, n))()
+    for i, l in enumerate(lists):
+        counts[i] = len(l)
+        for j, h in enumerate(l):
+            buf[i * stride + j] = _lib.FrameHit(*[int(x) for x in h])
+    out = (_lib.FrameHit * max(1, keep))()
+    nout = C.c_int64()
+    _check(_lib.load().swa_fhits_merge(buf, counts, n, stride, keep, out, C.byref(nout)))
+    return [(h.seqno, h.score, h.qstrand, h.qframe, h.dstrand, h.dframe) for h in out[: nout.value]]
+
+
 class Database:
     """One database shard resident in the HBM of one MI355X."""
 

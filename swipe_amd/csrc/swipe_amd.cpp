@@ -1358,6 +1358,25 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   return SWA_OK;
 }
 
+// the same for frame-tagged hits: entries of one sequence all come from the shard that holds it, already in the
+// reference's order (query frame, then database frame), which a stable sort on (score, seqno) preserves
+extern "C" int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, int nlists, int64_t stride, int64_t keep,
+                               swa_fhit_t* out, int64_t* nout)
+{
+  if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
+  std::vector<swa_fhit_t> all;
+  for (int l = 0; l < nlists; ++l)
+    for (int64_t i = 0; i < counts[l]; ++i) all.push_back(lists[int64_t(l) * stride + i]);
+  std::stable_sort(all.begin(), all.end(), [](const swa_fhit_t& a, const swa_fhit_t& b) {
+    if (a.score != b.score) return a.score > b.score;
+    return a.seqno > b.seqno;
+  });
+  const size_t k = std::min<size_t>(size_t(keep), all.size());
+  for (size_t i = 0; i < k; ++i) out[i] = all[i];
+  *nout = int64_t(k);
+  return SWA_OK;
+}
+
 extern "C" int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
                               int64_t keep, swa_hit_t* out, int64_t* nout)
 {

@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-from .api import merge_hits
+from .api import merge_frame_hits, merge_hits
 
 
 def shard_bounds(offsets: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
@@ -34,21 +34,23 @@ def shard_bounds(offsets: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
-def gather_topk(local_hits: Sequence[Tuple[int, int]], keep: int, totalhits: int = 0, obvious: int = 0,
-                group=None, device=None):
+def gather_topk(local_hits: Sequence[Tuple[int, ...]], keep: int, totalhits: int = 0, obvious: int = 0,
+                group=None, device=None, width: int = 2):
     """all_gather the per-rank ordered hit lists and merge them with the reference comparator.
 
-    Returns (hits, totalhits_sum, obvious_sum) - identical on every rank."""
+    Hits are (seqno, score) pairs, or the 6-tuples of Database.search_frames_topk (translated searches); pass
+    width=6 for those.  Returns (hits, totalhits_sum, obvious_sum) - identical on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    buf = torch.zeros(keep * 2 + 3, dtype=torch.int64)
+    W = width
+    buf = torch.zeros(keep * W + 3, dtype=torch.int64)
     n = min(len(local_hits), keep)
     if n:
-        buf[: 2 * n] = torch.tensor([v for h in local_hits[:n] for v in h], dtype=torch.int64)
-    buf[2 * keep] = n
-    buf[2 * keep + 1] = totalhits
-    buf[2 * keep + 2] = obvious
+        buf[: W * n] = torch.tensor([v for h in local_hits[:n] for v in h], dtype=torch.int64)
+    buf[W * keep] = n
+    buf[W * keep + 1] = totalhits
+    buf[W * keep + 2] = obvious
     if device is not None:
         buf = buf.to(device)
     out = [torch.empty_like(buf) for _ in range(world)]
@@ -56,11 +58,11 @@ def gather_topk(local_hits: Sequence[Tuple[int, int]], keep: int, totalhits: int
     lists, tot, obv = [], 0, 0
     for t in out:
         t = t.cpu()
-        k = int(t[2 * keep])
-        lists.append([(int(t[2 * i]), int(t[2 * i + 1])) for i in range(k)])
-        tot += int(t[2 * keep + 1])
-        obv += int(t[2 * keep + 2])
-    return merge_hits(lists, keep), tot, obv
+        k = int(t[W * keep])
+        lists.append([tuple(int(t[W * i + j]) for j in range(W)) for i in range(k)])
+        tot += int(t[W * keep + 1])
+        obv += int(t[W * keep + 2])
+    return (merge_hits(lists, keep) if W == 2 else merge_frame_hits(lists, keep)), tot, obv
 
 
 def align_sharded(db, query, hits: Sequence[Tuple[int, int]], first: int, last: int, dstrands=None, dframes=None,

@@ -287,3 +287,29 @@ def test_definition_lines_masks_and_taxid_filters_match_reference(tmp_path, vari
     size = [l for l in ref["db_lines"] if l.startswith("Database size")][0]
     assert size == "Database size:     %d residues in %d sequences" % (info["masked_symcount"], info["masked_seqcount"])
     assert [l for l in ref["db_lines"] if l.startswith("Database title")][0] == "Database title:    " + info["title"]
+
+
+@pytest.mark.parametrize("name", [f.__name__[5:] for f in cases.TRANSLATED])
+def test_frame_hit_merge_over_shards_equals_single_list(name):
+    """multi-GPU translated search: per-shard frame-tagged top-K lists merged by swa_fhits_merge equal the
+    reference CLI's single list (sequence, score and frame labels in order)."""
+    from conftest import load_golden
+    case, g = cases.get(name), load_golden(name)
+    cli = g["cli"]["1"]
+    nsym = int(sum(len(s) for s in case.seqs))
+    cut = len(case.seqs) // 2 + 3
+    lists = []
+    for lo, hi in ((0, cut), (cut, len(case.seqs))):
+        h = oracle.HitList(descriptions=case.keep, alignments=0, symtype=case.sym, matrix=case.matrix, gapopen=case.gapopen,
+                           gapextend=case.gapextend, qlen=len(case.query), dbseqs=len(case.seqs), dbsyms=nsym)
+        for qt in sorted({r[1] for r in g["raw"]}):
+            for r in g["raw"]:
+                if r[1] == qt and lo <= r[0] < hi:
+                    h.enter(r[0], r[8], qt // 3, qt % 3, r[2] // 3, r[2] % 3)
+        lists.append(h.full())
+    merged = swipe_amd.merge_frame_hits(lists, len(cli["seqno"]))
+    assert [m[0] for m in merged] == cli["seqno"] and [m[1] for m in merged] == cli["score"]
+    lab = lambda s, f: "%s%d" % ("-" if s else "+", f + 1)
+    got = [lab(m[2], m[3]) if case.sym == 2 else lab(m[4], m[5]) if case.sym == 3 else lab(m[2], m[3]) + "/" + lab(m[4], m[5])
+           for m in merged]
+    assert got == cli["strand"]
