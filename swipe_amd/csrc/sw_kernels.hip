@@ -577,29 +577,37 @@ static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, 
 }
 extern "C" int swa_narrow_rows_for(int qlen)
 {
-  // rows per lane: multiples of 4 up to 48 for the row-shifted kernel (16 K rows per pass), 64 for the plain one
+  // rows per lane of the plain kernel: multiples of 4 up to 48 (16 K rows per pass), then 64
   const int k = 4 * ((qlen + 63) / 64);
   if (k <= 0) return 4;
   if (k <= 48) return k;
   return qlen <= 1024 ? 64 : 0;
 }
+// rows per lane of the row-shifted kernel: exactly ceil(qlen / 16), every value 1..48 is instantiated, so
+// at most 15 padding rows are computed whatever the query length (0 = too long for one pass)
+extern "C" int swa_narrow_rows_exact(int qlen)
+{
+  const int k = (qlen + 15) / 16;
+  return k < 1 ? 1 : k <= 48 ? k : 0;
+}
+// resident waves per SIMD the register budget of K rows per lane allows (3 registers per row + profile units)
+static constexpr int shifted_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 32 ? 3 : 2; }
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
+#define SWA_SHIFTED_CASE(KK) case KK: return launch_narrow_shifted<KK, shifted_waves_for(KK)>(*p, blocks, st);
   if (p->shifted) switch (K) {
-    case 4:  return launch_narrow_shifted<4, 8>(*p, blocks, st);
-    case 8:  return launch_narrow_shifted<8, 8>(*p, blocks, st);
-    case 12: return launch_narrow_shifted<12, 6>(*p, blocks, st);
-    case 16: return launch_narrow_shifted<16, 4>(*p, blocks, st);
-    case 20: return launch_narrow_shifted<20, 4>(*p, blocks, st);
+    SWA_SHIFTED_CASE(1) SWA_SHIFTED_CASE(2) SWA_SHIFTED_CASE(3) SWA_SHIFTED_CASE(4) SWA_SHIFTED_CASE(5) SWA_SHIFTED_CASE(6)
+    SWA_SHIFTED_CASE(7) SWA_SHIFTED_CASE(8) SWA_SHIFTED_CASE(9) SWA_SHIFTED_CASE(10) SWA_SHIFTED_CASE(11) SWA_SHIFTED_CASE(12)
+    SWA_SHIFTED_CASE(13) SWA_SHIFTED_CASE(14) SWA_SHIFTED_CASE(15) SWA_SHIFTED_CASE(16) SWA_SHIFTED_CASE(17) SWA_SHIFTED_CASE(18)
+    SWA_SHIFTED_CASE(19) SWA_SHIFTED_CASE(20) SWA_SHIFTED_CASE(21) SWA_SHIFTED_CASE(22) SWA_SHIFTED_CASE(23)
     case 24: return p->waves == 4 ? launch_narrow_shifted<24, 4>(*p, blocks, st) : launch_narrow_shifted<24, 3>(*p, blocks, st);
-    case 28: return launch_narrow_shifted<28, 3>(*p, blocks, st);
-    case 32: return launch_narrow_shifted<32, 3>(*p, blocks, st);
-    case 36: return launch_narrow_shifted<36, 2>(*p, blocks, st);
-    case 40: return launch_narrow_shifted<40, 2>(*p, blocks, st);
-    case 44: return launch_narrow_shifted<44, 2>(*p, blocks, st);
-    case 48: return launch_narrow_shifted<48, 2>(*p, blocks, st);
+    SWA_SHIFTED_CASE(25) SWA_SHIFTED_CASE(26) SWA_SHIFTED_CASE(27) SWA_SHIFTED_CASE(28) SWA_SHIFTED_CASE(29) SWA_SHIFTED_CASE(30)
+    SWA_SHIFTED_CASE(31) SWA_SHIFTED_CASE(32) SWA_SHIFTED_CASE(33) SWA_SHIFTED_CASE(34) SWA_SHIFTED_CASE(35) SWA_SHIFTED_CASE(36)
+    SWA_SHIFTED_CASE(37) SWA_SHIFTED_CASE(38) SWA_SHIFTED_CASE(39) SWA_SHIFTED_CASE(40) SWA_SHIFTED_CASE(41) SWA_SHIFTED_CASE(42)
+    SWA_SHIFTED_CASE(43) SWA_SHIFTED_CASE(44) SWA_SHIFTED_CASE(45) SWA_SHIFTED_CASE(46) SWA_SHIFTED_CASE(47) SWA_SHIFTED_CASE(48)
     default: return hipErrorInvalidValue;
   }
+#undef SWA_SHIFTED_CASE
   switch (K) {
     case 4:  return launch_narrow<4>(*p, blocks, st);
     case 8:  return launch_narrow<8>(*p, blocks, st);

@@ -25,6 +25,7 @@
 
 extern "C" {
 int swa_narrow_rows_for(int qlen);
+int swa_narrow_rows_exact(int qlen);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
@@ -481,8 +482,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
   const bool single_pass = qlen <= 16 * 48 && K > 0 && !force_mp;
+  const int Kx = swa_narrow_rows_exact(int(std::min<int64_t>(qlen, 4096)));  // row-shifted kernel: ceil(qlen / 16) rows per lane
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  if (f16 && single_pass && f16_limit(db, K) >= 1024 && db->narrow_variant != 1) {
+  if (f16 && single_pass && Kx > 0 && f16_limit(db, Kx) >= 1024 && db->narrow_variant != 1) {
+    const int K = Kx;
     swa_narrow_params p{};
     p.query = db->query.p;
     p.stream = db->main.stream.p;

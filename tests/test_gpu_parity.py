@@ -142,6 +142,26 @@ def test_every_rows_per_lane_variant(qlen):
     db.close()
 
 
+def test_every_instantiation_of_the_row_shifted_kernel():
+    """rows per lane K = ceil(qlen / 16) for every K in 1..48: one query per instantiation, at both ends of its
+    16-row window, against one resident database"""
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(99, 1, 768, rtab)
+    res, off = swipe_amd.synth_db(6, 400, query=full)
+    seqs = [res[off[i]:off[i + 1]] for i in range(400)] + [full, full[100:500].copy(), full[::-1].copy(), np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    for K in range(1, 49):
+        for qlen in (16 * K - 15, 16 * K):
+            q = full[:qlen]
+            scores, c = db.search(q)
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == 1
+            assert np.array_equal(scores, oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)), (K, qlen)
+    db.close()
+
+
 @pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("gaps", [(11, 1), (5, 2), (0, 3), (14, 4), (30, 20)])
 def test_both_narrow_kernel_forms(monkeypatch, variant, gaps):
