@@ -368,6 +368,162 @@ swa_narrow_shifted_kernel(swa_narrow_params p)
   }
 }
 
+// ------------------------------------------------------------------ row-shifted kernel, 8 lanes per sequence pair
+// For queries of at most 8 * 48 rows the systolic chain is cut to 8 lanes: a 16-lane DPP row then carries TWO
+// sequence pairs (lanes 0-7 and 8-15), a wave 8 pairs = two consecutive batches of the same stream, and a
+// lane owns K = ceil(qlen / 8) rows.  Twice the rows per lane halves the per-step overhead (the DPP hand-overs
+// and residue addressing are per lane and step, not per row), the pipeline skew to drain is 8 steps instead of
+// 16, and K is exact to 8 rows instead of 16.  Differences to swa_narrow_shifted_kernel:
+//   * row_shr:1 would carry lane 7's hand-over into lane 8, the first lane of the neighbouring pair.  Lane 7
+//     has no successor, so it simply sends zeros: hsend / fsend are one v_pk_fma_f16 with per-lane constants
+//     (1, -K R) or (0, 0) instead of one v_pk_add_f16 - no extra instruction, and zero is exactly the boundary
+//     lane 8 must see.  Only the residue shift register needs a select for lane 8 (one v_cndmask per step);
+//   * a 16-byte LDS unit is stored once per HALF row: unit (d*C + c)*16 + l serves lane l & 7 of either half,
+//     so the two pairs of a DPP row read disjoint bank halves (l >= 8: upper 128 bytes) - conflict-free as before;
+//   * the residue register of a lane is refilled every 8 steps from the 16-column chunks of ITS batch.
+template <int K>
+__device__ __forceinline__ void build_profile_f16_half(unsigned char* lds, const swa_query* q, float add)
+{
+  constexpr int C = (K + 7) / 8;
+  unsigned short* t = (unsigned short*)lds;
+  const int total = 32 * C * 16 * 8;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int k = e & 7, l = (e >> 3) & 7, c = (e >> 7) % C, d = (e >> 7) / C;     // bit 6 of e: which half row
+    const int local = c * 8 + k;
+    const int row = l * K + local;
+    float v = -1.0f;
+    if (local < K && row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
+    t[e] = (unsigned short)float_to_half_bits(v + add);
+  }
+}
+
+template <int K, int W>
+__global__ void __launch_bounds__(256, W)
+swa_narrow_shifted8_kernel(swa_narrow_params p)
+{
+  constexpr int C = (K + 7) / 8;
+  constexpr u32 CS = C * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  build_profile_f16_half<K>(lds, p.query, p.gapextend_f);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int l8 = lane & 7, pairno = lane >> 3;            // pair 0..7 of the wave: batch 2w + (pairno >> 2), row pairno & 3
+  const u32 l16 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (u32)(lane & 15) * 16;
+  const bool second_half = (lane & 15) == 8;              // first lane of the upper pair of a DPP row
+  const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR);
+  const h2 zero = {0, 0};
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  const h2 send_mul = l8 == 7 ? zero : one;               // the last lane of a pair hands nothing on
+  const h2 send_add = l8 == 7 ? zero : as_h2(p.negKR);
+  const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
+  const u32 PADRAW = SWA_PAD | (SWA_PAD << 8);
+
+  for (;;) {
+    int w = 0;
+    if (lane == 0) w = atomicAdd(p.counter, 1);
+    w = __builtin_amdgcn_readfirstlane(w);
+    const int b0 = 2 * w;
+    if (b0 >= p.nbatches) break;
+    const swa_batch bd0 = p.batches[b0];
+    swa_batch bd1;
+    bd1.offset = 0;
+    bd1.steps = 0;
+    if (b0 + 1 < p.nbatches) bd1 = p.batches[b0 + 1];
+    const int steps = bd0.steps > bd1.steps ? bd0.steps : bd1.steps;
+    const bool upper = pairno >= 4;                       // this lane works on batch b0 + 1
+    const int mychunks = ((upper ? bd1.steps : bd0.steps) + 15) >> 4;
+    const uint16_t* s = p.stream + (int64_t)(upper ? bd1.offset : bd0.offset) * 64 + (pairno & 3) * 16 + l8;
+    const int total = steps + 8;                          // + drain of the 7-step skew, kept even
+
+    h2 H[K], E[K], SR[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r + 1]); E[r] = H[r]; SR[r] = H[r]; }
+    h2 diag = zero, hsend = zero, fsend = zero;
+    u32 cur = PADOFF;
+    u32 raw = mychunks > 0 ? (u32)s[0] : PADRAW;
+
+#define SWA_STEP8(ODD)                                                                         \
+    {                                                                                          \
+      const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
+      const u32 shifted = row_shr1(cur, pl);                                                   \
+      cur = second_half ? pl : shifted;                                                        \
+      pl = pl2;                                                                                \
+      const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+      h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+      h2 hd = diag;                                                                            \
+      diag = hup;                                                                              \
+      const u32 aoff = (cur & 0xFFFF) | l16;                                                   \
+      const u32 boff = (cur >> 16) | l16;                                                      \
+      u4v pa[C], pb[C];                                                                        \
+      _Pragma("unroll") for (int c = 0; c < C; ++c) {                                          \
+        pa[c] = *(lds_u4_ptr)(uintptr_t)(aoff + c * 256);                                      \
+        pb[c] = *(lds_u4_ptr)(uintptr_t)(boff + c * 256);                                      \
+      }                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < K; ++r) {                                          \
+        const int c = r >> 3, k = r & 7;                                                       \
+        const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;          \
+        const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;          \
+        const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u)); \
+        const h2 h = pk_max3(hd + sc, E[r], F);                                                \
+        hd = H[r];                                                                             \
+        if (ODD) SR[r] = pk_max3(SR[r], hd, h);                                                \
+        H[r] = h;                                                                              \
+        const h2 t = h + negQR;                                                                \
+        F = pk_max(F, t);                                                                      \
+        E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2])) + negR;                                  \
+      }                                                                                        \
+      hsend = __builtin_elementwise_fma(H[K - 1], send_mul, send_add);                         \
+      fsend = __builtin_elementwise_fma(F, send_mul, send_add);                                \
+    }
+
+    for (int m = 0; m * 8 < total; ++m) {                 // m-th block of 8 columns: half (m & 1) of chunk m >> 1
+      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+      const int mn = m + 1;
+      raw = ((mn >> 1) < mychunks) ? (u32)s[(int64_t)(mn >> 1) * 64 + (mn & 1) * 8] : PADRAW;
+      const int n = total - m * 8 < 8 ? total - m * 8 : 8;
+      for (int u = 0; u < n; u += 2) {
+        SWA_STEP8(0)
+        SWA_STEP8(1)
+      }
+    }
+#undef SWA_STEP8
+
+    h2 S = zero;
+#pragma unroll
+    for (int r = 0; r < K; ++r) S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
+    // max over the 8 lanes of a pair: shifts of 1, 2, 4 reach back exactly 7 lanes, so lanes 7 and 15 of a
+    // row end up with the maxima of lanes 0-7 and 8-15
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
+    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
+    {
+      const bool writer = l8 == 7;
+      const int b = b0 + (upper ? 1 : 0);
+      int sA = -1, sB = -1, idA = -1, idB = -1;
+      if (writer && b < p.nbatches) {
+        idA = p.slots[(int64_t)b * SWA_SLOTS + (pairno & 3) * 2];
+        idB = p.slots[(int64_t)b * SWA_SLOTS + (pairno & 3) * 2 + 1];
+        sA = (int)(float)S.x;
+        sB = (int)(float)S.y;
+        if (idA >= 0) p.scores[idA] = sA;
+        if (idB >= 0) p.scores[idB] = sB;
+      }
+      const bool oA = idA >= 0 && sA >= p.limit, oB = idB >= 0 && sB >= p.limit;
+      const u64 mA = __ballot(oA), mB = __ballot(oB);
+      const int nA = __popcll(mA), nB = __popcll(mB);
+      if (nA + nB) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(p.ovf_count, nA + nB);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const u64 below = (1ull << lane) - 1;
+        if (oA) p.ovf_list[base + __popcll(mA & below)] = idA;
+        if (oB) p.ovf_list[base + nA + __popcll(mB & below)] = idB;
+      }
+    }
+  }
+}
+
 #include "sw_mp_kernel.inc"
 
 // ------------------------------------------------------------------ hit filter
@@ -575,6 +731,15 @@ static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, 
   hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
+template <int K, int W>
+static hipError_t launch_narrow_shifted8(const swa_narrow_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted8_kernel<K, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((swa_narrow_shifted8_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
 extern "C" int swa_narrow_rows_for(int qlen)
 {
   // rows per lane of the plain kernel: multiples of 4 up to 48 (16 K rows per pass), then 64
@@ -592,6 +757,27 @@ extern "C" int swa_narrow_rows_exact(int qlen)
 }
 // resident waves per SIMD the register budget of K rows per lane allows (3 registers per row + profile units)
 static constexpr int shifted_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 32 ? 3 : 2; }
+static constexpr int half_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 31 ? 3 : 2; }
+// 8-lane form: K = ceil(qlen / 8) rows per lane for queries of at most 384 rows
+extern "C" int swa_narrow_rows_half(int qlen)
+{
+  const int k = (qlen + 7) / 8;
+  return k < 1 ? 1 : k <= 48 ? k : 0;
+}
+extern "C" hipError_t swa_launch_narrow8(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_S8_CASE(KK) case KK: return launch_narrow_shifted8<KK, half_waves_for(KK)>(*p, blocks, st);
+  switch (K) {
+    SWA_S8_CASE(1) SWA_S8_CASE(2) SWA_S8_CASE(3) SWA_S8_CASE(4) SWA_S8_CASE(5) SWA_S8_CASE(6) SWA_S8_CASE(7) SWA_S8_CASE(8)
+    SWA_S8_CASE(9) SWA_S8_CASE(10) SWA_S8_CASE(11) SWA_S8_CASE(12) SWA_S8_CASE(13) SWA_S8_CASE(14) SWA_S8_CASE(15) SWA_S8_CASE(16)
+    SWA_S8_CASE(17) SWA_S8_CASE(18) SWA_S8_CASE(19) SWA_S8_CASE(20) SWA_S8_CASE(21) SWA_S8_CASE(22) SWA_S8_CASE(23) SWA_S8_CASE(24)
+    SWA_S8_CASE(25) SWA_S8_CASE(26) SWA_S8_CASE(27) SWA_S8_CASE(28) SWA_S8_CASE(29) SWA_S8_CASE(30) SWA_S8_CASE(31) SWA_S8_CASE(32)
+    SWA_S8_CASE(33) SWA_S8_CASE(34) SWA_S8_CASE(35) SWA_S8_CASE(36) SWA_S8_CASE(37) SWA_S8_CASE(38) SWA_S8_CASE(39) SWA_S8_CASE(40)
+    SWA_S8_CASE(41) SWA_S8_CASE(42) SWA_S8_CASE(43) SWA_S8_CASE(44) SWA_S8_CASE(45) SWA_S8_CASE(46) SWA_S8_CASE(47) SWA_S8_CASE(48)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_S8_CASE
+}
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
 #define SWA_SHIFTED_CASE(KK) case KK: return launch_narrow_shifted<KK, shifted_waves_for(KK)>(*p, blocks, st);

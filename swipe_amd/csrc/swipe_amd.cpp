@@ -26,6 +26,8 @@
 extern "C" {
 int swa_narrow_rows_for(int qlen);
 int swa_narrow_rows_exact(int qlen);
+int swa_narrow_rows_half(int qlen);
+hipError_t swa_launch_narrow8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
@@ -484,8 +486,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   const bool single_pass = qlen <= 16 * 48 && K > 0 && !force_mp;
   const int Kx = swa_narrow_rows_exact(int(std::min<int64_t>(qlen, 4096)));  // row-shifted kernel: ceil(qlen / 16) rows per lane
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  if (f16 && single_pass && Kx > 0 && f16_limit(db, Kx) >= 1024 && db->narrow_variant != 1) {
-    const int K = Kx;
+  // queries of at most 384 rows: 8 lanes per sequence pair, K = ceil(qlen / 8) (SWA_LANES=16 forces the 16-lane form)
+  const char* lanes_env = std::getenv("SWA_LANES");
+  const int K8 = (lanes_env && std::atoi(lanes_env) == 16) ? 0 : swa_narrow_rows_half(int(std::min<int64_t>(qlen, 4096)));
+  const bool half = K8 > 0 && f16_limit(db, K8) >= 1024;
+  if (f16 && single_pass && (half || (Kx > 0 && f16_limit(db, Kx) >= 1024)) && db->narrow_variant != 1) {
+    const int K = half ? K8 : Kx;
     swa_narrow_params p{};
     p.query = db->query.p;
     p.stream = db->main.stream.p;
@@ -505,11 +511,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.negKR = f16_pair(-float(int64_t(K) * db->ge));
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
-    c.narrow_shifted = 1;
-    int blocks = persistent_blocks(db, p.nbatches);
+    c.narrow_shifted = half ? 2 : 1;
+    const int items = half ? (p.nbatches + 1) / 2 : p.nbatches;    // the 8-lane form takes two batches per wave
+    int blocks = persistent_blocks(db, items);
     if (const char* w = std::getenv("SWA_WAVES")) p.waves = std::atoi(w);
-    if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((p.nbatches + 3) / 4, db->cus * std::atoi(w)));
-    HIP_TRY(swa_launch_narrow(K, &p, blocks, st));
+    if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((items + 3) / 4, db->cus * std::atoi(w)));
+    HIP_TRY(half ? swa_launch_narrow8(K, &p, blocks, st) : swa_launch_narrow(K, &p, blocks, st));
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range

@@ -142,9 +142,11 @@ def test_every_rows_per_lane_variant(qlen):
     db.close()
 
 
-def test_every_instantiation_of_the_row_shifted_kernel():
-    """rows per lane K = ceil(qlen / 16) for every K in 1..48: one query per instantiation, at both ends of its
-    16-row window, against one resident database"""
+@pytest.mark.parametrize("lanes", [16, 8])
+def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
+    """rows per lane K = ceil(qlen / lanes) for every K in 1..48 of both forms (16 lanes per sequence pair, and 8 for
+    queries of at most 384 rows): one query per instantiation, at both ends of its window, one resident database"""
+    monkeypatch.setenv("SWA_LANES", str(lanes))
     rtab = synth.residue_table_protein()
     full = synth._random_residues(99, 1, 768, rtab)
     res, off = swipe_amd.synth_db(6, 400, query=full)
@@ -154,10 +156,10 @@ def test_every_instantiation_of_the_row_shifted_kernel():
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     Mo = oracle.matrix_builtin("BLOSUM62")
     for K in range(1, 49):
-        for qlen in (16 * K - 15, 16 * K):
+        for qlen in (lanes * K - lanes + 1, lanes * K):
             q = full[:qlen]
             scores, c = db.search(q)
-            assert c["narrow_rows"] == K and c["narrow_shifted"] == 1
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == (1 if lanes == 16 else 2)
             assert np.array_equal(scores, oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)), (K, qlen)
     db.close()
 
