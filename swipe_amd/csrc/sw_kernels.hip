@@ -368,27 +368,28 @@ swa_narrow_shifted_kernel(swa_narrow_params p)
   }
 }
 
-// ------------------------------------------------------------------ row-shifted kernel, 8 lanes per sequence pair
-// For queries of at most 8 * 48 rows the systolic chain is cut to 8 lanes: a 16-lane DPP row then carries TWO
-// sequence pairs (lanes 0-7 and 8-15), a wave 8 pairs = two consecutive batches of the same stream, and a
-// lane owns K = ceil(qlen / 8) rows.  Twice the rows per lane halves the per-step overhead (the DPP hand-overs
-// and residue addressing are per lane and step, not per row), the pipeline skew to drain is 8 steps instead of
-// 16, and K is exact to 8 rows instead of 16.  Differences to swa_narrow_shifted_kernel:
-//   * row_shr:1 would carry lane 7's hand-over into lane 8, the first lane of the neighbouring pair.  Lane 7
-//     has no successor, so it simply sends zeros: hsend / fsend are one v_pk_fma_f16 with per-lane constants
-//     (1, -K R) or (0, 0) instead of one v_pk_add_f16 - no extra instruction, and zero is exactly the boundary
-//     lane 8 must see.  Only the residue shift register needs a select for lane 8 (one v_cndmask per step);
-//   * a 16-byte LDS unit is stored once per HALF row: unit (d*C + c)*16 + l serves lane l & 7 of either half,
-//     so the two pairs of a DPP row read disjoint bank halves (l >= 8: upper 128 bytes) - conflict-free as before;
-//   * the residue register of a lane is refilled every 8 steps from the 16-column chunks of ITS batch.
-template <int K>
-__device__ __forceinline__ void build_profile_f16_half(unsigned char* lds, const swa_query* q, float add)
+// ------------------------------------------------------------------ row-shifted kernel, G = 8 or 4 lanes per sequence pair
+// For short queries the systolic chain is cut to G lanes: a 16-lane DPP row then carries 16 / G sequence
+// pairs, a wave 64 / G pairs = 16 / G consecutive batches of the same stream, and a lane owns K = ceil(qlen / G)
+// rows (G = 8: queries up to 384 rows, G = 4: up to 192).  More rows per lane shrink the per-step overhead
+// (DPP hand-overs and residue addressing are per lane and step, not per row), the pipeline skew to drain is G
+// steps instead of 16, and K is exact to G rows.  Differences to swa_narrow_shifted_kernel:
+//   * row_shr:1 would carry the hand-over of a pair's last lane into the first lane of the neighbouring pair.
+//     The last lane has no successor, so it simply sends zeros: hsend / fsend are one v_pk_fma_f16 with per-lane
+//     constants (1, -K R) or (0, 0) instead of one v_pk_add_f16 - no extra instruction, and zero is exactly the
+//     boundary the neighbour's first lane must see.  Only the residue shift register needs a select there
+//     (one v_cndmask per step);
+//   * a 16-byte LDS unit is stored once per pair position of a DPP row: unit (d*C + c)*16 + l serves lane
+//     l & (G-1) of each pair, so the pairs of a row read disjoint bank groups - conflict-free as before;
+//   * the residue register of a lane is refilled every G steps from the 16-column chunks of ITS batch.
+template <int K, int G>
+__device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, const swa_query* q, float add)
 {
   constexpr int C = (K + 7) / 8;
   unsigned short* t = (unsigned short*)lds;
   const int total = 32 * C * 16 * 8;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int k = e & 7, l = (e >> 3) & 7, c = (e >> 7) % C, d = (e >> 7) / C;     // bit 6 of e: which half row
+    const int k = e & 7, l = (e >> 3) & (G - 1), c = (e >> 7) % C, d = (e >> 7) / C;
     const int local = c * 8 + k;
     const int row = l * K + local;
     float v = -1.0f;
@@ -397,25 +398,26 @@ __device__ __forceinline__ void build_profile_f16_half(unsigned char* lds, const
   }
 }
 
-template <int K, int W>
+template <int K, int W, int G>
 __global__ void __launch_bounds__(256, W)
-swa_narrow_shifted8_kernel(swa_narrow_params p)
+swa_narrow_split_kernel(swa_narrow_params p)
 {
   constexpr int C = (K + 7) / 8;
   constexpr u32 CS = C * 256;
+  constexpr int NB = 16 / G;                              // batches per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  build_profile_f16_half<K>(lds, p.query, p.gapextend_f);
+  build_profile_f16_split<K, G>(lds, p.query, p.gapextend_f);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int l8 = lane & 7, pairno = lane >> 3;            // pair 0..7 of the wave: batch 2w + (pairno >> 2), row pairno & 3
+  const int lg = lane & (G - 1), pairno = lane / G;       // pair of the wave: batch pairno >> 2, row pairno & 3
   const u32 l16 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (u32)(lane & 15) * 16;
-  const bool second_half = (lane & 15) == 8;              // first lane of the upper pair of a DPP row
+  const bool inner_first = lg == 0 && (lane & 15) != 0;   // first lane of a pair that is not first in its DPP row
   const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR);
   const h2 zero = {0, 0};
   const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-  const h2 send_mul = l8 == 7 ? zero : one;               // the last lane of a pair hands nothing on
-  const h2 send_add = l8 == 7 ? zero : as_h2(p.negKR);
+  const h2 send_mul = lg == G - 1 ? zero : one;           // the last lane of a pair hands nothing on
+  const h2 send_add = lg == G - 1 ? zero : as_h2(p.negKR);
   const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
   const u32 PADRAW = SWA_PAD | (SWA_PAD << 8);
 
@@ -423,18 +425,20 @@ swa_narrow_shifted8_kernel(swa_narrow_params p)
     int w = 0;
     if (lane == 0) w = atomicAdd(p.counter, 1);
     w = __builtin_amdgcn_readfirstlane(w);
-    const int b0 = 2 * w;
+    const int b0 = NB * w;
     if (b0 >= p.nbatches) break;
-    const swa_batch bd0 = p.batches[b0];
-    swa_batch bd1;
-    bd1.offset = 0;
-    bd1.steps = 0;
-    if (b0 + 1 < p.nbatches) bd1 = p.batches[b0 + 1];
-    const int steps = bd0.steps > bd1.steps ? bd0.steps : bd1.steps;
-    const bool upper = pairno >= 4;                       // this lane works on batch b0 + 1
-    const int mychunks = ((upper ? bd1.steps : bd0.steps) + 15) >> 4;
-    const uint16_t* s = p.stream + (int64_t)(upper ? bd1.offset : bd0.offset) * 64 + (pairno & 3) * 16 + l8;
-    const int total = steps + 8;                          // + drain of the 7-step skew, kept even
+    int steps = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (b0 + i < p.nbatches) { const int st = p.batches[b0 + i].steps; steps = st > steps ? st : steps; }
+    const int b = b0 + (pairno >> 2);                     // this lane's batch
+    swa_batch bd;
+    bd.offset = 0;
+    bd.steps = 0;
+    if (b < p.nbatches) bd = p.batches[b];
+    const int mychunks = (bd.steps + 15) >> 4;
+    const uint16_t* s = p.stream + (int64_t)bd.offset * 64 + (pairno & 3) * 16 + lg;
+    const int total = steps + G;                          // + drain of the (G-1)-step skew, kept even
 
     h2 H[K], E[K], SR[K];
 #pragma unroll
@@ -443,11 +447,11 @@ swa_narrow_shifted8_kernel(swa_narrow_params p)
     u32 cur = PADOFF;
     u32 raw = mychunks > 0 ? (u32)s[0] : PADRAW;
 
-#define SWA_STEP8(ODD)                                                                         \
+#define SWA_STEPG(ODD)                                                                         \
     {                                                                                          \
       const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
       const u32 shifted = row_shr1(cur, pl);                                                   \
-      cur = second_half ? pl : shifted;                                                        \
+      cur = inner_first ? pl : shifted;                                                        \
       pl = pl2;                                                                                \
       const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
       h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
@@ -477,29 +481,28 @@ swa_narrow_shifted8_kernel(swa_narrow_params p)
       fsend = __builtin_elementwise_fma(F, send_mul, send_add);                                \
     }
 
-    for (int m = 0; m * 8 < total; ++m) {                 // m-th block of 8 columns: half (m & 1) of chunk m >> 1
+    for (int m = 0; m * G < total; ++m) {                 // m-th block of G columns of the 16-column chunks
       u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
-      const int mn = m + 1;
-      raw = ((mn >> 1) < mychunks) ? (u32)s[(int64_t)(mn >> 1) * 64 + (mn & 1) * 8] : PADRAW;
-      const int n = total - m * 8 < 8 ? total - m * 8 : 8;
+      const int col = (m + 1) * G;
+      raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW;
+      const int n = total - m * G < G ? total - m * G : G;
       for (int u = 0; u < n; u += 2) {
-        SWA_STEP8(0)
-        SWA_STEP8(1)
+        SWA_STEPG(0)
+        SWA_STEPG(1)
       }
     }
-#undef SWA_STEP8
+#undef SWA_STEPG
 
     h2 S = zero;
 #pragma unroll
     for (int r = 0; r < K; ++r) S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
-    // max over the 8 lanes of a pair: shifts of 1, 2, 4 reach back exactly 7 lanes, so lanes 7 and 15 of a
-    // row end up with the maxima of lanes 0-7 and 8-15
+    // max over the G lanes of a pair: shifts of 1, 2 (, 4) reach back exactly G - 1 lanes, so the last lane of
+    // every pair ends up with the maximum of its own pair only
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
-    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
+    if (G == 8) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
     {
-      const bool writer = l8 == 7;
-      const int b = b0 + (upper ? 1 : 0);
+      const bool writer = lg == G - 1;
       int sA = -1, sB = -1, idA = -1, idB = -1;
       if (writer && b < p.nbatches) {
         idA = p.slots[(int64_t)b * SWA_SLOTS + (pairno & 3) * 2];
@@ -731,13 +734,13 @@ static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, 
   hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
-template <int K, int W>
-static hipError_t launch_narrow_shifted8(const swa_narrow_params& p, int blocks, hipStream_t st)
+template <int K, int W, int G>
+static hipError_t launch_narrow_split(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
   const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted8_kernel<K, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_split_kernel<K, W, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((swa_narrow_shifted8_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((swa_narrow_split_kernel<K, W, G>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
 extern "C" int swa_narrow_rows_for(int qlen)
@@ -757,26 +760,30 @@ extern "C" int swa_narrow_rows_exact(int qlen)
 }
 // resident waves per SIMD the register budget of K rows per lane allows (3 registers per row + profile units)
 static constexpr int shifted_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 32 ? 3 : 2; }
-static constexpr int half_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 31 ? 3 : 2; }
-// 8-lane form: K = ceil(qlen / 8) rows per lane for queries of at most 384 rows
-extern "C" int swa_narrow_rows_half(int qlen)
+static constexpr int split_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 31 ? 3 : 2; }
+// G-lane form: K = ceil(qlen / G) rows per lane, at most 48 (0 = query too long for this G)
+extern "C" int swa_narrow_rows_split(int qlen, int G)
 {
-  const int k = (qlen + 7) / 8;
+  const int k = (qlen + G - 1) / G;
   return k < 1 ? 1 : k <= 48 ? k : 0;
 }
-extern "C" hipError_t swa_launch_narrow8(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+template <int G> static hipError_t launch_split_any(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-#define SWA_S8_CASE(KK) case KK: return launch_narrow_shifted8<KK, half_waves_for(KK)>(*p, blocks, st);
+#define SWA_SG_CASE(KK) case KK: return launch_narrow_split<KK, split_waves_for(KK), G>(*p, blocks, st);
   switch (K) {
-    SWA_S8_CASE(1) SWA_S8_CASE(2) SWA_S8_CASE(3) SWA_S8_CASE(4) SWA_S8_CASE(5) SWA_S8_CASE(6) SWA_S8_CASE(7) SWA_S8_CASE(8)
-    SWA_S8_CASE(9) SWA_S8_CASE(10) SWA_S8_CASE(11) SWA_S8_CASE(12) SWA_S8_CASE(13) SWA_S8_CASE(14) SWA_S8_CASE(15) SWA_S8_CASE(16)
-    SWA_S8_CASE(17) SWA_S8_CASE(18) SWA_S8_CASE(19) SWA_S8_CASE(20) SWA_S8_CASE(21) SWA_S8_CASE(22) SWA_S8_CASE(23) SWA_S8_CASE(24)
-    SWA_S8_CASE(25) SWA_S8_CASE(26) SWA_S8_CASE(27) SWA_S8_CASE(28) SWA_S8_CASE(29) SWA_S8_CASE(30) SWA_S8_CASE(31) SWA_S8_CASE(32)
-    SWA_S8_CASE(33) SWA_S8_CASE(34) SWA_S8_CASE(35) SWA_S8_CASE(36) SWA_S8_CASE(37) SWA_S8_CASE(38) SWA_S8_CASE(39) SWA_S8_CASE(40)
-    SWA_S8_CASE(41) SWA_S8_CASE(42) SWA_S8_CASE(43) SWA_S8_CASE(44) SWA_S8_CASE(45) SWA_S8_CASE(46) SWA_S8_CASE(47) SWA_S8_CASE(48)
+    SWA_SG_CASE(1) SWA_SG_CASE(2) SWA_SG_CASE(3) SWA_SG_CASE(4) SWA_SG_CASE(5) SWA_SG_CASE(6) SWA_SG_CASE(7) SWA_SG_CASE(8)
+    SWA_SG_CASE(9) SWA_SG_CASE(10) SWA_SG_CASE(11) SWA_SG_CASE(12) SWA_SG_CASE(13) SWA_SG_CASE(14) SWA_SG_CASE(15) SWA_SG_CASE(16)
+    SWA_SG_CASE(17) SWA_SG_CASE(18) SWA_SG_CASE(19) SWA_SG_CASE(20) SWA_SG_CASE(21) SWA_SG_CASE(22) SWA_SG_CASE(23) SWA_SG_CASE(24)
+    SWA_SG_CASE(25) SWA_SG_CASE(26) SWA_SG_CASE(27) SWA_SG_CASE(28) SWA_SG_CASE(29) SWA_SG_CASE(30) SWA_SG_CASE(31) SWA_SG_CASE(32)
+    SWA_SG_CASE(33) SWA_SG_CASE(34) SWA_SG_CASE(35) SWA_SG_CASE(36) SWA_SG_CASE(37) SWA_SG_CASE(38) SWA_SG_CASE(39) SWA_SG_CASE(40)
+    SWA_SG_CASE(41) SWA_SG_CASE(42) SWA_SG_CASE(43) SWA_SG_CASE(44) SWA_SG_CASE(45) SWA_SG_CASE(46) SWA_SG_CASE(47) SWA_SG_CASE(48)
     default: return hipErrorInvalidValue;
   }
-#undef SWA_S8_CASE
+#undef SWA_SG_CASE
+}
+extern "C" hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+  return G == 4 ? launch_split_any<4>(K, p, blocks, st) : G == 8 ? launch_split_any<8>(K, p, blocks, st) : hipErrorInvalidValue;
 }
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {

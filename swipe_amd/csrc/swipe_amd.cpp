@@ -26,8 +26,8 @@
 extern "C" {
 int swa_narrow_rows_for(int qlen);
 int swa_narrow_rows_exact(int qlen);
-int swa_narrow_rows_half(int qlen);
-hipError_t swa_launch_narrow8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+int swa_narrow_rows_split(int qlen, int G);
+hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
@@ -486,12 +486,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   const bool single_pass = qlen <= 16 * 48 && K > 0 && !force_mp;
   const int Kx = swa_narrow_rows_exact(int(std::min<int64_t>(qlen, 4096)));  // row-shifted kernel: ceil(qlen / 16) rows per lane
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  // queries of at most 384 rows: 8 lanes per sequence pair, K = ceil(qlen / 8) (SWA_LANES=16 forces the 16-lane form)
-  const char* lanes_env = std::getenv("SWA_LANES");
-  const int K8 = (lanes_env && std::atoi(lanes_env) == 16) ? 0 : swa_narrow_rows_half(int(std::min<int64_t>(qlen, 4096)));
-  const bool half = K8 > 0 && f16_limit(db, K8) >= 1024;
-  if (f16 && single_pass && (half || (Kx > 0 && f16_limit(db, Kx) >= 1024)) && db->narrow_variant != 1) {
-    const int K = half ? K8 : Kx;
+  // short queries: G = 4 (up to 192 rows) or 8 (up to 384) lanes per sequence pair, K = ceil(qlen / G) rows per
+  // lane (SWA_LANES = 4 / 8 / 16 picks the form: A/B runs and tests)
+  int G = qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
+  if (const char* e = std::getenv("SWA_LANES")) G = std::max(G, std::atoi(e));
+  int Kg = G < 16 ? swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G) : 0;
+  const bool split = Kg > 0 && f16_limit(db, Kg) >= 1024;
+  if (f16 && single_pass && (split || (Kx > 0 && f16_limit(db, Kx) >= 1024)) && db->narrow_variant != 1) {
+    const int K = split ? Kg : Kx;
     swa_narrow_params p{};
     p.query = db->query.p;
     p.stream = db->main.stream.p;
@@ -511,12 +513,13 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.negKR = f16_pair(-float(int64_t(K) * db->ge));
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
-    c.narrow_shifted = half ? 2 : 1;
-    const int items = half ? (p.nbatches + 1) / 2 : p.nbatches;    // the 8-lane form takes two batches per wave
+    c.narrow_shifted = split ? (G == 8 ? 2 : 3) : 1;
+    const int per_wave = split ? 16 / G : 1;                        // the G-lane forms take 16 / G batches per wave
+    const int items = (p.nbatches + per_wave - 1) / per_wave;
     int blocks = persistent_blocks(db, items);
     if (const char* w = std::getenv("SWA_WAVES")) p.waves = std::atoi(w);
     if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((items + 3) / 4, db->cus * std::atoi(w)));
-    HIP_TRY(half ? swa_launch_narrow8(K, &p, blocks, st) : swa_launch_narrow(K, &p, blocks, st));
+    HIP_TRY(split ? swa_launch_narrow_split(G, K, &p, blocks, st) : swa_launch_narrow(K, &p, blocks, st));
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range

@@ -142,10 +142,10 @@ def test_every_rows_per_lane_variant(qlen):
     db.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 8])
+@pytest.mark.parametrize("lanes", [16, 8, 4])
 def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
-    """rows per lane K = ceil(qlen / lanes) for every K in 1..48 of both forms (16 lanes per sequence pair, and 8 for
-    queries of at most 384 rows): one query per instantiation, at both ends of its window, one resident database"""
+    """rows per lane K = ceil(qlen / lanes) for every K in 1..48 of all three forms (16 lanes per sequence pair, 8 for
+    queries of at most 384 rows, 4 for at most 192): one query per instantiation, at both ends of its window"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     rtab = synth.residue_table_protein()
     full = synth._random_residues(99, 1, 768, rtab)
@@ -159,7 +159,7 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
         for qlen in (lanes * K - lanes + 1, lanes * K):
             q = full[:qlen]
             scores, c = db.search(q)
-            assert c["narrow_rows"] == K and c["narrow_shifted"] == (1 if lanes == 16 else 2)
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == {16: 1, 8: 2, 4: 3}[lanes]
             assert np.array_equal(scores, oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)), (K, qlen)
     db.close()
 

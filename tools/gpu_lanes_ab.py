@@ -17,9 +17,9 @@ for lanes in ("16", "8", "16", "8"):
         ref = s
     best = min(db.search(q, want_scores=False)[1]["kernel_ms"] for _ in range(4))
     print("lanes %2s: K=%2d form=%d  %.2f ms  %.0f GCUPS  identical=%s" % (lanes, c["narrow_rows"], c["narrow_shifted"], best, c["cells"] / best / 1e6, np.array_equal(s, ref)))
-for qlen in (100, 200, 300, 384):
+for qlen in (30, 60, 100, 150, 192, 200, 300, 375):
     qq = q[:qlen]
-    for lanes in ("16", "8"):
+    for lanes in ("16", "8", "4"):
         os.environ["SWA_LANES"] = lanes
         s, c = db.search(qq)
         best = min(db.search(qq, want_scores=False)[1]["kernel_ms"] for _ in range(3))
