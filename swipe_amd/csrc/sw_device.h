@@ -36,6 +36,7 @@ struct swa_narrow_params {
   /* row-shifted form (swa_narrow_shifted_kernel) */
   int32_t shifted;             /* 0 plain form, 1 row-shifted form */
   int32_t waves;               /* tuning: waves per SIMD the kernel is compiled for (0 = default) */
+  int32_t pipe;                /* split kernel: build with pipelined profile loads (K = 30..36): 1 / 0 forced, -1 = where it wins */
   float gapextend_f;           /* R, added to every profile entry */
   uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
   uint32_t rowc[68];           /* packed f16 pairs r*R for r = 0..K+1 */

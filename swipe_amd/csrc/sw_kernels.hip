@@ -398,7 +398,7 @@ __device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, cons
   }
 }
 
-template <int K, int W, int G>
+template <int K, int W, int G, bool PIPE>
 __global__ void __launch_bounds__(256, W)
 swa_narrow_split_kernel(swa_narrow_params p)
 {
@@ -447,6 +447,17 @@ swa_narrow_split_kernel(swa_narrow_params p)
     u32 cur = PADOFF;
     u32 raw = mychunks > 0 ? (u32)s[0] : PADRAW;
 
+#define SWA_CELL(r, k, wa, wb, ODD)                                                            \
+          {                                                                                    \
+            const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, ((k) & 1) ? 0x07060302u : 0x05040100u)); \
+            const h2 h = pk_max3(hd + sc, E[r], F);                                            \
+            hd = H[r];                                                                         \
+            if (ODD) SR[r] = pk_max3(SR[r], hd, h);                                            \
+            H[r] = h;                                                                          \
+            const h2 t = h + negQR;                                                            \
+            F = pk_max(F, t);                                                                  \
+            E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2])) + negR;                              \
+          }
 #define SWA_STEPG(ODD)                                                                         \
     {                                                                                          \
       const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
@@ -459,23 +470,35 @@ swa_narrow_split_kernel(swa_narrow_params p)
       diag = hup;                                                                              \
       const u32 aoff = (cur & 0xFFFF) | l16;                                                   \
       const u32 boff = (cur >> 16) | l16;                                                      \
-      u4v pa[C], pb[C];                                                                        \
-      _Pragma("unroll") for (int c = 0; c < C; ++c) {                                          \
-        pa[c] = *(lds_u4_ptr)(uintptr_t)(aoff + c * 256);                                      \
-        pb[c] = *(lds_u4_ptr)(uintptr_t)(boff + c * 256);                                      \
-      }                                                                                        \
-      _Pragma("unroll") for (int r = 0; r < K; ++r) {                                          \
-        const int c = r >> 3, k = r & 7;                                                       \
-        const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;          \
-        const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;          \
-        const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u)); \
-        const h2 h = pk_max3(hd + sc, E[r], F);                                                \
-        hd = H[r];                                                                             \
-        if (ODD) SR[r] = pk_max3(SR[r], hd, h);                                                \
-        H[r] = h;                                                                              \
-        const h2 t = h + negQR;                                                                \
-        F = pk_max(F, t);                                                                      \
-        E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2])) + negR;                                  \
+      if constexpr (!PIPE) {                                                                   \
+        u4v pa[C], pb[C];                                                                      \
+        _Pragma("unroll") for (int c = 0; c < C; ++c) {                                        \
+          pa[c] = *(lds_u4_ptr)(uintptr_t)(aoff + c * 256);                                    \
+          pb[c] = *(lds_u4_ptr)(uintptr_t)(boff + c * 256);                                    \
+        }                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < K; ++r) {                                        \
+          const int c = r >> 3, k = r & 7;                                                     \
+          const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;        \
+          const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;        \
+          SWA_CELL(r, k, wa, wb, ODD)                                                          \
+        }                                                                                      \
+      } else {        /* profile units one 8-row group ahead of use: 16 staging registers whatever K is */ \
+        u4v na = *(lds_u4_ptr)(uintptr_t)(aoff), nb = *(lds_u4_ptr)(uintptr_t)(boff);          \
+        _Pragma("unroll") for (int c = 0; c < C; ++c) {                                        \
+          const u4v ua = na, ub = nb;                                                          \
+          if (c + 1 < C) {                                                                     \
+            na = *(lds_u4_ptr)(uintptr_t)(aoff + (c + 1) * 256);                               \
+            nb = *(lds_u4_ptr)(uintptr_t)(boff + (c + 1) * 256);                               \
+          }                                                                                    \
+          _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                      \
+            const int r = c * 8 + k;                                                           \
+            if (r < K) {                                                                       \
+              const u32 wa = k < 2 ? ua.x : k < 4 ? ua.y : k < 6 ? ua.z : ua.w;                \
+              const u32 wb = k < 2 ? ub.x : k < 4 ? ub.y : k < 6 ? ub.z : ub.w;                \
+              SWA_CELL(r, k, wa, wb, ODD)                                                      \
+            }                                                                                  \
+          }                                                                                    \
+        }                                                                                      \
       }                                                                                        \
       hsend = __builtin_elementwise_fma(H[K - 1], send_mul, send_add);                         \
       fsend = __builtin_elementwise_fma(F, send_mul, send_add);                                \
@@ -492,6 +515,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
       }
     }
 #undef SWA_STEPG
+#undef SWA_CELL
 
     h2 S = zero;
 #pragma unroll
@@ -734,13 +758,13 @@ static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, 
   hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
-template <int K, int W, int G>
+template <int K, int W, int G, bool PIPE>
 static hipError_t launch_narrow_split(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
   const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_split_kernel<K, W, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_split_kernel<K, W, G, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((swa_narrow_split_kernel<K, W, G>), dim3(blocks), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((swa_narrow_split_kernel<K, W, G, PIPE>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
 extern "C" int swa_narrow_rows_for(int qlen)
@@ -767,9 +791,23 @@ extern "C" int swa_narrow_rows_split(int qlen, int G)
   const int k = (qlen + G - 1) / G;
   return k < 1 ? 1 : k <= 48 ? k : 0;
 }
+// pipelined profile loads (16 staging registers instead of 8 C) keep K = 32..36 at three waves per SIMD; measured
+// per K on MI355X (tools/gpu_pipe_sweep.py): +4 % at K = 32, +8 % at K = 35 and 36, no gain or a loss elsewhere
+static constexpr int pipe_waves_for(int K) { return K <= 36 ? 3 : 2; }
+template <int G> static hipError_t launch_split_pipe(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_SP_CASE(KK) case KK: return launch_narrow_split<KK, pipe_waves_for(KK), G, true>(*p, blocks, st);
+  switch (K) {
+    SWA_SP_CASE(30) SWA_SP_CASE(31) SWA_SP_CASE(32) SWA_SP_CASE(33) SWA_SP_CASE(34) SWA_SP_CASE(35) SWA_SP_CASE(36)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_SP_CASE
+}
 template <int G> static hipError_t launch_split_any(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-#define SWA_SG_CASE(KK) case KK: return launch_narrow_split<KK, split_waves_for(KK), G>(*p, blocks, st);
+  const bool pipe = p->pipe == 1 || (p->pipe < 0 && (K == 32 || K == 35 || K == 36));      // pipe: 1 / 0 forced, -1 auto
+  if (pipe && K >= 30 && K <= 36) return launch_split_pipe<G>(K, p, blocks, st);
+#define SWA_SG_CASE(KK) case KK: return launch_narrow_split<KK, split_waves_for(KK), G, false>(*p, blocks, st);
   switch (K) {
     SWA_SG_CASE(1) SWA_SG_CASE(2) SWA_SG_CASE(3) SWA_SG_CASE(4) SWA_SG_CASE(5) SWA_SG_CASE(6) SWA_SG_CASE(7) SWA_SG_CASE(8)
     SWA_SG_CASE(9) SWA_SG_CASE(10) SWA_SG_CASE(11) SWA_SG_CASE(12) SWA_SG_CASE(13) SWA_SG_CASE(14) SWA_SG_CASE(15) SWA_SG_CASE(16)

@@ -518,6 +518,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     const int items = (p.nbatches + per_wave - 1) / per_wave;
     int blocks = persistent_blocks(db, items);
     if (const char* w = std::getenv("SWA_WAVES")) p.waves = std::atoi(w);
+    p.pipe = -1;
+    if (const char* w = std::getenv("SWA_PIPE")) p.pipe = std::atoi(w);
     if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((items + 3) / 4, db->cus * std::atoi(w)));
     HIP_TRY(split ? swa_launch_narrow_split(G, K, &p, blocks, st) : swa_launch_narrow(K, &p, blocks, st));
     c.narrow = db->nseq;

@@ -164,6 +164,27 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
     db.close()
 
 
+@pytest.mark.parametrize("lanes", [8, 4])
+def test_pipelined_profile_build_of_the_split_kernel(lanes, monkeypatch):
+    """both builds of swa_narrow_split_kernel (all profile units staged / pipelined one unit ahead) for K = 30..36"""
+    monkeypatch.setenv("SWA_LANES", str(lanes))
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(98, 1, 300, rtab)
+    res, off = swipe_amd.synth_db(8, 300, query=full)
+    r2, o2 = oracle.pack([res[off[i]:off[i + 1]] for i in range(300)] + [full, full[50:250].copy()])
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    for K in range(30, 37):
+        q = full[: lanes * K - 1]
+        want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
+        for pipe in ("0", "1"):
+            monkeypatch.setenv("SWA_PIPE", pipe)
+            scores, c = db.search(q)
+            assert c["narrow_rows"] == K and np.array_equal(scores, want), (K, pipe)
+    db.close()
+
+
 @pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("gaps", [(11, 1), (5, 2), (0, 3), (14, 4), (30, 20)])
 def test_both_narrow_kernel_forms(monkeypatch, variant, gaps):
