@@ -36,7 +36,8 @@ struct swa_narrow_params {
   /* row-shifted form (swa_narrow_shifted_kernel) */
   int32_t shifted;             /* 0 plain form, 1 row-shifted form */
   int32_t waves;               /* tuning: waves per SIMD the kernel is compiled for (0 = default) */
-  int32_t pipe;                /* split kernel: build with pipelined profile loads (K = 30..36): 1 / 0 forced, -1 = where it wins */
+  int32_t pipe;                /* split kernel build: 0 staged, 1 pipelined within a step (K = 30..36), 2 across steps (K = 45..48);
+                                  -1 = whichever measured fastest for this K */
   float gapextend_f;           /* R, added to every profile entry */
   uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
   uint32_t rowc[68];           /* packed f16 pairs r*R for r = 0..K+1 */

@@ -398,7 +398,7 @@ __device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, cons
   }
 }
 
-template <int K, int W, int G, bool PIPE>
+template <int K, int W, int G, int PIPE>
 __global__ void __launch_bounds__(256, W)
 swa_narrow_split_kernel(swa_narrow_params p)
 {
@@ -470,7 +470,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
       diag = hup;                                                                              \
       const u32 aoff = (cur & 0xFFFF) | l16;                                                   \
       const u32 boff = (cur >> 16) | l16;                                                      \
-      if constexpr (!PIPE) {                                                                   \
+      if constexpr (PIPE == 0) {                                                               \
         u4v pa[C], pb[C];                                                                      \
         _Pragma("unroll") for (int c = 0; c < C; ++c) {                                        \
           pa[c] = *(lds_u4_ptr)(uintptr_t)(aoff + c * 256);                                    \
@@ -504,15 +504,76 @@ swa_narrow_split_kernel(swa_narrow_params p)
       fsend = __builtin_elementwise_fma(F, send_mul, send_add);                                \
     }
 
-    for (int m = 0; m * G < total; ++m) {                 // m-th block of G columns of the 16-column chunks
-      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
-      const int col = (m + 1) * G;
-      raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW;
-      const int n = total - m * G < G ? total - m * G : G;
-      for (int u = 0; u < n; u += 2) {
-        SWA_STEPG(0)
-        SWA_STEPG(1)
+    if constexpr (PIPE != 2) {
+      for (int m = 0; m * G < total; ++m) {               // m-th block of G columns of the 16-column chunks
+        u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+        const int col = (m + 1) * G;
+        raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW;
+        const int n = total - m * G < G ? total - m * G : G;
+        for (int u = 0; u < n; u += 2) {
+          SWA_STEPG(0)
+          SWA_STEPG(1)
+        }
       }
+    } else {
+      // PIPE == 2: the residue register is advanced and the first profile unit of a step is fetched while the
+      // previous step still computes, so no LDS latency is exposed at a step boundary
+      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+      raw = ((G >> 4) < mychunks) ? (u32)s[(int64_t)(G >> 4) * 64 + (G & 15)] : PADRAW;
+      u32 aoff, boff;
+      u4v na, nb;
+#define SWA_ADVANCE()                                                                          \
+      {                                                                                        \
+        const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
+        const u32 shifted = row_shr1(cur, pl);                                                 \
+        cur = inner_first ? pl : shifted;                                                      \
+        pl = pl2;                                                                              \
+        aoff = (cur & 0xFFFF) | l16;                                                           \
+        boff = (cur >> 16) | l16;                                                              \
+        na = *(lds_u4_ptr)(uintptr_t)(aoff);                                                   \
+        nb = *(lds_u4_ptr)(uintptr_t)(boff);                                                   \
+      }
+#define SWA_STEPX(ODD, RELOAD)                                                                 \
+      {                                                                                        \
+        const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+        h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+        h2 hd = diag;                                                                          \
+        diag = hup;                                                                            \
+        _Pragma("unroll") for (int c = 0; c < C; ++c) {                                        \
+          const u4v ua = na, ub = nb;                                                          \
+          if (c + 1 < C) {                                                                     \
+            na = *(lds_u4_ptr)(uintptr_t)(aoff + (c + 1) * 256);                               \
+            nb = *(lds_u4_ptr)(uintptr_t)(boff + (c + 1) * 256);                               \
+          } else {      /* last unit in flight: the next step's residue offsets and its unit 0 */ \
+            if (RELOAD) {                                                                      \
+              pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);                            \
+              const int col = (m + 2) * G;                                                     \
+              raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW; \
+            }                                                                                  \
+            SWA_ADVANCE()                                                                      \
+          }                                                                                    \
+          _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                      \
+            const int r = c * 8 + k;                                                           \
+            if (r < K) {                                                                       \
+              const u32 wa = k < 2 ? ua.x : k < 4 ? ua.y : k < 6 ? ua.z : ua.w;                \
+              const u32 wb = k < 2 ? ub.x : k < 4 ? ub.y : k < 6 ? ub.z : ub.w;                \
+              SWA_CELL(r, k, wa, wb, ODD)                                                      \
+            }                                                                                  \
+          }                                                                                    \
+        }                                                                                      \
+        hsend = __builtin_elementwise_fma(H[K - 1], send_mul, send_add);                       \
+        fsend = __builtin_elementwise_fma(F, send_mul, send_add);                              \
+      }
+      SWA_ADVANCE()
+      for (int m = 0; m * G < total; ++m) {
+        const int n = total - m * G < G ? total - m * G : G;
+        for (int u = 0; u < n; u += 2) {
+          SWA_STEPX(0, false)
+          SWA_STEPX(1, u + 2 >= n)
+        }
+      }
+#undef SWA_STEPX
+#undef SWA_ADVANCE
     }
 #undef SWA_STEPG
 #undef SWA_CELL
@@ -758,7 +819,7 @@ static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, 
   hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
-template <int K, int W, int G, bool PIPE>
+template <int K, int W, int G, int PIPE>
 static hipError_t launch_narrow_split(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
   const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
@@ -796,18 +857,30 @@ extern "C" int swa_narrow_rows_split(int qlen, int G)
 static constexpr int pipe_waves_for(int K) { return K <= 36 ? 3 : 2; }
 template <int G> static hipError_t launch_split_pipe(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-#define SWA_SP_CASE(KK) case KK: return launch_narrow_split<KK, pipe_waves_for(KK), G, true>(*p, blocks, st);
+#define SWA_SP_CASE(KK) case KK: return launch_narrow_split<KK, pipe_waves_for(KK), G, 1>(*p, blocks, st);
   switch (K) {
     SWA_SP_CASE(30) SWA_SP_CASE(31) SWA_SP_CASE(32) SWA_SP_CASE(33) SWA_SP_CASE(34) SWA_SP_CASE(35) SWA_SP_CASE(36)
     default: return hipErrorInvalidValue;
   }
 #undef SWA_SP_CASE
 }
+// cross-step pipelined build: the next step's first profile unit is requested while the last one of this step is
+// consumed.  Measured for K = 40..48 (tools/gpu_pipe2_probe.py): +0.7 % at K = 47 and 48, a loss below
+template <int G> static hipError_t launch_split_pipe2(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_SX_CASE(KK) case KK: return launch_narrow_split<KK, 2, G, 2>(*p, blocks, st);
+  switch (K) {
+    SWA_SX_CASE(45) SWA_SX_CASE(46) SWA_SX_CASE(47) SWA_SX_CASE(48)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_SX_CASE
+}
 template <int G> static hipError_t launch_split_any(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
+  if ((p->pipe == 2 && K >= 45) || (p->pipe < 0 && K >= 47)) return launch_split_pipe2<G>(K, p, blocks, st);
   const bool pipe = p->pipe == 1 || (p->pipe < 0 && (K == 32 || K == 35 || K == 36));      // pipe: 1 / 0 forced, -1 auto
   if (pipe && K >= 30 && K <= 36) return launch_split_pipe<G>(K, p, blocks, st);
-#define SWA_SG_CASE(KK) case KK: return launch_narrow_split<KK, split_waves_for(KK), G, false>(*p, blocks, st);
+#define SWA_SG_CASE(KK) case KK: return launch_narrow_split<KK, split_waves_for(KK), G, 0>(*p, blocks, st);
   switch (K) {
     SWA_SG_CASE(1) SWA_SG_CASE(2) SWA_SG_CASE(3) SWA_SG_CASE(4) SWA_SG_CASE(5) SWA_SG_CASE(6) SWA_SG_CASE(7) SWA_SG_CASE(8)
     SWA_SG_CASE(9) SWA_SG_CASE(10) SWA_SG_CASE(11) SWA_SG_CASE(12) SWA_SG_CASE(13) SWA_SG_CASE(14) SWA_SG_CASE(15) SWA_SG_CASE(16)

@@ -166,7 +166,8 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
 
 @pytest.mark.parametrize("lanes", [8, 4])
 def test_pipelined_profile_build_of_the_split_kernel(lanes, monkeypatch):
-    """both builds of swa_narrow_split_kernel (all profile units staged / pipelined one unit ahead) for K = 30..36"""
+    """the builds of swa_narrow_split_kernel: all profile units staged / pipelined one unit ahead (K = 30..36) /
+    pipelined across steps (K = 45..48)"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     rtab = synth.residue_table_protein()
     full = synth._random_residues(98, 1, 300, rtab)
@@ -175,10 +176,12 @@ def test_pipelined_profile_build_of_the_split_kernel(lanes, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     Mo = oracle.matrix_builtin("BLOSUM62")
-    for K in range(30, 37):
+    for K in list(range(30, 37)) + [45, 46, 47, 48]:
+        if lanes * K - 1 > len(full):
+            full = np.concatenate([full, synth._random_residues(97, 1, lanes * 48 - len(full), rtab)])
         q = full[: lanes * K - 1]
         want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
-        for pipe in ("0", "1"):
+        for pipe in (("0", "1") if K < 40 else ("0", "2")):
             monkeypatch.setenv("SWA_PIPE", pipe)
             scores, c = db.search(q)
             assert c["narrow_rows"] == K and np.array_equal(scores, want), (K, pipe)
