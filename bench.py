@@ -220,7 +220,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": ("swa_narrow_split_kernel<%d, W, 8>" if c["narrow_shifted"] == 2 else "swa_narrow_split_kernel<%d, W, 4>"
-                                    if c["narrow_shifted"] == 3 else "swa_narrow_shifted_kernel<%d, W>"
+                                    if c["narrow_shifted"] == 3 else "swa_narrow_split_kernel<%d, W, 16>"
                                     if c["narrow_shifted"] else "swa_narrow_kernel<%d>") % c["narrow_rows"],
                          "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes,

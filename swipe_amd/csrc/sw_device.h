@@ -33,7 +33,7 @@ struct swa_narrow_params {
   int32_t* ovf_count;
   int32_t* ovf_list;
   uint32_t negQ, negR;         /* packed f16 pairs: -(gapopen+gapextend), -gapextend */
-  /* row-shifted form (swa_narrow_shifted_kernel) */
+  /* row-shifted form (swa_narrow_split_kernel) */
   int32_t shifted;             /* 0 plain form, 1 row-shifted form */
   int32_t waves;               /* tuning: waves per SIMD the kernel is compiled for (0 = default) */
   int32_t pipe;                /* split kernel build: 0 staged, 1 pipelined within a step (K = 30..36), 2 across steps (K = 45..48);

@@ -274,106 +274,17 @@ swa_narrow_kernel(swa_narrow_params p)
 // correct boundary for lane 0 of a row (H[-1] = 0; F <= 0 is "no gap").  Per-row maxima S^[r] are
 // un-shifted once per batch.  Exact while every value stays within 2048, i.e. for scores below
 // 2048 - hi - (K+1) R.  The last chunk of a batch runs only as many steps as the batch needs
-// (+16 to drain the skew), rounded to 2 because S^ is updated every other column.
+// (+G to drain the skew), rounded to 2 because S^ is updated every other column.
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u4v* lds_u4_ptr;
 
-template <int K, int W>
-__global__ void __launch_bounds__(256, W)
-swa_narrow_shifted_kernel(swa_narrow_params p)
-{
-  constexpr int C = (K + 7) / 8;
-  constexpr u32 CS = C * 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  build_profile_f16<K>(lds, p.query, p.gapextend_f);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const u32 l16 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (u32)(lane & 15) * 16;
-  const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR), negKR = as_h2(p.negKR);
-  const h2 zero = {0, 0};
-  const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
-  const u32 PADRAW = SWA_PAD | (SWA_PAD << 8);
-
-  for (;;) {
-    int b = 0;
-    if (lane == 0) b = atomicAdd(p.counter, 1);
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= p.nbatches) break;
-    const swa_batch bd = p.batches[b];
-    const uint16_t* s = p.stream + (int64_t)bd.offset * 64;
-    const int nchunks = (bd.steps + 15) >> 4;
-    const int total = bd.steps + 16;                      // + drain of the 15-step skew, kept even
-
-    h2 H[K], E[K], SR[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r + 1]); E[r] = H[r]; SR[r] = H[r]; }   // 0 + (r+1) R
-    h2 diag = zero;                                       // H[-1][-1]
-    h2 hsend = zero, fsend = zero;                        // what the next lane reads: H[K-1] - K R, Fout - K R
-    u32 cur = PADOFF;
-    u32 raw = nchunks > 0 ? (u32)s[lane] : PADRAW;
-
-#define SWA_STEP(ODD)                                                                          \
-    {                                                                                          \
-      const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
-      cur = row_shr1(cur, pl);                                                                 \
-      pl = pl2;                                                                                \
-      const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
-      h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
-      h2 hd = diag;                                                                            \
-      diag = hup;                                                                              \
-      const u32 aoff = (cur & 0xFFFF) | l16;                                                   \
-      const u32 boff = (cur >> 16) | l16;                                                      \
-      u4v pa[C], pb[C];                                                                        \
-      _Pragma("unroll") for (int c = 0; c < C; ++c) {                                          \
-        pa[c] = *(lds_u4_ptr)(uintptr_t)(aoff + c * 256);                                      \
-        pb[c] = *(lds_u4_ptr)(uintptr_t)(boff + c * 256);                                      \
-      }                                                                                        \
-      _Pragma("unroll") for (int r = 0; r < K; ++r) {                                          \
-        const int c = r >> 3, k = r & 7;                                                       \
-        const u32 wa = k < 2 ? pa[c].x : k < 4 ? pa[c].y : k < 6 ? pa[c].z : pa[c].w;          \
-        const u32 wb = k < 2 ? pb[c].x : k < 4 ? pb[c].y : k < 6 ? pb[c].z : pb[c].w;          \
-        const h2 sc = as_h2(__builtin_amdgcn_perm(wb, wa, (k & 1) ? 0x07060302u : 0x05040100u)); \
-        const h2 h = pk_max3(hd + sc, E[r], F);                                                \
-        hd = H[r];                                                                             \
-        if (ODD) SR[r] = pk_max3(SR[r], hd, h);           /* two columns per update */         \
-        H[r] = h;                                                                              \
-        const h2 t = h + negQR;                                                                \
-        F = pk_max(F, t);                                                                      \
-        E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2])) + negR;                                  \
-      }                                                                                        \
-      hsend = H[K - 1] + negKR;                                                                \
-      fsend = F + negKR;                                                                       \
-    }
-
-    for (int m = 0; m * 16 < total; ++m) {
-      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
-      raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : PADRAW;
-      const int n = total - m * 16 < 16 ? total - m * 16 : 16;
-      for (int u = 0; u < n; u += 2) {
-        SWA_STEP(0)
-        SWA_STEP(1)
-      }
-    }
-#undef SWA_STEP
-
-    h2 S = zero;
-#pragma unroll
-    for (int r = 0; r < K; ++r) S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
-    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
-    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
-    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
-    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(8), 0xF, 0xF, true)));
-    narrow_write_scores(p, b, lane, S);
-  }
-}
-
-// ------------------------------------------------------------------ row-shifted kernel, G = 8 or 4 lanes per sequence pair
-// For short queries the systolic chain is cut to G lanes: a 16-lane DPP row then carries 16 / G sequence
-// pairs, a wave 64 / G pairs = 16 / G consecutive batches of the same stream, and a lane owns K = ceil(qlen / G)
-// rows (G = 8: queries up to 384 rows, G = 4: up to 192).  More rows per lane shrink the per-step overhead
+// ------------------------------------------------------------------ row-shifted kernel, G = 16, 8 or 4 lanes per sequence pair
+// G = 16 is the scheme described above (one sequence pair per DPP row, queries up to 768 rows).  For shorter
+// queries the systolic chain is cut to G lanes: a 16-lane DPP row then carries 16 / G sequence pairs, a wave
+// 64 / G pairs = 16 / G consecutive batches of the same stream, and a lane owns K = ceil(qlen / G) rows
+// (G = 8: queries up to 384 rows, G = 4: up to 192).  More rows per lane shrink the per-step overhead
 // (DPP hand-overs and residue addressing are per lane and step, not per row), the pipeline skew to drain is G
-// steps instead of 16, and K is exact to G rows.  Differences to swa_narrow_shifted_kernel:
+// steps instead of 16, and K is exact to G rows.  What G < 16 changes:
 //   * row_shr:1 would carry the hand-over of a pair's last lane into the first lane of the neighbouring pair.
 //     The last lane has no successor, so it simply sends zeros: hsend / fsend are one v_pk_fma_f16 with per-lane
 //     constants (1, -K R) or (0, 0) instead of one v_pk_add_f16 - no extra instruction, and zero is exactly the
@@ -585,7 +496,8 @@ swa_narrow_split_kernel(swa_narrow_params p)
     // every pair ends up with the maximum of its own pair only
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
-    if (G == 8) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
+    if (G >= 8) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
+    if (G == 16) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(8), 0xF, 0xF, true)));
     {
       const bool writer = lg == G - 1;
       int sA = -1, sB = -1, idA = -1, idB = -1;
@@ -810,15 +722,6 @@ static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStrea
   hipLaunchKernelGGL(swa_narrow_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
-template <int K, int W>
-static hipError_t launch_narrow_shifted(const swa_narrow_params& p, int blocks, hipStream_t st)
-{
-  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_shifted_kernel<K, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((swa_narrow_shifted_kernel<K, W>), dim3(blocks), dim3(256), lds, st, p);
-  return hipGetLastError();
-}
 template <int K, int W, int G, int PIPE>
 static hipError_t launch_narrow_split(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
@@ -836,15 +739,6 @@ extern "C" int swa_narrow_rows_for(int qlen)
   if (k <= 48) return k;
   return qlen <= 1024 ? 64 : 0;
 }
-// rows per lane of the row-shifted kernel: exactly ceil(qlen / 16), every value 1..48 is instantiated, so
-// at most 15 padding rows are computed whatever the query length (0 = too long for one pass)
-extern "C" int swa_narrow_rows_exact(int qlen)
-{
-  const int k = (qlen + 15) / 16;
-  return k < 1 ? 1 : k <= 48 ? k : 0;
-}
-// resident waves per SIMD the register budget of K rows per lane allows (3 registers per row + profile units)
-static constexpr int shifted_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 32 ? 3 : 2; }
 static constexpr int split_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 31 ? 3 : 2; }
 // G-lane form: K = ceil(qlen / G) rows per lane, at most 48 (0 = query too long for this G)
 extern "C" int swa_narrow_rows_split(int qlen, int G)
@@ -877,7 +771,7 @@ template <int G> static hipError_t launch_split_pipe2(int K, const swa_narrow_pa
 }
 template <int G> static hipError_t launch_split_any(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-  if ((p->pipe == 2 && K >= 45) || (p->pipe < 0 && K >= 47)) return launch_split_pipe2<G>(K, p, blocks, st);
+  if ((p->pipe == 2 && K >= 45) || (p->pipe < 0 && K >= 47 && G < 16)) return launch_split_pipe2<G>(K, p, blocks, st);
   const bool pipe = p->pipe == 1 || (p->pipe < 0 && (K == 32 || K == 35 || K == 36));      // pipe: 1 / 0 forced, -1 auto
   if (pipe && K >= 30 && K <= 36) return launch_split_pipe<G>(K, p, blocks, st);
 #define SWA_SG_CASE(KK) case KK: return launch_narrow_split<KK, split_waves_for(KK), G, 0>(*p, blocks, st);
@@ -894,24 +788,11 @@ template <int G> static hipError_t launch_split_any(int K, const swa_narrow_para
 }
 extern "C" hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-  return G == 4 ? launch_split_any<4>(K, p, blocks, st) : G == 8 ? launch_split_any<8>(K, p, blocks, st) : hipErrorInvalidValue;
+  return G == 4 ? launch_split_any<4>(K, p, blocks, st) : G == 8 ? launch_split_any<8>(K, p, blocks, st)
+         : G == 16 ? launch_split_any<16>(K, p, blocks, st) : hipErrorInvalidValue;
 }
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-#define SWA_SHIFTED_CASE(KK) case KK: return launch_narrow_shifted<KK, shifted_waves_for(KK)>(*p, blocks, st);
-  if (p->shifted) switch (K) {
-    SWA_SHIFTED_CASE(1) SWA_SHIFTED_CASE(2) SWA_SHIFTED_CASE(3) SWA_SHIFTED_CASE(4) SWA_SHIFTED_CASE(5) SWA_SHIFTED_CASE(6)
-    SWA_SHIFTED_CASE(7) SWA_SHIFTED_CASE(8) SWA_SHIFTED_CASE(9) SWA_SHIFTED_CASE(10) SWA_SHIFTED_CASE(11) SWA_SHIFTED_CASE(12)
-    SWA_SHIFTED_CASE(13) SWA_SHIFTED_CASE(14) SWA_SHIFTED_CASE(15) SWA_SHIFTED_CASE(16) SWA_SHIFTED_CASE(17) SWA_SHIFTED_CASE(18)
-    SWA_SHIFTED_CASE(19) SWA_SHIFTED_CASE(20) SWA_SHIFTED_CASE(21) SWA_SHIFTED_CASE(22) SWA_SHIFTED_CASE(23)
-    case 24: return p->waves == 4 ? launch_narrow_shifted<24, 4>(*p, blocks, st) : launch_narrow_shifted<24, 3>(*p, blocks, st);
-    SWA_SHIFTED_CASE(25) SWA_SHIFTED_CASE(26) SWA_SHIFTED_CASE(27) SWA_SHIFTED_CASE(28) SWA_SHIFTED_CASE(29) SWA_SHIFTED_CASE(30)
-    SWA_SHIFTED_CASE(31) SWA_SHIFTED_CASE(32) SWA_SHIFTED_CASE(33) SWA_SHIFTED_CASE(34) SWA_SHIFTED_CASE(35) SWA_SHIFTED_CASE(36)
-    SWA_SHIFTED_CASE(37) SWA_SHIFTED_CASE(38) SWA_SHIFTED_CASE(39) SWA_SHIFTED_CASE(40) SWA_SHIFTED_CASE(41) SWA_SHIFTED_CASE(42)
-    SWA_SHIFTED_CASE(43) SWA_SHIFTED_CASE(44) SWA_SHIFTED_CASE(45) SWA_SHIFTED_CASE(46) SWA_SHIFTED_CASE(47) SWA_SHIFTED_CASE(48)
-    default: return hipErrorInvalidValue;
-  }
-#undef SWA_SHIFTED_CASE
   switch (K) {
     case 4:  return launch_narrow<4>(*p, blocks, st);
     case 8:  return launch_narrow<8>(*p, blocks, st);

@@ -25,7 +25,6 @@
 
 extern "C" {
 int swa_narrow_rows_for(int qlen);
-int swa_narrow_rows_exact(int qlen);
 int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -484,16 +483,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
   const bool single_pass = qlen <= 16 * 48 && K > 0 && !force_mp;
-  const int Kx = swa_narrow_rows_exact(int(std::min<int64_t>(qlen, 4096)));  // row-shifted kernel: ceil(qlen / 16) rows per lane
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  // short queries: G = 4 (up to 192 rows) or 8 (up to 384) lanes per sequence pair, K = ceil(qlen / G) rows per
-  // lane (SWA_LANES = 4 / 8 / 16 picks the form: A/B runs and tests)
+  // G = 4 (up to 192 rows), 8 (up to 384) or 16 (up to 768) lanes per sequence pair, K = ceil(qlen / G) rows per
+  // lane (SWA_LANES = 8 / 16 forces a longer chain: A/B runs and tests)
   int G = qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
-  if (const char* e = std::getenv("SWA_LANES")) G = std::max(G, std::atoi(e));
-  int Kg = G < 16 ? swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G) : 0;
-  const bool split = Kg > 0 && f16_limit(db, Kg) >= 1024;
-  if (f16 && single_pass && (split || (Kx > 0 && f16_limit(db, Kx) >= 1024)) && db->narrow_variant != 1) {
-    const int K = split ? Kg : Kx;
+  if (const char* e = std::getenv("SWA_LANES")) G = std::min(16, std::max(G, std::atoi(e)));
+  const int Kg = swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
+  if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->narrow_variant != 1) {
+    const int K = Kg;
     swa_narrow_params p{};
     p.query = db->query.p;
     p.stream = db->main.stream.p;
@@ -513,15 +510,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.negKR = f16_pair(-float(int64_t(K) * db->ge));
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
-    c.narrow_shifted = split ? (G == 8 ? 2 : 3) : 1;
-    const int per_wave = split ? 16 / G : 1;                        // the G-lane forms take 16 / G batches per wave
+    c.narrow_shifted = G == 8 ? 2 : G == 4 ? 3 : 1;
+    const int per_wave = 16 / G;                                    // a wave takes 16 / G batches at a time
     const int items = (p.nbatches + per_wave - 1) / per_wave;
     int blocks = persistent_blocks(db, items);
-    if (const char* w = std::getenv("SWA_WAVES")) p.waves = std::atoi(w);
     p.pipe = -1;
     if (const char* w = std::getenv("SWA_PIPE")) p.pipe = std::atoi(w);
     if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((items + 3) / 4, db->cus * std::atoi(w)));
-    HIP_TRY(split ? swa_launch_narrow_split(G, K, &p, blocks, st) : swa_launch_narrow(K, &p, blocks, st));
+    HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
