@@ -39,6 +39,8 @@ hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* off
 hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
 hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
+int swa_dual_rows_for(int qlen, int nres);
+hipError_t swa_launch_dual(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
@@ -596,7 +598,45 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (rc != SWA_OK) return rc;
   std::vector<int32_t> rq1, rq2;
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  if (f16_applicable(db) && f16_limit(db, mp_rows_for(1, qlen)) >= 1024) {
+  // single pass with the whole query in registers when it fits (nucleotide alphabets: 1024 rows, others 512);
+  // SWA_DUAL_MP=1 forces the multi-pass kernel (A/B, tests)
+  const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
+  const bool dual_mp = std::getenv("SWA_DUAL_MP") && std::atoi(std::getenv("SWA_DUAL_MP")) == 1;
+  const int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres);
+  if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
+    swa_mp_params p{};
+    p.qseq = db->qseq.p;
+    p.qseq2 = db->qseq2.p;
+    p.matrix = db->matrix.p;
+    p.qlen = int32_t(qlen);
+    p.rows_per_lane = Kd;
+    p.npass = 1;
+    p.stream = db->single.stream.p;
+    p.batches = db->single.batches.p;
+    p.slots = db->single.slots.p;
+    p.nbatches = db->single.nbatches;
+    p.counter = db->ctl.p + 0;
+    p.scores = db->scores.p;
+    p.scores2 = db->scores2.p;
+    p.limit = f16_limit(db, Kd);
+    p.ovf_count = db->ctl.p + 1;
+    p.ovf_list = db->ovf_list.p;
+    p.ovf_count2 = db->ctl.p + 3;
+    p.ovf_list2 = db->ovf_list2.p;
+    p.gapextend_f = float(db->ge);
+    p.negQR = f16_pair(-float(db->goe - db->ge));
+    p.negR = f16_pair(-float(db->ge));
+    p.negKR = f16_pair(-float(int64_t(Kd) * db->ge));
+    for (int i = 0; i <= Kd + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
+    HIP_TRY(swa_launch_dual(Kd, nres, &p, db->cus, st));
+    c.narrow_rows = Kd;
+    c.narrow_shifted = 4;                                // single-pass dual kernel
+    c.narrow = db->nseq;
+    HIP_TRY(hipEventRecord(db->ev[2], st));
+    rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
+    if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
+    if (rc != SWA_OK) return rc;
+  } else if (f16_applicable(db) && f16_limit(db, mp_rows_for(1, qlen)) >= 1024) {
     MpRun r;
     r.mode = 1;
     r.set = &db->single;

@@ -305,6 +305,38 @@ def test_dual_query_kernel_both_strands(qlen):
     db.close()
 
 
+@pytest.mark.parametrize("protein", [False, True])
+def test_every_instantiation_of_the_single_pass_dual_kernel(protein, monkeypatch):
+    """two queries of equal length in one pass, K = ceil(qlen / 16): every K of the nucleotide build (1..64) and of
+    the protein build (1..32), and the multi-pass kernel as cross-check at the ends"""
+    tab = synth.residue_table_protein() if protein else synth.residue_table_nucleotide()
+    full = synth._random_residues(55, 1, 1024, tab)
+    res, off = swipe_amd.synth_db(9, 250, protein=protein)
+    seqs = [res[off[i]:off[i + 1]] for i in range(250)] + [full, full[200:900].copy(), np.zeros(0, np.uint8)]
+    if not protein:
+        seqs += [blastdb.revcomp_nt16(full[100:800])]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2, symtype=1 if protein else 0)
+    if protein:
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        Mo, goe, ge = oracle.matrix_builtin("BLOSUM62"), 12, 1
+    else:
+        db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+        Mo, goe, ge = oracle.matrix_nucleotide(1, -3), 7, 2
+    for K in range(1, (32 if protein else 64) + 1):
+        qlen = 16 * K - (K % 16)
+        q1 = full[:qlen]
+        q2 = q1[::-1].copy() if protein else blastdb.revcomp_nt16(q1)
+        s1, s2, c = db.search2(q1, q2)
+        assert c["narrow_rows"] == K and c["narrow_shifted"] == 4
+        assert np.array_equal(s1, oracle.search_all63(r2, o2, q1, Mo, goe, ge, threads=THREADS)), K
+        assert np.array_equal(s2, oracle.search_all63(r2, o2, q2, Mo, goe, ge, threads=THREADS)), K
+    monkeypatch.setenv("SWA_DUAL_MP", "1")
+    t1, t2, c = db.search2(q1, q2)
+    assert c["narrow_shifted"] == 1 and np.array_equal(t1, s1) and np.array_equal(t2, s2)
+    db.close()
+
+
 @pytest.mark.parametrize("K", ["16", "24", "32"])
 def test_multipass_pair_kernel_rows_per_lane(monkeypatch, K):
     """every rows-per-lane build of the multi-pass pair kernel (SWA_MP_K override) on a long protein query"""
