@@ -39,8 +39,8 @@ hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* off
 hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
 hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
-int swa_dual_rows_for(int qlen, int nres);
-hipError_t swa_launch_dual(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
+int swa_dual_rows_for(int qlen, int nres, int G);
+hipError_t swa_launch_dual(int K, int nres, int G, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
@@ -602,8 +602,12 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   // SWA_DUAL_MP=1 forces the multi-pass kernel (A/B, tests)
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
   const bool dual_mp = std::getenv("SWA_DUAL_MP") && std::atoi(std::getenv("SWA_DUAL_MP")) == 1;
-  const int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres);
+  // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
+  int Gd = qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
+  if (const char* e = std::getenv("SWA_LANES")) Gd = std::min(16, std::max(Gd, std::atoi(e)));
+  const int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
+    const BatchSet& set = Gd == 16 ? db->single : db->main;
     swa_mp_params p{};
     p.qseq = db->qseq.p;
     p.qseq2 = db->qseq2.p;
@@ -611,10 +615,10 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     p.qlen = int32_t(qlen);
     p.rows_per_lane = Kd;
     p.npass = 1;
-    p.stream = db->single.stream.p;
-    p.batches = db->single.batches.p;
-    p.slots = db->single.slots.p;
-    p.nbatches = db->single.nbatches;
+    p.stream = set.stream.p;
+    p.batches = set.batches.p;
+    p.slots = set.slots.p;
+    p.nbatches = set.nbatches;
     p.counter = db->ctl.p + 0;
     p.scores = db->scores.p;
     p.scores2 = db->scores2.p;
@@ -628,7 +632,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     p.negR = f16_pair(-float(db->ge));
     p.negKR = f16_pair(-float(int64_t(Kd) * db->ge));
     for (int i = 0; i <= Kd + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
-    HIP_TRY(swa_launch_dual(Kd, nres, &p, db->cus, st));
+    HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
     c.narrow_rows = Kd;
     c.narrow_shifted = 4;                                // single-pass dual kernel
     c.narrow = db->nseq;

@@ -305,10 +305,12 @@ def test_dual_query_kernel_both_strands(qlen):
     db.close()
 
 
+@pytest.mark.parametrize("lanes", [16, 8, 4])
 @pytest.mark.parametrize("protein", [False, True])
-def test_every_instantiation_of_the_single_pass_dual_kernel(protein, monkeypatch):
-    """two queries of equal length in one pass, K = ceil(qlen / 16): every K of the nucleotide build (1..63) and of
-    the protein build (1..32), and the multi-pass kernel as cross-check at the ends"""
+def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monkeypatch):
+    """two queries of equal length in one pass, K = ceil(qlen / lanes): every K of the nucleotide build (1..63 with
+    16-lane chains, 1..32 with 8 / 4) and of the protein build (1..32), and the multi-pass kernel as cross-check"""
+    monkeypatch.setenv("SWA_LANES", str(lanes))
     tab = synth.residue_table_protein() if protein else synth.residue_table_nucleotide()
     full = synth._random_residues(55, 1, 1024, tab)
     res, off = swipe_amd.synth_db(9, 250, protein=protein)
@@ -323,8 +325,8 @@ def test_every_instantiation_of_the_single_pass_dual_kernel(protein, monkeypatch
     else:
         db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
         Mo, goe, ge = oracle.matrix_nucleotide(1, -3), 7, 2
-    for K in range(1, (32 if protein else 63) + 1):
-        qlen = 16 * K - (K % 16)
+    for K in range(1, (32 if (protein or lanes < 16) else 63) + 1):
+        qlen = lanes * K - (K % lanes)
         q1 = full[:qlen]
         q2 = q1[::-1].copy() if protein else blastdb.revcomp_nt16(q1)
         s1, s2, c = db.search2(q1, q2)

@@ -12,12 +12,13 @@ db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
 for qlen in map(int, sys.argv[1:]):
     q = full[:qlen]; qm = blastdb.revcomp_nt16(q)
     out = []
-    for mp in ("0", "1"):
-        os.environ["SWA_DUAL_MP"] = mp
+    for mp in ("0", "16", "1"):
+        os.environ["SWA_DUAL_MP"] = "1" if mp == "1" else "0"
+        os.environ["SWA_LANES"] = "16" if mp == "16" else "4"
         db.search2(q, qm, want_scores=False)
         best, c = 1e9, None
         for _ in range(3):
             _, _, c = db.search2(q, qm, want_scores=False)
             best = min(best, c["kernel_ms"])
-        out.append("%s K=%2d %.0f GCUPS" % ("multi-pass" if mp == "1" else "single-pass", c["narrow_rows"], c["cells"] / best / 1e6))
-    print("qlen %4d: %s | %s" % (qlen, out[0], out[1]), flush=True)
+        out.append("%s K=%2d %.0f GCUPS" % ({"0": "short chains", "16": "16-lane", "1": "multi-pass"}[mp], c["narrow_rows"], c["cells"] / best / 1e6))
+    print("qlen %4d: %s" % (qlen, " | ".join(out)), flush=True)
