@@ -1,0 +1,66 @@
+// Device primitives shared by the kernel translation units (sw_kernels.hip, sw_mp_kernels.hip).
+#ifndef SW_COMMON_CUH
+#define SW_COMMON_CUH
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sw_device.h"
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------ packed f16 primitives
+// hipcc lowers __builtin_elementwise_maximum on a 2 x f16 vector to v_pk_maximum3_f16 (fusing
+// nested calls and literal zero operands) without canonicalising inputs; a + b is v_pk_add_f16.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 pk_max(h2 a, h2 b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ h2 pk_max3(h2 a, h2 b, h2 c)
+{ return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
+__device__ __forceinline__ h2 as_h2(u32 v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ u32 as_u32(h2 v) { return __builtin_bit_cast(u32, v); }
+
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_SHL1 0x101
+#define DPP_ROW_SHR(n) (0x110 + (n))
+
+// value of lane-1 within the 16-lane row; lane 0 of each row receives `fill`
+__device__ __forceinline__ u32 row_shr1(u32 v, u32 fill)
+{ return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_ROW_SHR1, 0xF, 0xF, false); }
+__device__ __forceinline__ u32 row_shl1(u32 v)
+{ return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHL1, 0xF, 0xF, false); }
+
+__device__ __forceinline__ u32 float_to_half_bits(float f)
+{ _Float16 x = (_Float16)f; unsigned short s; __builtin_memcpy(&s, &x, 2); return s; }
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u4v* lds_u4_ptr;
+
+// scores of the 8 sequences of a batch + overflow re-queue: ballot, one atomic per wave, compacted append
+__device__ __forceinline__ void narrow_write_scores(const swa_narrow_params& p, int b, int lane, h2 S)
+{
+  const bool writer = (lane & 15) == 15;
+  const int grp = lane >> 4;
+  int sA = -1, sB = -1, idA = -1, idB = -1;
+  if (writer) {
+    idA = p.slots[(int64_t)b * SWA_SLOTS + grp * 2];
+    idB = p.slots[(int64_t)b * SWA_SLOTS + grp * 2 + 1];
+    sA = (int)(float)S.x;
+    sB = (int)(float)S.y;
+    if (idA >= 0) p.scores[idA] = sA;
+    if (idB >= 0) p.scores[idB] = sB;
+  }
+  // overflow re-queue: ballot, one atomic per wave, compacted append
+  const bool oA = writer && idA >= 0 && sA >= p.limit;
+  const bool oB = writer && idB >= 0 && sB >= p.limit;
+  const u64 mA = __ballot(oA), mB = __ballot(oB);
+  const int nA = __popcll(mA), nB = __popcll(mB);
+  if (nA + nB) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(p.ovf_count, nA + nB);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const u64 below = (1ull << lane) - 1;
+    if (oA) p.ovf_list[base + __popcll(mA & below)] = idA;
+    if (oB) p.ovf_list[base + nA + __popcll(mB & below)] = idB;
+  }
+}
+
+#endif
