@@ -110,7 +110,7 @@ def nucleotide_main(a, rank, local, world):
                       "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True,
                       "dtype": "f16x2 (plus strand | minus strand)", "data": "synthetic",
                       "config": {"workload": f"1000-nt query, both strands, vs {a.nseq} nt sequences ({int(off[-1])} bases), "
-                                             "+1/-3, gap 5+2", "kernel": "swa_mp_kernel<pol_f16_dual,%d>" % c["narrow_rows"]},
+                                             "+1/-3, gap 5+2", "kernel": ("swa_dual_kernel<%d, W, 16, G>" if c["narrow_shifted"] == 4 else "swa_mp_kernel<pol_f16_dual, %d>") % c["narrow_rows"]},
                       "kernel_ms": round(float(np.mean(kms)), 3), "totalhits": int(tot)}), flush=True)
     db.close()
 
@@ -240,10 +240,17 @@ def main():
             except Exception as e:   # a missing baseline must not lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": cores, "kind": "reference",
                                        "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     db.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to C stdout, block-buffered when piped, i.e. at exit - AFTER anything Python
+        # printed.  Drain the C buffers first so that the JSON line is the last line on stdout.
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
