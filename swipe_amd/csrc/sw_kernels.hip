@@ -67,37 +67,73 @@ swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restric
 // Six-frame translation of a nucleotide shard into the protein residues the DP kernels consume - the
 // pre-pass for translated-database searches (-p 3 / -p 4).  db_translate (database.cc:1182-1218): virtual
 // sequence v = 6*s + 3*strand + frame holds (len_s - frame) / 3 residues, table[256a + 16b + c] over the
-// three IUPAC nibbles of a codon, strand 1 reading the reverse complement.  One thread per output residue
-// (located by binary search in the virtual offsets, which stay L2 resident), so a chromosome-sized
-// sequence and a thousand short reads load the GPU alike; writes are coalesced, each nucleotide line is
-// read by six frames out of L2.  HBM-bound: 1 B read + 2 B written per base.
+// three IUPAC nibbles of a codon, strand 1 reading the reverse complement.  One thread per output residue,
+// consecutive lanes on consecutive residues, so writes are coalesced and a wave reads 192 contiguous
+// nucleotide bytes per load; a chromosome-sized sequence and a thousand short reads load the GPU alike.
+// A block takes 4096 consecutive output residues: one thread locates the first virtual sequence by binary
+// search in the global offsets, the block stages the next 2048 offsets in LDS and every output finds its
+// sequence by an 11-step search there (a tile crossing more than 2048 sequence boundaries - average length
+// below 2 - falls back to the global search).  HBM-bound: 1 B read + 2 B written per base.
+#define SWA_TR_TILE 4096
+#define SWA_TR_WIN 2048
 extern "C" __global__ void __launch_bounds__(256)
 swa_translate_frames(const uint8_t* __restrict__ nt, const int64_t* __restrict__ ntoff,
                      const int64_t* __restrict__ voff, int64_t nv, const uint8_t* __restrict__ table,
                      uint8_t* __restrict__ prot, int64_t total)
 {
   __shared__ uint8_t tab[4096];
+  __shared__ int64_t win[SWA_TR_WIN + 1];
+  __shared__ int64_t s_v0;
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) tab[i] = table[i];
-  __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += stride) {
-    int64_t lo = 0, hi = nv;                              // largest v with voff[v] <= r
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (voff[mid] <= r) lo = mid; else hi = mid;
+  for (int64_t r0 = (int64_t)blockIdx.x * SWA_TR_TILE; r0 < total; r0 += (int64_t)gridDim.x * SWA_TR_TILE) {
+    const int64_t r1 = r0 + SWA_TR_TILE < total ? r0 + SWA_TR_TILE : total;
+    if (threadIdx.x == 0) {
+      int64_t lo = 0, hi = nv;                            // largest v with voff[v] <= r0
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (voff[mid] <= r0) lo = mid; else hi = mid;
+      }
+      s_v0 = lo;
     }
-    const int64_t s = lo / 6, k = r - voff[lo];
-    const int t = (int)(lo - 6 * s), f = t % 3;
-    const int64_t o = ntoff[s], len = ntoff[s + 1] - o;
-    u32 a, b, c;
-    if (t < 3) {
-      const uint8_t* p = nt + o + f + 3 * k;
-      a = p[0] & 15; b = p[1] & 15; c = p[2] & 15;
-    } else {                                              // complement of a nibble = its 4 bits reversed
-      const uint8_t* p = nt + o + len - 1 - f - 3 * k;
-      a = __brev((u32)p[0]) >> 28; b = __brev((u32)p[-1]) >> 28; c = __brev((u32)p[-2]) >> 28;
+    __syncthreads();
+    const int64_t v0 = s_v0;
+    for (int i = threadIdx.x; i <= SWA_TR_WIN; i += blockDim.x)
+      win[i] = v0 + i <= nv ? voff[v0 + i] : INT64_MAX;
+    __syncthreads();
+    const bool covered = win[SWA_TR_WIN] >= r1;           // every boundary of the tile is in the window
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+      int64_t v, vo;
+      if (covered) {
+        int lo = 0, hi = SWA_TR_WIN;                      // largest i with win[i] <= r
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (win[mid] <= r) lo = mid; else hi = mid;
+        }
+        v = v0 + lo;
+        vo = win[lo];
+      } else {
+        int64_t lo = v0, hi = nv;
+        while (hi - lo > 1) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (voff[mid] <= r) lo = mid; else hi = mid;
+        }
+        v = lo;
+        vo = voff[lo];
+      }
+      const int64_t sq = v / 6, k = r - vo;
+      const int t = (int)(v - 6 * sq), f = t % 3;
+      const int64_t o = ntoff[sq], len = ntoff[sq + 1] - o;
+      u32 a, b, c;
+      if (t < 3) {
+        const uint8_t* p = nt + o + f + 3 * k;
+        a = p[0] & 15; b = p[1] & 15; c = p[2] & 15;
+      } else {                                            // complement of a nibble = its 4 bits reversed
+        const uint8_t* p = nt + o + len - 1 - f - 3 * k;
+        a = __brev((u32)p[0]) >> 28; b = __brev((u32)p[-1]) >> 28; c = __brev((u32)p[-2]) >> 28;
+      }
+      prot[r] = tab[256 * a + 16 * b + c];
     }
-    prot[r] = tab[256 * a + 16 * b + c];
+    __syncthreads();
   }
 }
 
@@ -772,8 +808,8 @@ extern "C" hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* nto
                                            const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st)
 {
   if (total <= 0) return hipSuccess;
-  const int64_t want = (total + 255) / 256;
-  const int blocks = (int)(want < 16384 ? want : 16384);
+  const int64_t want = (total + SWA_TR_TILE - 1) / SWA_TR_TILE;
+  const int blocks = (int)(want < 8192 ? want : 8192);
   hipLaunchKernelGGL(swa_translate_frames, dim3(blocks), dim3(256), 0, st, nt, ntoff, voff, nv, table, prot, total);
   return hipGetLastError();
 }

@@ -522,6 +522,22 @@ def test_translated_scores_equal_reference(name):
     db.close()
 
 
+def test_six_frame_translation_at_awkward_shapes():
+    """swa_translate_frames: thousands of empty / 1..5-base sequences in a row (more sequence boundaries per tile than
+    the LDS window holds -> global-search fallback), one sequence spanning hundreds of tiles, ambiguity codes"""
+    rng = np.random.default_rng(3)
+    seqs = [rng.integers(1, 16, int(n)).astype(np.uint8) for n in rng.integers(0, 6, 9000)]
+    seqs += [rng.integers(1, 16, 700_001).astype(np.uint8)]
+    seqs += [rng.integers(1, 16, int(n)).astype(np.uint8) for n in rng.integers(0, 400, 300)]
+    res, off = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(res, off, translate_gencode=11)
+    t = oracle.translate_table(11)
+    for s in list(range(0, 9000, 97)) + [8998, 8999, 9000, 9001, 9150, len(seqs) - 1]:
+        for tag in range(6):
+            assert np.array_equal(db.sequence(s, tag // 3, tag % 3), oracle.translate(seqs[s], tag // 3, tag % 3, t)), (s, tag)
+    db.close()
+
+
 @pytest.mark.parametrize("name", TNAMES)
 def test_translated_hit_list_and_alignments_equal_reference(name):
     case, g = cases.get(name), load_golden(name)
