@@ -312,10 +312,17 @@ struct MpRun {
 
 int mp_rows_for(int mode, int64_t qlen)
 {
-  if (mode == 0) return 16;
   // measured on MI355X (tools/gpu_nt_knobs.py): 16 rows per lane at 4 waves/SIMD beats 24 or 32 rows at
-  // 3 or 2 waves even though it needs more passes
-  if (mode == 1 || mode == 2) return qlen <= 128 ? 8 : 16;
+  // 3 or 2 waves even though it needs more passes.  For the f16 policies the passes are then made as even as
+  // the query allows: npass = ceil(qlen / 256), K = ceil(qlen / (16 npass)) in 9..16, so that at most
+  // 16 npass - 1 padding rows are computed (769 rows: 4 passes of 13 rows per lane instead of 16)
+  if (mode == 0 || mode == 1) {
+    if (mode == 1 && qlen <= 128) return 8;
+    const int64_t npass = (qlen + 255) / 256;
+    const int64_t k = (qlen + 16 * npass - 1) / (16 * npass);
+    return int(std::max<int64_t>(9, std::min<int64_t>(16, k)));
+  }
+  if (mode == 2) return qlen <= 128 ? 8 : 16;
   return 8;
 }
 
@@ -354,7 +361,8 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   p.negKR = f16_pair(-float(int64_t(K) * db->ge));
   for (int i = 0; i <= K + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
 
-  const size_t lds = size_t(32) * (K / (r.mode == 0 ? 8 : 4)) * 256;
+  const int rpu = r.mode == 0 ? 8 : 4;
+  const size_t lds = size_t(32) * ((K + rpu - 1) / rpu) * 256;
   // resident waves per SIMD the kernel's VGPR count allows (-Rpass-analysis=kernel-resource-usage)
   int wps = swa_mp_waves(r.mode, K);
   if (const char* e = std::getenv("SWA_MP_W")) { p.tune_w = std::atoi(e); if (r.mode == 1 && K == 32) wps = p.tune_w; }
