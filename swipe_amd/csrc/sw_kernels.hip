@@ -719,7 +719,7 @@ static constexpr int split_waves_for(int K) { return K <= 8 ? 8 : K <= 12 ? 6 : 
 extern "C" int swa_narrow_rows_split(int qlen, int G)
 {
   const int k = (qlen + G - 1) / G;
-  return k < 1 ? 1 : k <= 48 ? k : 0;
+  return k < 1 ? 1 : k <= (G == 16 ? 58 : 48) ? k : 0;
 }
 // pipelined profile loads (16 staging registers instead of 8 C) keep K = 32..36 at three waves per SIMD; measured
 // per K on MI355X (tools/gpu_pipe_sweep.py): +4 % at K = 32, +8 % at K = 35 and 36, no gain or a loss elsewhere
@@ -744,8 +744,22 @@ template <int G> static hipError_t launch_split_pipe2(int K, const swa_narrow_pa
   }
 #undef SWA_SX_CASE
 }
+// 16-lane chains only: K = 49..58 rows per lane (queries of 769..928 rows in one pass) with the pipelined
+// profile loads, two waves per SIMD; from K = 59 on the registers of two resident waves no longer hold 3 K values
+// without spilling 80+ bytes and the multi-pass kernel takes over
+static hipError_t launch_split_long(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_SL_CASE(KK) case KK: return launch_narrow_split<KK, 2, 16, 1>(*p, blocks, st);
+  switch (K) {
+    SWA_SL_CASE(49) SWA_SL_CASE(50) SWA_SL_CASE(51) SWA_SL_CASE(52) SWA_SL_CASE(53) SWA_SL_CASE(54) SWA_SL_CASE(55) SWA_SL_CASE(56)
+    SWA_SL_CASE(57) SWA_SL_CASE(58)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_SL_CASE
+}
 template <int G> static hipError_t launch_split_any(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
+  if (G == 16 && K > 48) return launch_split_long(K, p, blocks, st);
   if ((p->pipe == 2 && K >= 45) || (p->pipe < 0 && K >= 47 && G < 16)) return launch_split_pipe2<G>(K, p, blocks, st);
   const bool pipe = p->pipe == 1 || (p->pipe < 0 && (K == 32 || K == 35 || K == 36));      // pipe: 1 / 0 forced, -1 auto
   if (pipe && K >= 30 && K <= 36) return launch_split_pipe<G>(K, p, blocks, st);

@@ -492,7 +492,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   const bool f16 = f16_applicable(db);
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
-  const bool single_pass = qlen <= 16 * 48 && K > 0 && !force_mp;
+  const bool single_pass = qlen <= 16 * 58 && K > 0 && !force_mp;
   HIP_TRY(hipEventRecord(db->ev[1], st));
   // G = 4 (up to 192 rows), 8 (up to 384) or 16 (up to 768) lanes per sequence pair, K = ceil(qlen / G) rows per
   // lane (SWA_LANES = 8 / 16 forces a longer chain: A/B runs and tests)

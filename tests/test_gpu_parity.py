@@ -148,14 +148,14 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
     queries of at most 384 rows, 4 for at most 192): one query per instantiation, at both ends of its window"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     rtab = synth.residue_table_protein()
-    full = synth._random_residues(99, 1, 768, rtab)
+    full = synth._random_residues(99, 1, 928, rtab)
     res, off = swipe_amd.synth_db(6, 400, query=full)
     seqs = [res[off[i]:off[i + 1]] for i in range(400)] + [full, full[100:500].copy(), full[::-1].copy(), np.zeros(0, np.uint8)]
     r2, o2 = oracle.pack(seqs)
     db = swipe_amd.Database.from_arrays(r2, o2)
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     Mo = oracle.matrix_builtin("BLOSUM62")
-    for K in range(1, 49):
+    for K in range(1, 59 if lanes == 16 else 49):
         for qlen in (lanes * K - lanes + 1, lanes * K):
             q = full[:qlen]
             scores, c = db.search(q)
