@@ -91,6 +91,7 @@ struct BatchSet {
   DevBuf<uint16_t> stream;
   int nbatches = 0;
   int64_t chunks = 0;
+  std::vector<int32_t> h_steps;             // steps of every batch (non-increasing: batches are cut from a length-sorted list)
 };
 
 uint16_t f16_bits(float f)
@@ -203,6 +204,8 @@ int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchS
   }
   bs.nbatches = int(nb);
   bs.chunks = int64_t(chunk_total);
+  bs.h_steps.resize(size_t(nb));
+  for (int64_t b = 0; b < nb; ++b) bs.h_steps[size_t(b)] = batches[size_t(b)].steps;
   return SWA_OK;
 }
 
@@ -374,11 +377,46 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   const int per_cu = std::max(1, std::min(by_lds, waves_cu / nw));
   const int supers = (p.nbatches + nw - 1) / nw;
   const int blocks = std::max(1, std::min(supers, db->cus * per_cu));
-  if (p.npass > 1) {
+  if (p.npass > 1 && p.nbatches > 0) {
+    // Bottom-row hand-over between passes: every resident wave owns (columns of its batch + 48) x 4 rows x (H, F).
+    // Sized by the longest sequence that would be chromosome-scale memory for a few batches of a genome database,
+    // so the budget is bounded and the batches that do not fit it run first, on as few waves as their size allows.
     const size_t vbytes = r.mode == 3 ? 8 : 4;
-    p.boundary_cols = int32_t(((db->longest + 1) & ~int64_t(1)) + 48);
-    HIP_TRY(db->boundary.reserve(size_t(blocks) * nw * size_t(p.boundary_cols) * 8 * vbytes));
-    p.boundary = db->boundary.p;
+    const size_t per_col = 8 * vbytes;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = std::min<size_t>(size_t(4) << 30, (free_b + db->boundary.bytes()) / 4);
+    if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
+    const int64_t need = int64_t(r.set->h_steps.empty() ? db->longest : r.set->h_steps[0]) + 48;
+    const int64_t cols_all = int64_t(budget / (size_t(blocks) * nw * per_col));
+    if (need <= cols_all) {
+      p.boundary_cols = int32_t(need);
+      HIP_TRY(db->boundary.reserve(size_t(blocks) * nw * size_t(need) * per_col));
+      p.boundary = db->boundary.p;
+    } else {
+      // batches [0, i0) are too long for the common allotment
+      const std::vector<int32_t>& hs = r.set->h_steps;
+      const int64_t fit = std::max<int64_t>(cols_all, 64);
+      const int i0 = int(std::partition_point(hs.begin(), hs.end(), [&](int32_t st) { return int64_t(st) + 48 > fit; }) - hs.begin());
+      const int supers_a = (i0 + nw - 1) / nw;
+      int blocks_a = int(std::max<int64_t>(1, std::min<int64_t>(supers_a, int64_t(budget / (size_t(nw) * size_t(need) * per_col)))));
+      const size_t bytes_a = size_t(blocks_a) * nw * size_t(need) * per_col;
+      const size_t bytes_b = size_t(blocks) * nw * size_t(fit) * per_col;
+      if (bytes_a > free_b + db->boundary.bytes())
+        return fail(SWA_ENOMEM, "a database sequence is too long for the multi-pass kernel's hand-over buffer; use a shorter query");
+      HIP_TRY(db->boundary.reserve(std::max(bytes_a, bytes_b)));
+      p.boundary = db->boundary.p;
+      swa_mp_params pa = p;
+      pa.nbatches = i0;
+      pa.boundary_cols = int32_t(need);
+      HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
+      HIP_TRY(swa_launch_mp(r.mode, K, &pa, blocks_a, threads, st));
+      p.batches = r.set->batches.p + i0;
+      p.slots = r.set->slots.p + size_t(i0) * SWA_SLOTS;
+      p.nbatches = r.set->nbatches - i0;
+      p.boundary_cols = int32_t(fit);
+      if (p.nbatches <= 0) return SWA_OK;
+    }
   }
   HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
   HIP_TRY(swa_launch_mp(r.mode, K, &p, blocks, threads, st));

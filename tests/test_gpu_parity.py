@@ -339,6 +339,32 @@ def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monk
     db.close()
 
 
+@pytest.mark.parametrize("two", [False, True])
+def test_multipass_hand_over_buffer_is_bounded(two, monkeypatch):
+    """a database whose longest sequences do not fit the common allotment of the pass hand-over buffer: those batches
+    run first on fewer waves, the rest with the bounded allotment - same scores (SWA_BOUNDARY_MB shrinks the budget)"""
+    monkeypatch.setenv("SWA_BOUNDARY_MB", "8")
+    tab = synth.residue_table_nucleotide() if two else synth.residue_table_protein()
+    q = synth._random_residues(61, 1, 1300, tab)
+    res, off = swipe_amd.synth_db(11, 3000, protein=not two)
+    seqs = [res[off[i]:off[i + 1]] for i in range(3000)]
+    seqs += [synth._random_residues(62 + k, 1, n, tab) for k, n in enumerate([20000, 9000, 9001, 4000])] + [np.concatenate([seqs[0], q[100:1200], seqs[1]])]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2, symtype=0 if two else 1)
+    if two:
+        db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+        Mo, goe, ge = oracle.matrix_nucleotide(1, -3), 7, 2
+        q2 = blastdb.revcomp_nt16(q)
+        s1, s2, c = db.search2(q, q2)
+        assert np.array_equal(s2, oracle.search_all63(r2, o2, q2, Mo, goe, ge, threads=THREADS))
+    else:
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        Mo, goe, ge = oracle.matrix_builtin("BLOSUM62"), 12, 1
+        s1, c = db.search(q)
+    assert np.array_equal(s1, oracle.search_all63(r2, o2, q, Mo, goe, ge, threads=THREADS))
+    db.close()
+
+
 @pytest.mark.parametrize("K", ["16", "24", "32"])
 def test_multipass_pair_kernel_rows_per_lane(monkeypatch, K):
     """every rows-per-lane build of the multi-pass pair kernel (SWA_MP_K override) on a long protein query"""
