@@ -313,3 +313,23 @@ def test_frame_hit_merge_over_shards_equals_single_list(name):
     got = [lab(m[2], m[3]) if case.sym == 2 else lab(m[4], m[5]) if case.sym == 3 else lab(m[2], m[3]) + "/" + lab(m[4], m[5])
            for m in merged]
     assert got == cli["strand"]
+
+
+def test_makedb_fasta_to_v4_volumes(tmp_path):
+    """python -m swipe_amd.makedb: FASTA in, volumes the C++ reader (and the reference) open; multi-volume alias"""
+    from swipe_amd import makedb
+    case = cases.get("edges")
+    fa = tmp_path / "in.fasta"
+    with open(fa, "w") as f:
+        for i, s in enumerate(case.seqs):
+            text = "".join(blastdb.NCBISTDAA[c] for c in s)
+            f.write(">id%d some title %d\n" % (i, i) + "\n".join(text[k:k + 60] for k in range(0, len(text), 60)) + "\n")
+    assert makedb.main([str(fa), str(tmp_path / "one")]) == 0
+    assert makedb.main(["--volume-residues", "900", str(fa), str(tmp_path / "many")]) == 0
+    r2, o2 = oracle.pack(case.seqs)
+    for base in ("one", "many"):
+        res, off, info = swipe_amd.read_blastdb(str(tmp_path / base))
+        assert np.array_equal(res, r2) and np.array_equal(off, o2)
+    assert os.path.exists(tmp_path / "many.pal")
+    h = swipe_amd.Headers(str(tmp_path / "many"))
+    assert h.get(5) == ["lcl|id5 some title 5"] and h.get(len(case.seqs) - 1) == ["lcl|id%d some title %d" % (len(case.seqs) - 1, len(case.seqs) - 1)]
