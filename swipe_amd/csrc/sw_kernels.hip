@@ -286,7 +286,7 @@ __device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, cons
   }
 }
 
-template <int K, int W, int G, int PIPE>
+template <int K, int W, int G, int PIPE, bool DEFER>
 __global__ void __launch_bounds__(256, W)
 swa_narrow_split_kernel(swa_narrow_params p)
 {
@@ -344,7 +344,16 @@ swa_narrow_split_kernel(swa_narrow_params p)
             H[r] = h;                                                                          \
             const h2 t = h + negQR;                                                            \
             F = pk_max(F, t);                                                                  \
-            E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2])) + negR;                              \
+            /* the -R of the E update is issued one row later: a packed op consumed by the very next \
+               instruction costs a wait state (the compiler pads it with s_nop) */            \
+            const h2 em = pk_max3(E[r], t, as_h2(p.rowc[r + 2]));                              \
+            if constexpr (DEFER) {                                                             \
+              if ((r) > 0) E[(r) - 1] = eprev + negR;                                          \
+              eprev = em;                                                                      \
+              if ((r) == K - 1) E[r] = eprev + negR;                                           \
+            } else {                                                                           \
+              E[r] = em + negR;                                                                \
+            }                                                                                  \
           }
 #define SWA_STEPG(ODD)                                                                         \
     {                                                                                          \
@@ -355,6 +364,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
       const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
       h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
       h2 hd = diag;                                                                            \
+      h2 eprev = zero;                                                                         \
       diag = hup;                                                                              \
       const u32 aoff = (cur & 0xFFFF) | l16;                                                   \
       const u32 boff = (cur >> 16) | l16;                                                      \
@@ -426,6 +436,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
         const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
         h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
         h2 hd = diag;                                                                          \
+        h2 eprev = zero;                                                                       \
         diag = hup;                                                                            \
         _Pragma("unroll") for (int c = 0; c < C; ++c) {                                        \
           const u4v ua = na, ub = nb;                                                          \
@@ -697,14 +708,22 @@ static hipError_t launch_narrow(const swa_narrow_params& p, int blocks, hipStrea
   hipLaunchKernelGGL(swa_narrow_kernel<K>, dim3(blocks), dim3(256), lds, st, p);
   return hipGetLastError();
 }
+template <int K, int W, int G, int PIPE, bool DEFER>
+static hipError_t launch_narrow_split_d(const swa_narrow_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_split_kernel<K, W, G, PIPE, DEFER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((swa_narrow_split_kernel<K, W, G, PIPE, DEFER>), dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+// DEFER (the -R of the E update issued one row later, which spares the compiler a wait state between two dependent
+// packed ops) was swept over every (G, K) on MI355X with both builds instantiated: +2 % for 16-lane chains of 48..58 rows,
+// within noise everywhere else - so it is compiled in exactly there
 template <int K, int W, int G, int PIPE>
 static hipError_t launch_narrow_split(const swa_narrow_params& p, int blocks, hipStream_t st)
 {
-  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)swa_narrow_split_kernel<K, W, G, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((swa_narrow_split_kernel<K, W, G, PIPE>), dim3(blocks), dim3(256), lds, st, p);
-  return hipGetLastError();
+  return launch_narrow_split_d<K, W, G, PIPE, (G == 16 && K >= 48)>(p, blocks, st);
 }
 extern "C" int swa_narrow_rows_for(int qlen)
 {
