@@ -268,6 +268,7 @@ void usage(const char* prog)
   std::printf("  -I, --show_gis             show gi numbers in results (no)\n");
   std::printf("  -H, --show_taxid           show taxid etc in results (no)\n");
   std::printf("  -x, --taxidlist=FILE       taxid list filename (none)\n");
+  std::printf("  -N, --dump=NUM             dump database [0-2=no,yes,split headers] (0)\n");
   std::printf("  -Q, --query_gencode=NUM    query genetic code [1-23] (1)\n");
   std::printf("  -D, --db_gencode=NUM       database genetic code [1-23] (1)\n");
   std::printf("  -S, --strand=NAME/NUM      query strands to search [1-3] (3)\n");
@@ -283,7 +284,7 @@ int main(int argc, char** argv)
   bool show_gis = false, show_taxid = false;
   long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
   long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100, query_gencode = 1, db_gencode = 1;
-  long threads = 1;
+  long threads = 1, dump = 0;
   double expect = 10.0, minexpect = 0.0;
   static const option longopts[] = {
       {"db", 1, 0, 'd'}, {"query", 1, 0, 'i'}, {"matrix", 1, 0, 'M'}, {"penalty", 1, 0, 'q'}, {"reward", 1, 0, 'r'},
@@ -322,9 +323,7 @@ int main(int argc, char** argv)
         if (std::strlen(optarg) != 0 && strcasecmp(optarg, "F") != 0) fatal("Query sequence filtering not supported.");
         break;
       case 'K': break;                                                 // subalignments: read and never used by the reference
-      case 'N':
-        if (std::atol(optarg) != 0) fatal("Database dumping (-N) is not part of swipe_amd_cli.");
-        break;
+      case 'N': dump = std::atol(optarg); break;
       case 'h': usage(argv[0]); std::exit(0);
       case 'I': show_gis = true; break;
       case 'H': show_taxid = true; break;
@@ -371,6 +370,53 @@ int main(int argc, char** argv)
   if (strands == 2 && (symtype == 1 || symtype == 3 || symtype == 4)) fatal("Illegal strand specified for protein query.");
   if (!swa_gencode_name(int(query_gencode))) fatal("Illegal query genetic code specified.");
   if (!swa_gencode_name(int(db_gencode))) fatal("Illegal database genetic code specified.");
+
+  if (dump < 0 || dump > 2) fatal("Illegal dump mode.");
+  if (dump) {
+    // -N 1 / 2: the database as FASTA (db_show_fasta, database.cc:1483-1537), host only: every definition line that
+    // passes the membership / taxid filters, gi's always shown; merged on one header line (1) or one record each (2)
+    const int ftype = db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN;
+    swa_headers* hd = nullptr;
+    check(swa_headers_open(dbname.c_str(), ftype, taxidfile.empty() ? nullptr : taxidfile.c_str(), &hd));
+    uint8_t* res = nullptr;
+    int64_t* off = nullptr;
+    int64_t n = 0;
+    check(swa_blastdb_read(dbname.c_str(), ftype, 0, -1, &res, &off, &n, nullptr, nullptr, nullptr));
+    const char* sym = db_nt ? "-ACMGRSVTWYHKDBN################" : "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ####";   // query.cc:177-178
+    auto print_seq = [&](int64_t s) {                                 // db_print_seq_map, database.cc:146-162
+      const int64_t len = off[s + 1] - off[s];
+      for (int64_t i = 0; i < len; i += 80) {
+        for (int64_t k = i; k < std::min(len, i + 80); ++k) std::fputc(sym[res[off[s] + k] & 31], out);
+        std::fputc('\n', out);
+      }
+    };
+    std::vector<char> buf(1 << 16);
+    for (int64_t s = 0; s < n; ++s) {
+      int64_t need = 0;
+      int rc = swa_headers_get(hd, s, SWA_HEADERS_SHOW_GIS | (show_taxid ? SWA_HEADERS_SHOW_TAXID : 0), buf.data(), int64_t(buf.size()), &need);
+      if (rc == SWA_ERANGE) { buf.resize(size_t(need)); rc = swa_headers_get(hd, s, SWA_HEADERS_SHOW_GIS | (show_taxid ? SWA_HEADERS_SHOW_TAXID : 0), buf.data(), int64_t(buf.size()), &need); }
+      check(rc);
+      const std::string all(buf.data());
+      if (all.empty()) continue;
+      size_t from = 0;
+      bool first = true;
+      while (from <= all.size()) {
+        size_t nl = all.find('\n', from);
+        if (nl == std::string::npos) nl = all.size();
+        const std::string d = all.substr(from, nl - from);
+        from = nl + 1;
+        if (dump == 2) { std::fprintf(out, ">%s\n", d.c_str()); print_seq(s); }
+        else { std::fprintf(out, first ? ">%s" : " >%s", d.c_str()); first = false; }
+        if (nl == all.size()) break;
+      }
+      if (dump == 1) { std::fputc('\n', out); print_seq(s); }
+    }
+    swa_free(res);
+    swa_free(off);
+    swa_headers_close(hd);
+    if (out != stdout) std::fclose(out);
+    return 0;
+  }
 
   int64_t M[1024];
   if (symtype == 0) check(swa_matrix_nucleotide(match, mismatch, M));

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tests/golden/headers.json: the reference CLI (oracle/_ref/swipe) on the `headers` case of tests/cases.py -
 a protein volume whose definition lines use every Seq-id flavour, behind (a) nothing, (b) an OID-mask alias,
-(c) a taxid list, (d) both; with and without -I (show gi's) and -H (show taxid etc.).  Build container only."""
+(c) a taxid list, (d) both; with and without -I (show gi's) and -H (show taxid etc.); with --dump,
+tests/golden/dump.json: the -N 1 / -N 2 FASTA dumps.  Build container only."""
 import json, os, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -57,5 +58,25 @@ def main():
         json.dump(out, f, separators=(",", ":"))
 
 
+
+
+def dump_golden():
+    """-N 1 / -N 2 (database dump as FASTA) of the same volume, plain / masked / with the taxid list, and of the
+    nucleotide fixture (ambiguity codes)"""
+    case = cases.get("headers")
+    d = tempfile.mkdtemp(prefix="golden_dump_")
+    vol, masked, tx, qf = build(case, d)
+    out = {}
+    for name, db, extra in (("plain", vol, []), ("masked", masked, []), ("taxlist_taxid", vol, ["-x", tx, "-H"])):
+        for n in ("1", "2"):
+            out[name + "_N" + n] = subprocess.run([REF, "-d", db, "-N", n] + extra, capture_output=True, text=True, check=True).stdout
+    nt = cases.get("nt")
+    base = os.path.join(d, "nt")
+    blastdb.write_db(base, nt.seqs[295:], protein=False)
+    out["nt_N1"] = subprocess.run([REF, "-d", base, "-p", "0", "-N", "1"], capture_output=True, text=True, check=True).stdout
+    json.dump(out, open(os.path.join(HERE, "dump.json"), "w"), separators=(",", ":"))
+    print("dump golden:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    dump_golden() if "--dump" in sys.argv else main()

@@ -333,3 +333,25 @@ def test_makedb_fasta_to_v4_volumes(tmp_path):
     assert os.path.exists(tmp_path / "many.pal")
     h = swipe_amd.Headers(str(tmp_path / "many"))
     assert h.get(5) == ["lcl|id5 some title 5"] and h.get(len(case.seqs) - 1) == ["lcl|id%d some title %d" % (len(case.seqs) - 1, len(case.seqs) - 1)]
+
+
+def test_cli_database_dump_equals_reference(tmp_path):
+    """-N 1 / -N 2 (db_show_fasta): host-only path of the CLI, byte for byte against the reference's dumps - merged
+    definition lines, membership / taxid filtering of records, 80-column sequence lines, nucleotide ambiguity codes"""
+    import subprocess
+    from conftest import load_golden
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    g = load_golden("dump")
+    case, vol, masked, tx = build_headers_db(tmp_path)
+    for name, db, extra in (("plain", vol, []), ("masked", masked, []), ("taxlist_taxid", vol, ["-x", tx, "-H"])):
+        for n in ("1", "2"):
+            r = subprocess.run([exe, "-d", db, "-N", n] + extra, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert r.stdout == g[name + "_N" + n], (name, n)
+    nt = cases.get("nt")
+    base = str(tmp_path / "nt")
+    blastdb.write_db(base, nt.seqs[295:], protein=False)
+    r = subprocess.run([exe, "-d", base, "-p", "0", "-N", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == g["nt_N1"]
