@@ -1060,19 +1060,37 @@ bool cand_before(const Cand& a, const Cand& b)
 
 int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
 {
-  std::vector<int32_t> s32(size_t(db->nseq));
-  HIP_TRY(hipMemcpy(s32.data(), dev, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  std::vector<long long> s64;
-  for (int64_t i = 0; i < db->nseq; ++i) {
-    if (s32[size_t(i)] == SWA_SCORE_IN_64) {
-      if (s64.empty()) {
-        s64.resize(size_t(db->nseq));
-        HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      }
-      out[i] = s64[size_t(i)];
-    } else {
-      out[i] = s32[size_t(i)];
+  // the int32 scores land in the upper half of the caller's int64 buffer and are widened in place, front to back
+  // (entry i is read from byte 4n + 4i and written to byte 8i <= 4n + 4i), by a few threads on disjoint ranges
+  const int64_t n = db->nseq;
+  int32_t* staged = reinterpret_cast<int32_t*>(out) + n;
+  HIP_TRY(hipMemcpy(staged, dev, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, n >> 18}));
+  std::vector<uint8_t> wide(size_t(nthreads), 0);
+  auto widen = [&](int64_t t) {
+    const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+    bool any = false;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int32_t v = staged[i];
+      any |= v == SWA_SCORE_IN_64;
+      out[i] = v;
     }
+    wide[size_t(t)] = any;
+  };
+  if (nthreads == 1) {
+    widen(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(widen, t);
+    for (std::thread& t : pool) t.join();
+  }
+  bool any = false;
+  for (uint8_t w : wide) any |= w != 0;
+  if (any) {                                               // scores beyond 32 bits live in scores64
+    std::vector<long long> s64((size_t(n)));
+    HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i)
+      if (out[i] == SWA_SCORE_IN_64) out[i] = s64[size_t(i)];
   }
   return SWA_OK;
 }
