@@ -115,6 +115,7 @@ struct swa_db {
   // sequences left out by an OID mask / taxid list (swa_db_set_inclusion): not in any batch, score -1
   DevBuf<int32_t> excluded;
   int64_t n_excluded = 0, active_sym = 0;
+  std::vector<int32_t> h_stage;            // host staging for score downloads
   std::vector<int64_t> h_ntlen;
   int64_t nt_sym = 0, nt_longest = 0;
   std::vector<int64_t> h_offsets;
@@ -1030,20 +1031,34 @@ int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t
       cand.push_back({db->first_seqno + idx[size_t(i)] / db->frames, sc[size_t(i)], which, idx[size_t(i)] % db->frames});
     return SWA_OK;
   }
-  // more candidates than the compaction buffer: take every score to the host instead
+  // more candidates than the compaction buffer (a very permissive threshold): take every score to the host, find
+  // the score of the keep-th best accepted entry from a histogram and keep only what can still make the list
   std::vector<int32_t> s32(size_t(db->nseq));
   HIP_TRY(hipMemcpy(s32.data(), scores, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
   std::vector<long long> s64;
-  for (int64_t i = 0; i < db->nseq; ++i) {
-    int64_t v = s32[size_t(i)];
-    if (v == SWA_SCORE_IN_64) {
-      if (s64.empty()) {
-        s64.resize(size_t(db->nseq));
-        HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      }
-      v = s64[size_t(i)];
+  auto value = [&](int64_t i) -> int64_t {
+    const int64_t v = s32[size_t(i)];
+    return v == SWA_SCORE_IN_64 ? int64_t(s64[size_t(i)]) : v;
+  };
+  for (int64_t i = 0; i < db->nseq && s64.empty(); ++i)
+    if (s32[size_t(i)] == SWA_SCORE_IN_64) {
+      s64.resize(size_t(db->nseq));
+      HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
     }
-    if (v >= minscore && v <= maxscore) cand.push_back({db->first_seqno + i / db->frames, v, which, int32_t(i % db->frames)});
+  constexpr int64_t BINS = 1 << 16;
+  std::vector<int64_t> hist(size_t(BINS), 0);
+  for (int64_t i = 0; i < db->nseq; ++i) {
+    const int64_t v = value(i);
+    if (v >= minscore && v <= maxscore) ++hist[size_t(std::min<int64_t>(std::max<int64_t>(v, 0), BINS - 1))];
+  }
+  int64_t floor_score = minscore, seen = 0;
+  for (int64_t b = BINS - 1; b >= 0; --b) {
+    seen += hist[size_t(b)];
+    if (seen >= keep) { floor_score = std::max(minscore, b == BINS - 1 ? minscore : b); break; }
+  }
+  for (int64_t i = 0; i < db->nseq; ++i) {
+    const int64_t v = value(i);
+    if (v >= floor_score && v <= maxscore) cand.push_back({db->first_seqno + i / db->frames, v, which, int32_t(i % db->frames)});
   }
   return SWA_OK;
 }
@@ -1060,10 +1075,11 @@ bool cand_before(const Cand& a, const Cand& b)
 
 int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
 {
-  // the int32 scores land in the upper half of the caller's int64 buffer and are widened in place, front to back
-  // (entry i is read from byte 4n + 4i and written to byte 8i <= 4n + 4i), by a few threads on disjoint ranges
+  // the int32 scores land in a host buffer the handle keeps and are widened into the caller's int64 array by a few
+  // threads on disjoint ranges
   const int64_t n = db->nseq;
-  int32_t* staged = reinterpret_cast<int32_t*>(out) + n;
+  if (db->h_stage.size() < size_t(n)) db->h_stage.resize(size_t(n));
+  int32_t* staged = db->h_stage.data();
   HIP_TRY(hipMemcpy(staged, dev, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost));
   const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, n >> 18}));
   std::vector<uint8_t> wide(size_t(nthreads), 0);

@@ -278,6 +278,25 @@ def test_properties_at_scale():
     db.close()
 
 
+def test_permissive_threshold_takes_the_histogram_path():
+    """minscore 1 on 1.3 M short sequences: more candidates than the device compaction buffer holds, so the top-K floor
+    comes from the host-side histogram; list, totalhits and the obvious count must still be exact"""
+    q = cases.Q375[:60]
+    n = 1_300_000
+    rtab = synth.residue_table_protein()
+    res = synth._random_residues(4, 1, 12 * n, rtab)
+    off = np.arange(n + 1, dtype=np.int64) * 12
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    s, _ = db.search(q)
+    for keep, lo, hi in ((100, 1, 1 << 40), (2000, 1, 28), (50, 0, 1 << 40)):
+        hits, tot, obv, _ = db.search_topk(q, keep=keep, minscore=lo, maxscore=hi)
+        order = sorted(((int(v), i) for i, v in enumerate(s) if lo <= v <= hi), key=lambda t: (-t[0], -t[1]))
+        assert hits == [(i, v) for v, i in order[:keep]]
+        assert tot == int((s >= lo).sum()) and obv == int((s > hi).sum())
+    db.close()
+
+
 @pytest.mark.parametrize("qlen", [1, 100, 128, 129, 300, 384, 385, 512, 513, 1000, 1024, 1025, 3000])
 def test_dual_query_kernel_both_strands(qlen):
     """search2: plus strand and reverse complement in the two halves of one pass (single and multi pass)"""
