@@ -15,9 +15,18 @@
      search7 + search16 + fullsw under search_chunk
                         (swipe.h:200-258, swipe.cc:1416-1592)  swa_search
      hits_enter loop + top-K list (hits.cc:163-222)     swa_search_topk / swa_hits_*
-     search16s end points (swipe.h:237-249)             swa_search_endpoints
+     search16s end points (swipe.h:237-249)             swa_search_endpoints[_strand]
      hits_init thresholds, E-values (hits.cc:283-511,
                         1777-1779; stats.cc)            swa_stats_init / swa_evalue / swa_bits
+     the qstrand/qframe x dstrand/dframe loops of search_chunk
+                        (swipe.cc:277-337, 1379-1404)   swa_search_frames_topk / swa_fhits_merge
+     translate, db_translate (query.cc:377-506,
+                        database.cc:1182-1218)          swa_translate[_table] / swa_db_open_translated
+     align_chunk + hits_align + align (swipe.cc:339-414,
+                        hits.cc:546-618, align.cc)      swa_align_hits / swa_traceback / swa_db_sequence
+     db_check_inclusion, db_showheader, alias masks
+                        (database.cc:670-772, 1424-1481,
+                        asnparse.cc)                    swa_headers_* / swa_db_set_inclusion
 
    Conventions: plain pointers and sizes, caller owns every buffer, the callee keeps no host
    pointer past return.  Every function returns SWA_OK (0) or a negative SWA_E* code; the
