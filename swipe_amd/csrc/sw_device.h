@@ -41,6 +41,11 @@ struct swa_narrow_params {
   float gapextend_f;           /* R, added to every profile entry */
   uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
   uint32_t rowc[68];           /* packed f16 pairs r*R for r = 0..K+1 */
+  /* one pass of a long query (MP build of swa_narrow_split_kernel) */
+  void* boundary;              /* (H, F) f16 pairs of the pass's last row: 8 bytes per stream element, stream layout */
+  long long boundary_base;     /* stream chunk (swa_batch.offset units) that boundary[0] belongs to */
+  int32_t row0;                /* first query row of the pass */
+  int32_t pass, last;          /* pass index; 1 when no pass follows */
 };
 
 /* generic multi-pass kernel (sw_mp_kernel.inc) */

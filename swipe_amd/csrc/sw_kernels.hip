@@ -271,7 +271,7 @@ swa_narrow_kernel(swa_narrow_params p)
 //     l & (G-1) of each pair, so the pairs of a row read disjoint bank groups - conflict-free as before;
 //   * the residue register of a lane is refilled every G steps from the 16-column chunks of ITS batch.
 template <int K, int G>
-__device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, const swa_query* q, float add)
+__device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, const swa_query* q, float add, int row0 = 0)
 {
   constexpr int C = (K + 7) / 8;
   unsigned short* t = (unsigned short*)lds;
@@ -279,22 +279,29 @@ __device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, cons
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int k = e & 7, l = (e >> 3) & (G - 1), c = (e >> 7) % C, d = (e >> 7) / C;
     const int local = c * 8 + k;
-    const int row = l * K + local;
+    const int row = row0 + l * K + local;
     float v = -1.0f;
     if (local < K && row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
     t[e] = (unsigned short)float_to_half_bits(v + add);
   }
 }
 
-template <int K, int W, int G, int PIPE, bool DEFER>
+//
+// MP (16-lane chains only): one PASS of a query longer than 928 rows.  The launch covers rows
+// [p.row0, p.row0 + 16 K) of the query; lane 15 of every DPP row leaves (H, F) of its last row for every column
+// in p.boundary - 8 bytes per element of the residue stream, same [chunk][row][lane] layout - and lane 0 of the
+// next pass (the next launch) takes them where a single pass sees the zero edge.  The hand-over is written
+// behind the position it is read at, so one buffer serves both directions; scores are the maximum over the passes.
+template <int K, int W, int G, int PIPE, bool DEFER, bool MP = false>
 __global__ void __launch_bounds__(256, W)
 swa_narrow_split_kernel(swa_narrow_params p)
 {
+  static_assert(!MP || (G == 16 && PIPE != 2), "multi-pass build: 16-lane chains, step-local pipelining");
   constexpr int C = (K + 7) / 8;
   constexpr u32 CS = C * 256;
   constexpr int NB = 16 / G;                              // batches per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  build_profile_f16_split<K, G>(lds, p.query, p.gapextend_f);
+  build_profile_f16_split<K, G>(lds, p.query, p.gapextend_f, MP ? p.row0 : 0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -304,8 +311,8 @@ swa_narrow_split_kernel(swa_narrow_params p)
   const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR);
   const h2 zero = {0, 0};
   const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-  const h2 send_mul = lg == G - 1 ? zero : one;           // the last lane of a pair hands nothing on
-  const h2 send_add = lg == G - 1 ? zero : as_h2(p.negKR);
+  const h2 send_mul = (lg == G - 1 && !MP) ? zero : one;  // the last lane of a pair hands nothing on (MP: to the next pass)
+  const h2 send_add = (lg == G - 1 && !MP) ? zero : as_h2(p.negKR);
   const u32 PADOFF = (SWA_PAD * CS) | ((SWA_PAD * CS) << 16);
   const u32 PADRAW = SWA_PAD | (SWA_PAD << 8);
 
@@ -334,6 +341,14 @@ swa_narrow_split_kernel(swa_narrow_params p)
     h2 diag = zero, hsend = zero, fsend = zero;
     u32 cur = PADOFF;
     u32 raw = mychunks > 0 ? (u32)s[0] : PADRAW;
+    // MP: hand-over of the previous pass for the 16 columns of a chunk (lane = column), and the one being collected
+    uint2* bq = nullptr;
+    uint2 bnext = {0u, 0u};
+    h2 bh = zero, bf = zero, acc_h = zero, acc_f = zero;
+    if constexpr (MP) {
+      bq = (uint2*)p.boundary + ((int64_t)bd.offset - p.boundary_base) * 64 + (lane & 48);
+      if (p.pass > 0 && (lane & 15) < bd.steps) bnext = bq[lane & 15];
+    }
 
 #define SWA_CELL(r, k, wa, wb, ODD)                                                            \
           {                                                                                    \
@@ -361,8 +376,16 @@ swa_narrow_split_kernel(swa_narrow_params p)
       const u32 shifted = row_shr1(cur, pl);                                                   \
       cur = inner_first ? pl : shifted;                                                        \
       pl = pl2;                                                                                \
-      const h2 hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
-      h2 F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+      h2 hup, F;                                                                               \
+      if constexpr (MP) {       /* lane 0 keeps the hand-over of its column, which then moves on one lane */ \
+        hup = as_h2((u32)__builtin_amdgcn_update_dpp((int)as_u32(bh), (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, false)); \
+        F = as_h2((u32)__builtin_amdgcn_update_dpp((int)as_u32(bf), (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, false)); \
+        bh = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(bh), DPP_ROW_SHL1, 0xF, 0xF, true)); \
+        bf = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(bf), DPP_ROW_SHL1, 0xF, 0xF, true)); \
+      } else {                                                                                 \
+        hup = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(hsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+        F = as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(fsend), DPP_ROW_SHR1, 0xF, 0xF, true)); \
+      }                                                                                        \
       h2 hd = diag;                                                                            \
       h2 eprev = zero;                                                                         \
       diag = hup;                                                                              \
@@ -400,6 +423,10 @@ swa_narrow_split_kernel(swa_narrow_params p)
       }                                                                                        \
       hsend = __builtin_elementwise_fma(H[K - 1], send_mul, send_add);                         \
       fsend = __builtin_elementwise_fma(F, send_mul, send_add);                                \
+      if constexpr (MP) {       /* lane 15 files its column, the earlier ones move down one lane */ \
+        acc_h = as_h2((u32)__builtin_amdgcn_update_dpp((int)as_u32(hsend), (int)as_u32(acc_h), DPP_ROW_SHL1, 0xF, 0xF, false)); \
+        acc_f = as_h2((u32)__builtin_amdgcn_update_dpp((int)as_u32(fsend), (int)as_u32(acc_f), DPP_ROW_SHL1, 0xF, 0xF, false)); \
+      }                                                                                        \
     }
 
     if constexpr (PIPE != 2) {
@@ -408,9 +435,21 @@ swa_narrow_split_kernel(swa_narrow_params p)
         const int col = (m + 1) * G;
         raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW;
         const int n = total - m * G < G ? total - m * G : G;
+        if constexpr (MP) {
+          bh = as_h2(bnext.x);
+          bf = as_h2(bnext.y);
+          bnext = uint2{0u, 0u};
+          // columns past the longest sequence of the batch were never handed over: they see the zero edge
+          if (p.pass > 0 && 16 * (m + 1) + (lane & 15) < bd.steps) bnext = bq[(int64_t)(m + 1) * 64 + (lane & 15)];
+        }
         for (int u = 0; u < n; u += 2) {
           SWA_STEPG(0)
           SWA_STEPG(1)
+        }
+        if constexpr (MP) {
+          // after step t = 16 m + n - 1 lane l holds the column lane 15 finished 15 - l steps ago: t - 30 + l
+          const int c = 16 * m + n - 31 + (lane & 15);
+          if (!p.last && c >= 0 && c < bd.steps) bq[(int64_t)(c >> 4) * 64 + (c & 15)] = uint2{as_u32(acc_h), as_u32(acc_f)};
         }
       }
     } else {
@@ -494,6 +533,13 @@ swa_narrow_split_kernel(swa_narrow_params p)
         idB = p.slots[(int64_t)b * SWA_SLOTS + (pairno & 3) * 2 + 1];
         sA = (int)(float)S.x;
         sB = (int)(float)S.y;
+        if constexpr (MP) {     // maximum over the passes; a sequence is re-queued by the first pass that overflows
+          if (p.pass > 0) {
+            const int pA = idA >= 0 ? p.scores[idA] : 0, pB = idB >= 0 ? p.scores[idB] : 0;
+            if (pA >= p.limit) idA = -1; else sA = sA > pA ? sA : pA;
+            if (pB >= p.limit) idB = -1; else sB = sB > pB ? sB : pB;
+          }
+        }
         if (idA >= 0) p.scores[idA] = sA;
         if (idB >= 0) p.scores[idB] = sB;
       }
@@ -793,6 +839,29 @@ template <int G> static hipError_t launch_split_any(int K, const swa_narrow_para
     default: return hipErrorInvalidValue;
   }
 #undef SWA_SG_CASE
+}
+// one pass of a long query (MP build): 16-lane chains of 30..56 rows, two waves per SIMD.  All four (PIPE, DEFER) builds
+// of every K were measured on MI355X (tools/gpu_pass_sweep.py): the step-local pipelined loads with the deferred -R win
+// or tie everywhere (+1..5 % at K <= 34 and K >= 45) except K = 37 and 38, where the staged loads are 1 % ahead
+template <int K> static hipError_t launch_split_mp_any(const swa_narrow_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
+  auto kern = swa_narrow_split_kernel<K, 2, 16, (K == 37 || K == 38) ? 0 : 1, true, true>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_MPK(KK) case KK: return launch_split_mp_any<KK>(*p, blocks, st);
+  switch (K) {
+    SWA_MPK(30) SWA_MPK(31) SWA_MPK(32) SWA_MPK(33) SWA_MPK(34) SWA_MPK(35) SWA_MPK(36) SWA_MPK(37) SWA_MPK(38) SWA_MPK(39)
+    SWA_MPK(40) SWA_MPK(41) SWA_MPK(42) SWA_MPK(43) SWA_MPK(44) SWA_MPK(45) SWA_MPK(46) SWA_MPK(47) SWA_MPK(48)
+    SWA_MPK(49) SWA_MPK(50) SWA_MPK(51) SWA_MPK(52) SWA_MPK(53) SWA_MPK(54) SWA_MPK(55) SWA_MPK(56)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_MPK
 }
 extern "C" hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {

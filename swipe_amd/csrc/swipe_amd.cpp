@@ -27,6 +27,7 @@ extern "C" {
 int swa_narrow_rows_for(int qlen);
 int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
@@ -424,6 +425,91 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   return SWA_OK;
 }
 
+// Queries longer than one pass of the tuned kernel (928 rows): passes of 16 x K rows, K <= 56, made as even as the
+// query allows, each pass ONE launch of the MP build of swa_narrow_split_kernel over a run of batches.  The last
+// row of a pass is handed to the next launch through db->boundary, 8 bytes per element of the residue stream
+// (13 GB for a 10 M-sequence protein database: HBM is the one thing this box has to spare, and at 26 GB of extra
+// traffic per pass boundary it costs 3 ms of a 130 ms pass).  The buffer is capped; batches are taken in runs
+// that fit it, all passes of a run before the next run.
+void split_pass_shape(int64_t qlen, int* npass, int* K)
+{
+  const int kmax = 56;                                 // 57+ rows of a pass build spill
+  const int64_t np = (qlen + 16 * kmax - 1) / (16 * kmax);
+  *npass = int(np);
+  *K = int(std::max<int64_t>(30, (qlen + 16 * np - 1) / (16 * np)));
+}
+
+int split_pass_rows(int64_t qlen)
+{
+  int npass = 0, K = 0;
+  split_pass_shape(qlen, &npass, &K);
+  return K;
+}
+
+int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st)
+{
+  int npass = 0, K = 0;
+  split_pass_shape(qlen, &npass, &K);
+  const BatchSet& bs = db->main;
+  swa_narrow_params p{};
+  p.query = db->query.p;
+  p.stream = bs.stream.p;
+  p.counter = db->ctl.p + 0;
+  p.scores = db->scores.p;
+  p.ovf_count = db->ctl.p + 1;
+  p.ovf_list = db->ovf_list.p;
+  p.negQ = f16_pair(-float(db->goe));
+  p.negR = f16_pair(-float(db->ge));
+  p.shifted = 1;
+  p.limit = int32_t(f16_limit(db, K));
+  p.gapextend_f = float(db->ge);
+  p.negQR = f16_pair(-float(db->goe - db->ge));
+  p.negKR = f16_pair(-float(int64_t(K) * db->ge));
+  for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
+
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t avail = free_b + db->boundary.bytes();
+  size_t budget = std::min<size_t>(size_t(16) << 30, avail / 4);
+  if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
+  const size_t per_chunk = 64 * 8;
+  const int nb = bs.nbatches;
+  std::vector<int> cut{0};                             // runs of batches [cut[i], cut[i+1])
+  std::vector<int64_t> first_chunk{0};
+  size_t largest = 0, bytes = 0;
+  int64_t chunk = 0;
+  for (int b = 0; b < nb; ++b) {
+    const size_t need = size_t((bs.h_steps[size_t(b)] + 15) / 16) * per_chunk;
+    if (bytes && bytes + need > budget) {
+      cut.push_back(b);
+      first_chunk.push_back(chunk);
+      bytes = 0;
+    }
+    bytes += need;
+    chunk += (bs.h_steps[size_t(b)] + 15) / 16;
+    largest = std::max(largest, bytes);
+  }
+  cut.push_back(nb);
+  if (largest > avail)
+    return fail(SWA_ENOMEM, "a database sequence is too long for the multi-pass hand-over buffer; use a shorter query");
+  HIP_TRY(db->boundary.reserve(largest));
+  p.boundary = db->boundary.p;
+  for (size_t i = 0; i + 1 < cut.size(); ++i) {
+    p.batches = bs.batches.p + cut[i];
+    p.slots = bs.slots.p + size_t(cut[i]) * SWA_SLOTS;
+    p.nbatches = cut[i + 1] - cut[i];
+    p.boundary_base = first_chunk[i];
+    for (int pass = 0; pass < npass; ++pass) {
+      p.row0 = pass * 16 * K;
+      p.pass = pass;
+      p.last = pass + 1 == npass;
+      HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
+      HIP_TRY(swa_launch_narrow_pass(K, &p, persistent_blocks(db, p.nbatches), st));
+    }
+  }
+  return SWA_OK;
+}
+
 int read_requeue(swa_db* db, int ctl_index, const int32_t* list, std::vector<int32_t>& out, hipStream_t st)
 {
   int32_t n = 0;
@@ -585,8 +671,15 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     c.narrow_rows = K;
     HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
     c.narrow = db->nseq;
+  } else if (f16 && !force_mp && qlen > 16 * 58 && f16_limit(db, split_pass_rows(qlen)) >= 1024) {
+    rc = launch_split_passes(db, qlen, st);            // long query: passes of the tuned kernel
+    if (rc != SWA_OK) return rc;
+    const int Kp = split_pass_rows(qlen);
+    c.narrow_rows = Kp;
+    c.narrow_shifted = 5;
+    c.narrow = db->nseq;
   } else if (f16 && f16_limit(db, mp_rows_for(0, qlen)) >= 1024) {
-    MpRun r;                                           // long query: multi-pass pair kernel
+    MpRun r;                                           // multi-pass pair kernel (short passes: large gap-extension penalties)
     r.mode = 0;
     r.set = &db->main;
     r.q1 = db->qseq.p;

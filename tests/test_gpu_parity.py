@@ -384,9 +384,43 @@ def test_multipass_hand_over_buffer_is_bounded(two, monkeypatch):
     db.close()
 
 
+def test_every_pass_build_of_the_row_shifted_kernel(monkeypatch):
+    """queries longer than 928 rows run as passes of 16 x K rows, K = 30..56, one launch per pass with the last row handed
+    over through HBM: every K with two passes, then three and more passes; the planted sequences straddle the pass
+    boundaries, overflow the packed range in the first, a middle or the last pass, or stay exact across all of them.
+    SWA_BOUNDARY_MB = 1 also cuts the batches into several runs"""
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(123, 1, 5200, rtab)
+    res, off = swipe_amd.synth_db(9, 500, query=full[:1200])
+    base = [res[off[i]:off[i + 1]] for i in range(500)]
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    lens = [32 * K for K in range(30, 57)] + [32 * K - 31 for K in (30, 41, 56)] + [929, 1793, 48 * 40, 2688, 2689, 5200]
+    for n, qlen in enumerate(lens):
+        monkeypatch.setenv("SWA_BOUNDARY_MB", "1" if n % 3 == 0 else "4096")
+        q = full[:qlen]
+        npass = (qlen + 895) // 896
+        K = max(30, -(-qlen // (16 * npass)))
+        edge = 16 * K
+        planted = [q, q[edge - 120:edge + 130].copy(), q[:300].copy(), q[qlen - 320:].copy(), q[edge - 5:edge + 5].copy(),
+                   q[edge * (npass - 1) - 200:edge * (npass - 1) + 60].copy(), np.concatenate([base[0], q[edge - 60:edge + 40], base[1]]),
+                   q[100:qlen - 100:2].copy(), np.zeros(0, np.uint8)]
+        r2, o2 = oracle.pack(base + planted)
+        db = swipe_amd.Database.from_arrays(r2, o2)
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        scores, c = db.search(q)
+        want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
+        assert c["narrow_shifted"] == 5 and c["narrow_rows"] == K, (qlen, c)
+        assert np.array_equal(scores, want), (qlen, np.nonzero(scores != want)[0][:10])
+        assert c["wide"] >= 1
+        db.close()
+
+
 @pytest.mark.parametrize("K", ["16", "24", "32"])
 def test_multipass_pair_kernel_rows_per_lane(monkeypatch, K):
-    """every rows-per-lane build of the multi-pass pair kernel (SWA_MP_K override) on a long protein query"""
+    """every rows-per-lane build of the multi-pass pair kernel (SWA_MP_K override) on a long protein query; since the
+    tuned kernel runs long queries in passes of its own this one only serves gap-extension penalties too large for 30+
+    rows per lane, so it is forced here"""
+    monkeypatch.setenv("SWA_FORCE_MP", "1")
     monkeypatch.setenv("SWA_MP_K", K)
     rtab = synth.residue_table_protein()
     q = synth._random_residues(77, 1, 1300, rtab)
