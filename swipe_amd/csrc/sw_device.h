@@ -70,6 +70,9 @@ struct swa_mp_params {
   int32_t* ovf_list2;
   void* boundary;              /* per wave: boundary_cols x 4 rows x (H, F) */
   int32_t boundary_cols;
+  /* pass builds of swa_dual_kernel: boundary holds 8 bytes per stream element, as in swa_narrow_params */
+  long long boundary_base;
+  int32_t row0, pass, last;
   long long gapopenextend, gapextend;
   float gapextend_f;
   uint32_t negQR, negR, negKR;

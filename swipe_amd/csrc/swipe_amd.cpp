@@ -28,6 +28,7 @@ int swa_narrow_rows_for(int qlen);
 int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
@@ -425,6 +426,40 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   return SWA_OK;
 }
 
+// Runs of batches whose pass hand-over (8 bytes per stream element) fits the buffer budget; reserves db->boundary.
+struct PassRuns {
+  std::vector<int> cut{0};                             // run i = batches [cut[i], cut[i+1])
+  std::vector<int64_t> first_chunk{0};                 // stream chunk run i starts at
+};
+int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
+{
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t avail = free_b + db->boundary.bytes();
+  size_t budget = std::min<size_t>(size_t(16) << 30, avail / 4);
+  if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
+  const size_t per_chunk = 64 * 8;
+  const int nb = bs.nbatches;
+  size_t largest = 0, bytes = 0;
+  int64_t chunk = 0;
+  for (int b = 0; b < nb; ++b) {
+    const size_t need = size_t((bs.h_steps[size_t(b)] + 15) / 16) * per_chunk;
+    if (bytes && bytes + need > budget) {
+      runs.cut.push_back(b);
+      runs.first_chunk.push_back(chunk);
+      bytes = 0;
+    }
+    bytes += need;
+    chunk += (bs.h_steps[size_t(b)] + 15) / 16;
+    largest = std::max(largest, bytes);
+  }
+  runs.cut.push_back(nb);
+  if (largest > avail)
+    return fail(SWA_ENOMEM, "a database sequence is too long for the multi-pass hand-over buffer; use a shorter query");
+  HIP_TRY(db->boundary.reserve(largest));
+  return SWA_OK;
+}
+
 // Queries longer than one pass of the tuned kernel (928 rows): passes of 16 x K rows, K <= 56, made as even as the
 // query allows, each pass ONE launch of the MP build of swa_narrow_split_kernel over a run of batches.  The last
 // row of a pass is handed to the next launch through db->boundary, 8 bytes per element of the residue stream
@@ -467,32 +502,11 @@ int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st)
   p.negKR = f16_pair(-float(int64_t(K) * db->ge));
   for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
 
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  const size_t avail = free_b + db->boundary.bytes();
-  size_t budget = std::min<size_t>(size_t(16) << 30, avail / 4);
-  if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
-  const size_t per_chunk = 64 * 8;
-  const int nb = bs.nbatches;
-  std::vector<int> cut{0};                             // runs of batches [cut[i], cut[i+1])
-  std::vector<int64_t> first_chunk{0};
-  size_t largest = 0, bytes = 0;
-  int64_t chunk = 0;
-  for (int b = 0; b < nb; ++b) {
-    const size_t need = size_t((bs.h_steps[size_t(b)] + 15) / 16) * per_chunk;
-    if (bytes && bytes + need > budget) {
-      cut.push_back(b);
-      first_chunk.push_back(chunk);
-      bytes = 0;
-    }
-    bytes += need;
-    chunk += (bs.h_steps[size_t(b)] + 15) / 16;
-    largest = std::max(largest, bytes);
-  }
-  cut.push_back(nb);
-  if (largest > avail)
-    return fail(SWA_ENOMEM, "a database sequence is too long for the multi-pass hand-over buffer; use a shorter query");
-  HIP_TRY(db->boundary.reserve(largest));
+  PassRuns runs;
+  const int prc = plan_pass_runs(db, bs, runs);
+  if (prc != SWA_OK) return prc;
+  const std::vector<int>& cut = runs.cut;
+  const std::vector<int64_t>& first_chunk = runs.first_chunk;
   p.boundary = db->boundary.p;
   for (size_t i = 0; i + 1 < cut.size(); ++i) {
     p.batches = bs.batches.p + cut[i];
@@ -505,6 +519,68 @@ int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st)
       p.last = pass + 1 == npass;
       HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
       HIP_TRY(swa_launch_narrow_pass(K, &p, persistent_blocks(db, p.nbatches), st));
+    }
+  }
+  return SWA_OK;
+}
+
+// The same for two queries (swa_dual_kernel's MP build over the one-sequence-per-row stream): passes of at most 56 rows
+// per lane for nucleotide alphabets (1 KB of LDS per residue code and 4 rows), 32 for the others.
+void dual_pass_shape(int64_t qlen, int nres, int* npass, int* K)
+{
+  const int kmax = nres == 16 ? 56 : 32;
+  const int64_t np = (qlen + 16 * kmax - 1) / (16 * kmax);
+  *npass = int(np);
+  *K = int(std::max<int64_t>(nres == 16 ? 32 : 17, (qlen + 16 * np - 1) / (16 * np)));
+}
+int dual_pass_rows(int64_t qlen, int nres)
+{
+  int npass = 0, K = 0;
+  dual_pass_shape(qlen, nres, &npass, &K);
+  return K;
+}
+
+int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
+{
+  int npass = 0, K = 0;
+  dual_pass_shape(qlen, nres, &npass, &K);
+  const BatchSet& bs = db->single;
+  swa_mp_params p{};
+  p.qseq = db->qseq.p;
+  p.qseq2 = db->qseq2.p;
+  p.matrix = db->matrix.p;
+  p.qlen = int32_t(qlen);
+  p.rows_per_lane = K;
+  p.npass = npass;
+  p.stream = bs.stream.p;
+  p.counter = db->ctl.p + 0;
+  p.scores = db->scores.p;
+  p.scores2 = db->scores2.p;
+  p.limit = f16_limit(db, K);
+  p.ovf_count = db->ctl.p + 1;
+  p.ovf_list = db->ovf_list.p;
+  p.ovf_count2 = db->ctl.p + 3;
+  p.ovf_list2 = db->ovf_list2.p;
+  p.gapextend_f = float(db->ge);
+  p.negQR = f16_pair(-float(db->goe - db->ge));
+  p.negR = f16_pair(-float(db->ge));
+  p.negKR = f16_pair(-float(int64_t(K) * db->ge));
+  for (int i = 0; i <= K + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
+  PassRuns runs;
+  const int prc = plan_pass_runs(db, bs, runs);
+  if (prc != SWA_OK) return prc;
+  p.boundary = db->boundary.p;
+  for (size_t i = 0; i + 1 < runs.cut.size(); ++i) {
+    p.batches = bs.batches.p + runs.cut[i];
+    p.slots = bs.slots.p + size_t(runs.cut[i]) * SWA_SLOTS;
+    p.nbatches = runs.cut[i + 1] - runs.cut[i];
+    p.boundary_base = runs.first_chunk[i];
+    for (int pass = 0; pass < npass; ++pass) {
+      p.row0 = pass * 16 * K;
+      p.pass = pass;
+      p.last = pass + 1 == npass;
+      HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
+      HIP_TRY(swa_launch_dual_pass(K, nres, &p, db->cus, st));
     }
   }
   return SWA_OK;
@@ -775,6 +851,16 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
     c.narrow_rows = Kd;
     c.narrow_shifted = 4;                                // single-pass dual kernel
+    c.narrow = db->nseq;
+    HIP_TRY(hipEventRecord(db->ev[2], st));
+    rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
+    if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
+    if (rc != SWA_OK) return rc;
+  } else if (f16_applicable(db) && !dual_mp && Gd == 16 && f16_limit(db, dual_pass_rows(qlen, nres)) >= 1024) {
+    rc = launch_dual_passes(db, qlen, nres, st);         // long queries: one launch per pass of the same kernel
+    if (rc != SWA_OK) return rc;
+    c.narrow_rows = dual_pass_rows(qlen, nres);
+    c.narrow_shifted = 6;
     c.narrow = db->nseq;
     HIP_TRY(hipEventRecord(db->ev[2], st));
     rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);

@@ -435,6 +435,45 @@ def test_multipass_pair_kernel_rows_per_lane(monkeypatch, K):
     db.close()
 
 
+@pytest.mark.parametrize("protein", [False, True])
+def test_every_pass_build_of_the_dual_kernel(protein, monkeypatch):
+    """two queries longer than one pass of the dual kernel (1008 rows for nucleotides, 512 otherwise): passes of 16 x K rows,
+    K = 32..56 (nucleotide) / 17..32, one launch per pass; every K with two passes, then more passes; sequences that straddle
+    the pass boundaries and ones that overflow in one query only; SWA_BOUNDARY_MB = 1 cuts the batches into several runs"""
+    tab = synth.residue_table_protein() if protein else synth.residue_table_nucleotide()
+    full = synth._random_residues(321, 1, 4200, tab)
+    res, off = swipe_amd.synth_db(19, 300, protein=protein)
+    base = [res[off[i]:off[i + 1]] for i in range(300)]
+    if protein:
+        Mo, goe, ge, kmax, kmin = oracle.matrix_builtin("BLOSUM62"), 12, 1, 32, 17
+    else:
+        Mo, goe, ge, kmax, kmin = oracle.matrix_nucleotide(1, -3), 7, 2, 56, 32
+    lens = [32 * K for K in range(kmin, kmax + 1)] + [32 * kmax + 1, 48 * (kmax - 3), 64 * kmax + 7, 4200]
+    for n, qlen in enumerate(lens):
+        monkeypatch.setenv("SWA_BOUNDARY_MB", "1" if n % 3 == 0 else "4096")
+        q1 = full[:qlen]
+        q2 = q1[::-1].copy() if protein else blastdb.revcomp_nt16(q1)
+        npass = -(-qlen // (16 * kmax))
+        K = max(kmin, -(-qlen // (16 * npass)))
+        edge = 16 * K
+        planted = [q1, q1[edge - 150:edge + 150].copy(), q2[edge - 150:edge + 150].copy(), q1[:400].copy(), q2[qlen - 400:].copy(),
+                   q1[edge * (npass - 1) - 90:edge * (npass - 1) + 90].copy(), np.concatenate([base[0], q2[edge - 70:edge + 50], base[1]]),
+                   q1[50:qlen - 50:2].copy(), np.zeros(0, np.uint8)]
+        r2, o2 = oracle.pack(base + planted)
+        db = swipe_amd.Database.from_arrays(r2, o2, symtype=1 if protein else 0)
+        if protein:
+            db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        else:
+            db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+        s1, s2, c = db.search2(q1, q2)
+        assert c["narrow_shifted"] == 6 and c["narrow_rows"] == K, (qlen, c)
+        w1 = oracle.search_all63(r2, o2, q1, Mo, goe, ge, threads=THREADS)
+        w2 = oracle.search_all63(r2, o2, q2, Mo, goe, ge, threads=THREADS)
+        assert np.array_equal(s1, w1), (qlen, np.nonzero(s1 != w1)[0][:10])
+        assert np.array_equal(s2, w2), (qlen, np.nonzero(s2 != w2)[0][:10])
+        db.close()
+
+
 def test_dual_query_protein_and_custom_matrix():
     """the dual kernel is not nucleotide specific: two protein queries of equal length"""
     q1 = cases.Q375

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import swipe_amd
 from swipe_amd import synth, blastdb
 rtab = synth.residue_table_nucleotide()
-full = synth._random_residues(99, 1, 1100, rtab)
+full = synth._random_residues(99, 1, 6000, rtab)
 res, off = swipe_amd.synth_db(3, 2_000_000, protein=False)
 db = swipe_amd.Database.from_arrays(res, off, symtype=0)
 db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
