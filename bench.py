@@ -110,7 +110,8 @@ def nucleotide_main(a, rank, local, world):
                       "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True,
                       "dtype": "f16x2 (plus strand | minus strand)", "data": "synthetic",
                       "config": {"workload": f"1000-nt query, both strands, vs {a.nseq} nt sequences ({int(off[-1])} bases), "
-                                             "+1/-3, gap 5+2", "kernel": ("swa_dual_kernel<%d, W, 16, G>" if c["narrow_shifted"] == 4 else "swa_mp_kernel<pol_f16_dual, %d>") % c["narrow_rows"]},
+                                             "+1/-3, gap 5+2", "kernel": {4: "swa_dual_kernel<%d, W, 16, G>", 6: "swa_dual_kernel<%d, W, 16, 16, MP>, one launch per pass of 16 x %d rows"}.get(
+                                     c["narrow_shifted"], "swa_mp_kernel<pol_f16_dual, %d>").replace("%d", str(c["narrow_rows"]))},
                       "kernel_ms": round(float(np.mean(kms)), 3), "totalhits": int(tot)}), flush=True)
     db.close()
 

@@ -531,7 +531,7 @@ void dual_pass_shape(int64_t qlen, int nres, int* npass, int* K)
   const int kmax = nres == 16 ? 56 : 32;
   const int64_t np = (qlen + 16 * kmax - 1) / (16 * kmax);
   *npass = int(np);
-  *K = int(std::max<int64_t>(nres == 16 ? 32 : 17, (qlen + 16 * np - 1) / (16 * np)));
+  *K = int(std::max<int64_t>(nres == 16 ? 31 : 17, (qlen + 16 * np - 1) / (16 * np)));
 }
 int dual_pass_rows(int64_t qlen, int nres)
 {
@@ -814,14 +814,15 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (rc != SWA_OK) return rc;
   std::vector<int32_t> rq1, rq2;
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  // single pass with the whole query in registers when it fits (nucleotide alphabets: 1024 rows, others 512);
+  // single pass with the whole query in registers when it fits (nucleotide alphabets: 976 rows, others 512);
   // SWA_DUAL_MP=1 forces the multi-pass kernel (A/B, tests)
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
   const bool dual_mp = std::getenv("SWA_DUAL_MP") && std::atoi(std::getenv("SWA_DUAL_MP")) == 1;
   // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
   int Gd = qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
   if (const char* e = std::getenv("SWA_LANES")) Gd = std::min(16, std::max(Gd, std::atoi(e)));
-  const int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
+  int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
+  if (const char* e = std::getenv("SWA_DUAL_KMAX")) if (Kd > std::atoi(e)) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     const BatchSet& set = Gd == 16 ? db->single : db->main;
     swa_mp_params p{};
