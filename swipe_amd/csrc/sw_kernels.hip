@@ -522,7 +522,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
     // max over the G lanes of a pair: shifts of 1, 2 (, 4) reach back exactly G - 1 lanes, so the last lane of
     // every pair ends up with the maximum of its own pair only
     S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(1), 0xF, 0xF, true)));
-    S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
+    if (G >= 4) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(2), 0xF, 0xF, true)));
     if (G >= 8) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(4), 0xF, 0xF, true)));
     if (G == 16) S = pk_max(S, as_h2((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(S), DPP_ROW_SHR(8), 0xF, 0xF, true)));
     {
@@ -865,7 +865,7 @@ extern "C" hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, 
 }
 extern "C" hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st)
 {
-  return G == 4 ? launch_split_any<4>(K, p, blocks, st) : G == 8 ? launch_split_any<8>(K, p, blocks, st)
+  return G == 2 ? launch_split_any<2>(K, p, blocks, st) : G == 4 ? launch_split_any<4>(K, p, blocks, st) : G == 8 ? launch_split_any<8>(K, p, blocks, st)
          : G == 16 ? launch_split_any<16>(K, p, blocks, st) : hipErrorInvalidValue;
 }
 extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st)

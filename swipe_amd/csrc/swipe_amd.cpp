@@ -695,10 +695,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
   const bool single_pass = qlen <= 16 * 58 && K > 0 && !force_mp;
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  // G = 4 (up to 192 rows), 8 (up to 384) or 16 (up to 768) lanes per sequence pair, K = ceil(qlen / G) rows per
-  // lane (SWA_LANES = 8 / 16 forces a longer chain: A/B runs and tests)
-  int G = qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
-  if (const char* e = std::getenv("SWA_LANES")) G = std::min(16, std::max(G, std::atoi(e)));
+  // G = 2 (up to 40 rows), 4 (up to 192), 8 (up to 384) or 16 (up to 928) lanes per sequence pair, K = ceil(qlen / G)
+  // rows per lane (SWA_LANES = 2 / 4 / 8 / 16 picks the chain length if the query fits it: A/B runs and tests)
+  // (2 lanes: measured ahead of 4 up to 40 rows - 10 aa 4.5 -> 5.7, 30 aa 7.3 -> 7.9 TCUPS - and level or behind beyond)
+  int G = qlen <= 40 ? 2 : qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
+  if (const char* e = std::getenv("SWA_LANES")) {
+    G = std::atoi(e) >= 16 ? 16 : std::atoi(e) >= 8 ? 8 : std::atoi(e) >= 4 ? 4 : 2;
+    while (G < 16 && qlen > G * 48) G *= 2;
+  }
   const int Kg = swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
   if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->narrow_variant != 1) {
     const int K = Kg;
@@ -721,7 +725,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.negKR = f16_pair(-float(int64_t(K) * db->ge));
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
-    c.narrow_shifted = G == 8 ? 2 : G == 4 ? 3 : 1;
+    c.narrow_shifted = G == 8 ? 2 : G == 4 ? 3 : G == 2 ? 7 : 1;
     const int per_wave = 16 / G;                                    // a wave takes 16 / G batches at a time
     const int items = (p.nbatches + per_wave - 1) / per_wave;
     int blocks = persistent_blocks(db, items);
@@ -819,8 +823,11 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
   const bool dual_mp = std::getenv("SWA_DUAL_MP") && std::atoi(std::getenv("SWA_DUAL_MP")) == 1;
   // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
-  int Gd = qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
-  if (const char* e = std::getenv("SWA_LANES")) Gd = std::min(16, std::max(Gd, std::atoi(e)));
+  int Gd = qlen <= 2 * 32 ? 2 : qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
+  if (const char* e = std::getenv("SWA_LANES")) {
+    Gd = std::atoi(e) >= 16 ? 16 : std::atoi(e) >= 8 ? 8 : std::atoi(e) >= 4 ? 4 : 2;
+    while (Gd < 16 && qlen > Gd * 32) Gd *= 2;
+  }
   int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
   if (const char* e = std::getenv("SWA_DUAL_KMAX")) if (Kd > std::atoi(e)) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {

@@ -142,7 +142,7 @@ def test_every_rows_per_lane_variant(qlen):
     db.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 8, 4])
+@pytest.mark.parametrize("lanes", [16, 8, 4, 2])
 def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
     """rows per lane K = ceil(qlen / lanes) for every K in 1..48 of all three forms (16 lanes per sequence pair, 8 for
     queries of at most 384 rows, 4 for at most 192): one query per instantiation, at both ends of its window"""
@@ -159,7 +159,7 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
         for qlen in (lanes * K - lanes + 1, lanes * K):
             q = full[:qlen]
             scores, c = db.search(q)
-            assert c["narrow_rows"] == K and c["narrow_shifted"] == {16: 1, 8: 2, 4: 3}[lanes]
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == {16: 1, 8: 2, 4: 3, 2: 7}[lanes]
             assert np.array_equal(scores, oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)), (K, qlen)
     db.close()
 
@@ -324,7 +324,7 @@ def test_dual_query_kernel_both_strands(qlen):
     db.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 8, 4])
+@pytest.mark.parametrize("lanes", [16, 8, 4, 2])
 @pytest.mark.parametrize("protein", [False, True])
 def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monkeypatch):
     """two queries of equal length in one pass, K = ceil(qlen / lanes): every K of the nucleotide build (1..61 with
