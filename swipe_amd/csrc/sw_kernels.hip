@@ -894,6 +894,23 @@ extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* 
   hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
   return hipGetLastError();
 }
+// the sequences the alignment phase wants back on the host, packed one after the other (one block per sequence)
+extern "C" __global__ void __launch_bounds__(256)
+swa_gather_sequences(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets, const int* __restrict__ ids,
+                     const int64_t* __restrict__ out_off, int n, uint8_t* __restrict__ out)
+{
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int64_t o = offsets[ids[i]], len = offsets[ids[i] + 1] - o, d = out_off[i];
+  for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[d + k] = residues[o + k];
+}
+extern "C" hipError_t swa_launch_gather(const uint8_t* residues, const int64_t* offsets, const int* ids, const int64_t* out_off,
+                                        int n, uint8_t* out, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swa_gather_sequences, dim3(n), dim3(256), 0, st, residues, offsets, ids, out_off, n, out);
+  return hipGetLastError();
+}
 // excluded sequences (OID mask / taxid filter) report -1 so that no score threshold >= 0 ever accepts them
 extern "C" __global__ void swa_mark_excluded(int* __restrict__ scores, const int* __restrict__ ids, int n)
 {

@@ -29,6 +29,8 @@ int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
+hipError_t swa_launch_gather(const uint8_t* residues, const int64_t* offsets, const int* ids, const int64_t* out_off, int n,
+                             uint8_t* out, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
 hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
@@ -1517,6 +1519,50 @@ int fetch_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, std::vect
   }
   return SWA_OK;
 }
+// the same for a list: one gather kernel and one copy instead of a synchronous copy per sequence
+int fetch_sequences(swa_db* db, const int64_t* seqnos, const int32_t* dstrands, const int32_t* dframes, int64_t n,
+                    std::vector<std::vector<uint8_t>>& seqs)
+{
+  seqs.assign(size_t(n), {});
+  if (n == 0) return SWA_OK;
+  std::vector<int32_t> ids((size_t(n)));
+  std::vector<uint8_t> minus((size_t(n)), 0);
+  std::vector<int64_t> out_off(size_t(n) + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t local = 0;
+    bool m = false;
+    const int rc = locate(db, seqnos[i], dstrands ? (dstrands[i] ? 1 : 0) : 0, dframes ? dframes[i] : 0, &local, &m);
+    if (rc != SWA_OK) return rc;
+    ids[size_t(i)] = int32_t(local);
+    minus[size_t(i)] = m;
+    out_off[size_t(i) + 1] = out_off[size_t(i)] + db->h_offsets[size_t(local) + 1] - db->h_offsets[size_t(local)];
+  }
+  const int64_t total = out_off[size_t(n)];
+  HIP_TRY(hipSetDevice(db->device));
+  hipStream_t st = db->stream;
+  DevBuf<int32_t> d_ids;
+  DevBuf<int64_t> d_off;
+  DevBuf<uint8_t> d_out;
+  HIP_TRY(d_ids.reserve(size_t(n)));
+  HIP_TRY(d_off.reserve(size_t(n)));
+  HIP_TRY(d_out.reserve(size_t(total) + 1));
+  HIP_TRY(hipMemcpyAsync(d_ids.p, ids.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_off.p, out_off.data(), size_t(n) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(swa_launch_gather(db->residues.p, db->offsets.p, d_ids.p, d_off.p, int(n), d_out.p, st));
+  std::vector<uint8_t> all(size_t(total) + 1);
+  HIP_TRY(hipMemcpyAsync(all.data(), d_out.p, size_t(total), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};     // database.cc ntcompl
+  for (int64_t i = 0; i < n; ++i) {
+    std::vector<uint8_t>& seq = seqs[size_t(i)];
+    seq.assign(all.begin() + out_off[size_t(i)], all.begin() + out_off[size_t(i) + 1]);
+    if (minus[size_t(i)]) {
+      std::reverse(seq.begin(), seq.end());
+      for (uint8_t& c : seq) c = compl4[c & 15];
+    }
+  }
+  return SWA_OK;
+}
 }  // namespace
 
 extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
@@ -1630,16 +1676,14 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   const int64_t limit16 = 65536 - db->hi;                           // SCORELIMIT_16, matrices.cc:578
   // sequences come back from the device on this thread; the tracebacks are independent and run on a few host
   // threads (the reference spreads align_chunk over its worker threads the same way, swipe.cc:615-647)
-  std::vector<std::vector<uint8_t>> dseqs{size_t(n)};
-  for (int64_t i = 0; i < n; ++i) {
-    rc = fetch_sequence(db, seqnos[i], dstrands ? (dstrands[i] ? 1 : 0) : 0, dframes ? dframes[i] : 0, dseqs[size_t(i)]);
-    if (rc != SWA_OK) return rc;
-  }
+  std::vector<std::vector<uint8_t>> dseqs;
+  rc = fetch_sequences(db, seqnos, dstrands, dframes, n, dseqs);
+  if (rc != SWA_OK) return rc;
   std::vector<std::string> scripts{size_t(n)};
   std::vector<int> status(size_t(n), SWA_OK);
-  auto work = [&](int64_t lo, int64_t hi) {
+  auto work = [&](int64_t first, int64_t step) {
     std::vector<swa::EditOp> ops;
-    for (int64_t i = lo; i < hi; ++i) {
+    for (int64_t i = first; i < n; i += step) {
       const std::vector<uint8_t>& dseq = dseqs[size_t(i)];
       swa_alignment_t& a = out[i];
       std::memset(&a, 0, sizeof a);
@@ -1658,12 +1702,13 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
       for (const swa::EditOp& op : ops) { sc += op.kind; sc += std::to_string(op.count); }
     }
   };
-  const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({n, int64_t(std::thread::hardware_concurrency()), 16}));
+  // two alignments per thread at least; the hits are ordered by score, so a thread takes every nthreads-th one
+  const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({n / 2, int64_t(std::thread::hardware_concurrency()), 64}));
   if (nthreads == 1) {
-    work(0, n);
+    work(0, 1);
   } else {
     std::vector<std::thread> pool;
-    for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
+    for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(work, t, nthreads);
     for (std::thread& t : pool) t.join();
   }
   std::string all;
