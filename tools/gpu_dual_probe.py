@@ -14,11 +14,14 @@ for qlen in map(int, sys.argv[1:]):
     out = []
     for mp in ("0", "16", "1"):
         os.environ["SWA_DUAL_MP"] = "1" if mp == "1" else "0"
-        os.environ["SWA_LANES"] = "16" if mp == "16" else "4"
+        if mp == "16":
+            os.environ["SWA_LANES"] = "16"
+        else:
+            os.environ.pop("SWA_LANES", None)
         db.search2(q, qm, want_scores=False)
         best, c = 1e9, None
         for _ in range(3):
             _, _, c = db.search2(q, qm, want_scores=False)
             best = min(best, c["kernel_ms"])
-        out.append("%s K=%2d %.0f GCUPS" % ({"0": "short chains", "16": "16-lane", "1": "multi-pass"}[mp], c["narrow_rows"], c["cells"] / best / 1e6))
+        out.append("%s K=%2d %.0f GCUPS" % ({"0": "default", "16": "16-lane chains", "1": "block-synchronous multi-pass"}[mp], c["narrow_rows"], c["cells"] / best / 1e6))
     print("qlen %4d: %s" % (qlen, " | ".join(out)), flush=True)

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import swipe_amd
 from swipe_amd import synth
 rtab = synth.residue_table_protein()
-full = synth._random_residues(7, 1, 800, rtab)
+full = synth._random_residues(7, 1, 6000, rtab)
 res, off = swipe_amd.synth_db(1, 2_000_000, query=full[:375])
 db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
