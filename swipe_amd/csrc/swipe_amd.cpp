@@ -438,7 +438,7 @@ int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const size_t avail = free_b + db->boundary.bytes();
-  size_t budget = std::min<size_t>(size_t(16) << 30, avail / 4);
+  size_t budget = std::min<size_t>(size_t(64) << 30, avail / 4);
   if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
   const size_t per_chunk = 64 * 8;
   const int nb = bs.nbatches;
@@ -466,7 +466,7 @@ int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
 // query allows, each pass ONE launch of the MP build of swa_narrow_split_kernel over a run of batches.  The last
 // row of a pass is handed to the next launch through db->boundary, 8 bytes per element of the residue stream
 // (13 GB for a 10 M-sequence protein database: HBM is the one thing this box has to spare, and at 26 GB of extra
-// traffic per pass boundary it costs 3 ms of a 130 ms pass).  The buffer is capped; batches are taken in runs
+// traffic per pass boundary it costs 3 ms of a 130 ms pass).  The buffer is capped (64 GB or a quarter of the free memory); batches are taken in runs
 // that fit it, all passes of a run before the next run.
 void split_pass_shape(int64_t qlen, int* npass, int* K)
 {
