@@ -208,6 +208,7 @@ def main():
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
+        OPS = {0: 8.5, 1: 7.5, 2: 7.5, 3: 7.5, 7: 7.5, 8: 6.5}        # VALU instructions per cell pair of each form
         out = {
             "metric": "GCUPS, 375-aa query vs 10M-seq protein db at 1/2/4/8 GPUs; bit-exact scores",
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -220,17 +221,19 @@ def main():
                        if world > 1 else "single shard"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": ("swa_narrow_split_kernel<%d, W, 8>" if c["narrow_shifted"] == 2 else "swa_narrow_split_kernel<%d, W, 4>"
-                                    if c["narrow_shifted"] == 3 else "swa_narrow_split_kernel<%d, W, 16>"
-                                    if c["narrow_shifted"] else "swa_narrow_kernel<%d>") % c["narrow_rows"],
+                         "kernel": {2: "swa_narrow_split_kernel<%d, W, 8>", 3: "swa_narrow_split_kernel<%d, W, 4>",
+                                    1: "swa_narrow_split_kernel<%d, W, 16>", 0: "swa_narrow_kernel<%d>",
+                                    8: "swa_narrow_bound_kernel<%d, 2, 8, 16> (bound build of the first pass; sequences "
+                                       "at or above the score threshold recomputed by the 32-bit kernel inside the step)"}[
+                                        c["narrow_shifted"]] % c["narrow_rows"],
                          "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer DP at 375 cells per residue byte is VALU-issue-bound, not HBM-bound; "
                                  "see valu_roofline"},
             "valu_roofline": {"achieved_gcups_kernel": round(nsym * len(q) / (k_ms * 1e-3) / 1e9, 1),
-                              "peak_gcups": round(256 * 4 * 2.4e9 / 4 * 128 / (7.5 if c["narrow_shifted"] else 8.5) / 1e9, 1),
+                              "peak_gcups": round(256 * 4 * 2.4e9 / 4 * 128 / OPS[c["narrow_shifted"]] / 1e9, 1),
                               "model": "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per VOP3P wave64 op x 128 cells / "
-                                       + ("7.5" if c["narrow_shifted"] else "8.5") + " ops per cell pair"},
+                                       "%.1f ops per cell pair" % OPS[c["narrow_shifted"]]},
             "search": {"totalhits": int(tot), "top_hit": list(hits[0]) if hits else None, "requeued_32bit": int(c["wide"]),
                        "requeued_64bit": int(c["full"])},
             "setup_s": {"generate": round(t_gen, 2), "load_format": round(t_load, 2)},

@@ -29,6 +29,11 @@ int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
+hipError_t swa_launch_narrow_bound_g4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_bound_g8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_bound_g16(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+int swa_bound_period(void);
+int swa_bound_available(int G, int K);
 hipError_t swa_launch_gather(const uint8_t* residues, const int64_t* offsets, const int* ids, const int64_t* out_off, int n,
                              uint8_t* out, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -152,6 +157,7 @@ struct swa_db {
   int32_t h_matrix[1024];
   int64_t goe = 0, ge = 0, hi = 0, lo = 0;
   int narrow_variant = 0;                  // 0 auto, 1 plain, 2 row-shifted (SWA_NARROW_VARIANT, for A/B runs)
+  bool bound_off = false;                  // the bound build sent back too many sequences under this scoring system
 
   ~swa_db()
   {
@@ -675,7 +681,9 @@ int finish_empty(swa_db* db, swa_counters_t& c, swa_counters_t* counters, bool t
 }
 
 // the escalation loop: packed f16 -> 32 bit -> 64 bit.  Scores end up in db->scores / scores64.
-int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* counters)
+// bound_min > 0: the caller only wants the sequences scoring at least bound_min (top-K searches); the first pass may
+// then be the bound build of the kernel (sw_cb_kernels.hip), which leaves placeholders below bound_min for the rest
+int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* counters, int64_t bound_min = 0)
 {
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
@@ -692,6 +700,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, 8 * sizeof(int32_t), st));
 
   std::vector<int32_t> requeue;
+  bool used_bound = false;
   const bool f16 = f16_applicable(db);
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
@@ -734,7 +743,24 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     p.pipe = -1;
     if (const char* w = std::getenv("SWA_PIPE")) p.pipe = std::atoi(w);
     if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((items + 3) / 4, db->cus * std::atoi(w)));
-    HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));
+    // Bound build (6.5 instead of 7.5 instructions per cell pair): its result is at most (period - 1) R above the score,
+    // everything at or above bound_min is recomputed by the 32-bit kernel.  Used when the threshold is far enough above
+    // that slack for the recomputed share to be negligible (SWA_BOUND = 0 never, 1 whenever a build exists); if more
+    // than 2 % of the sequences come back it is switched off for this scoring system and the exact kernel runs
+    const int Nb = swa_bound_period();
+    const char* be = std::getenv("SWA_BOUND");
+    const int bmode = be ? std::atoi(be) : -1;
+    used_bound = bound_min > 0 && bmode != 0 && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024 &&
+                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge));
+    if (used_bound) {
+      p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
+      for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
+      c.narrow_shifted = 8;
+      HIP_TRY(G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
+                     : swa_launch_narrow_bound_g16(K, &p, blocks, st));
+    } else {
+      HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));
+    }
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
@@ -778,6 +804,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   if (c.narrow) {
     rc = read_requeue(db, 1, db->ovf_list.p, requeue, st);
     if (rc != SWA_OK) return rc;
+    if (used_bound && int64_t(requeue.size()) * 50 > db->nseq && !(std::getenv("SWA_BOUND") && std::atoi(std::getenv("SWA_BOUND")) == 1)) {
+      db->bound_off = true;                            // threshold too close to the bulk of the scores
+      return run_search(db, query, qlen, counters, 0);
+    }
   } else {
     requeue.assign(db->h_order.begin(), db->h_order.end());
   }
@@ -1182,6 +1212,7 @@ extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapope
   HIP_TRY(hipMemcpyAsync(db->matrix.p, db->h_matrix, sizeof db->h_matrix, hipMemcpyHostToDevice, db->stream));
   HIP_TRY(hipStreamSynchronize(db->stream));
   db->scoring_set = true;
+  db->bound_off = false;
   return SWA_OK;
 }
 
@@ -1314,7 +1345,7 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
 {
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
-  int rc = run_search(db, query, qlen, counters);
+  int rc = run_search(db, query, qlen, counters, minscore);
   if (rc != SWA_OK) return rc;
   *nhits = 0;
   int64_t tot = 0, obv = 0;

@@ -164,6 +164,93 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
     db.close()
 
 
+def _expected_topk(scores, keep, minscore, maxscore=1 << 62):
+    order = sorted((i for i in range(len(scores)) if scores[i] >= minscore), key=lambda i: (-int(scores[i]), -i))
+    kept = [i for i in order if scores[i] <= maxscore]     # hits.cc:174-178: "obvious" hits are counted, not listed
+    return [(i, int(scores[i])) for i in kept[:keep]], len(order), int((scores > maxscore).sum())
+
+
+@pytest.mark.parametrize("lanes", [16, 8, 4])
+def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
+    """top-K searches may run the bound build of the row-shifted kernel (6.5 instructions per cell pair, result at most
+    15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (50)
+    of every chain length, hits planted at every distance from the threshold, thresholds from "everything comes back"
+    to "nothing does", gap extension penalties 1..3 - hit list, totalhits and obvious must equal the exact ones"""
+    monkeypatch.setenv("SWA_LANES", str(lanes))
+    monkeypatch.setenv("SWA_BOUND", "1")
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(99, 1, 800, rtab)
+    rng = np.random.default_rng(lanes)
+    res, off = swipe_amd.synth_db(6, 1500, query=full)
+    seqs = [res[off[i]:off[i + 1]] for i in range(1500)]
+    for k in range(120):                                   # pieces of the query of every length: scores across every threshold
+        a = int(rng.integers(0, 700))
+        piece = full[a:a + int(rng.integers(8, 90))].copy()
+        mut = rng.random(len(piece)) < rng.random() * 0.4
+        piece[mut] = rtab[rng.integers(0, len(rtab), int(mut.sum()))]
+        seqs.append(np.concatenate([seqs[k][:int(rng.integers(0, 60))], piece, seqs[k + 1][:int(rng.integers(0, 60))]]))
+    seqs += [full, full[::2].copy(), np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    n = 0
+    for K in range(25, (50 if lanes == 16 else 48) + 1):
+        go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
+        q = full[:lanes * K - (K % lanes)]
+        want = oracle.search_all63(r2, o2, q, Mo, go + ge, ge, threads=THREADS)
+        for minscore, maxscore in ((1, 1 << 62), (35, 90), (60, 1 << 62), (100, 300), (400, 1 << 62)):
+            hits, tot, obv, c = db.search_topk(q, keep=40, minscore=minscore, maxscore=maxscore)
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == 8, (K, c)
+            assert (hits, tot, obv) == _expected_topk(want, 40, minscore, maxscore), (K, minscore)
+            n += c["wide"]
+    assert n > 0
+    # all scores are still exact when they are asked for
+    scores, c = db.search(q)
+    assert c["narrow_shifted"] in (1, 2, 3) and np.array_equal(scores, want)
+    db.close()
+
+
+def test_bound_build_is_dropped_when_too_much_comes_back(monkeypatch):
+    """auto mode: the bound build runs only for thresholds well above its slack, and a search that sends more than 2 % of
+    the sequences back switches it off until the scoring system changes; results are exact either way"""
+    monkeypatch.delenv("SWA_BOUND", raising=False)
+    q = cases.Q375
+    rtab = synth.residue_table_protein()
+    rng = np.random.default_rng(5)
+    res, off = swipe_amd.synth_db(6, 2000, query=q)
+    seqs = [res[off[i]:off[i + 1]] for i in range(2000)]
+    r2, o2 = oracle.pack(seqs)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    hits, tot, obv, c = db.search_topk(q, keep=50, minscore=30)            # threshold below 4 x 16 R: exact kernel
+    assert c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want, 50, 30)
+    hits, tot, obv, c = db.search_topk(q, keep=50, minscore=80)
+    assert c["narrow_shifted"] == 8 and (hits, tot, obv) == _expected_topk(want, 50, 80)
+    # a family database: a tenth of the sequences are relatives of the query
+    fam = list(seqs)
+    for k in range(0, 2000, 10):
+        piece = q.copy()
+        mut = rng.random(len(piece)) < 0.5
+        piece[mut] = rtab[rng.integers(0, len(rtab), int(mut.sum()))]
+        fam[k] = piece
+    r3, o3 = oracle.pack(fam)
+    want3 = oracle.search_all63(r3, o3, q, Mo, 12, 1, threads=THREADS)
+    db3 = swipe_amd.Database.from_arrays(r3, o3)
+    db3.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=80)
+    assert tot > 40 and c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want3, 50, 80)     # fell back
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=80)
+    assert c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want3, 50, 80)                  # and stays off
+    db3.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=900)
+    assert c["narrow_shifted"] == 8 and (hits, tot, obv) == _expected_topk(want3, 50, 900)
+    db.close()
+    db3.close()
+
+
 @pytest.mark.parametrize("lanes", [8, 4])
 def test_pipelined_profile_build_of_the_split_kernel(lanes, monkeypatch):
     """the builds of swa_narrow_split_kernel: all profile units staged / pipelined one unit ahead (K = 30..36) /

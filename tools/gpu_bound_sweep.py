@@ -1,0 +1,24 @@
+"""Bound build vs exact first pass, kernel GCUPS for every rows-per-lane K of each chain length G (top-250 search, threshold 80)."""
+import os, sys, numpy as np
+np.seterr(over='ignore')
+sys.path.insert(0, '.')
+import swipe_amd
+from swipe_amd import synth
+rtab = synth.residue_table_protein()
+full = synth._random_residues(7, 1, 900, rtab)
+res, off = swipe_amd.synth_db(1, 2_000_000)
+db = swipe_amd.Database.from_arrays(res, off)
+db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+for G in (4, 8, 16):
+    os.environ["SWA_LANES"] = str(G)
+    for K in range(25, (50 if G == 16 else 48) + 1):
+        q = full[:G * K]
+        out, ref = [], None
+        for mode in ("0", "1"):
+            os.environ["SWA_BOUND"] = mode
+            hits, tot, obv, c = db.search_topk(q, keep=250, minscore=80)
+            if ref is None: ref = (hits, tot, obv)
+            best = min(db.search_topk(q, keep=250, minscore=80)[3]["kernel_ms"] for _ in range(3))
+            out.append((c["cells"] / best / 1e6, c["narrow_shifted"], c["wide"], (hits, tot, obv) == ref))
+        print("G=%2d K=%2d exact %5.0f  bound %5.0f (form %d, requeued %d, same hits %s)  %+.1f %%" % (
+            G, K, out[0][0], out[1][0], out[1][1], out[1][2], out[1][3], 100 * (out[1][0] / out[0][0] - 1)), flush=True)
