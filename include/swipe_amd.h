@@ -88,7 +88,8 @@ typedef struct {
                             per sequence pair (queries of at most 928 / 384 / 192 rows); 4: single-pass two-query kernel;
                             5: row-shifted form, one launch per pass of 16 x narrow_rows query rows (queries > 928 rows);
                             6: two-query kernel, one launch per pass (queries > 976 nucleotide / 512 other rows);
-                            7: row-shifted form with 2 lanes per sequence pair (queries of at most 40 rows) */
+                            7: row-shifted form with 2 lanes per sequence pair (queries of at most 40 rows);
+                            8: bound build of the row-shifted form (swa_search_topk only, see there) */
 } swa_counters_t;
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;
@@ -174,7 +175,13 @@ SWA_API int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* 
                swa_counters_t* counters);
 /* The hits_enter loop on device: keeps the `keep` best (score desc, seqno desc) among
    minscore <= score <= maxscore; *totalhits counts scores >= minscore, *obvious counts scores
-   > maxscore (hits.cc:174-178).  hits[] receives *nhits entries, already ordered. */
+   > maxscore (hits.cc:174-178).  hits[] receives *nhits entries, already ordered.
+   Only scores >= minscore are observable here, so when minscore is well above the spread of unrelated
+   sequences the first pass may be the BOUND build of the kernel (6.5 instead of 7.5 instructions per
+   cell pair; it yields an upper bound at most 15 x gapextend above the score) and every sequence whose
+   bound reaches minscore is recomputed exactly before the list is made: hits, *totalhits and *obvious
+   are identical to the exact pass's (counters.narrow_shifted = 8; SWA_BOUND=0 in the environment
+   disables it). */
 SWA_API int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep,
                     int64_t minscore, int64_t maxscore, swa_hit_t* hits, int64_t* nhits,
                     int64_t* totalhits, int64_t* obvious, swa_counters_t* counters);

@@ -654,7 +654,8 @@ swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* _
                           const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
                           const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
                           int* __restrict__ bh, int* __restrict__ bf, const int64_t* __restrict__ boff,
-                          long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q)
+                          long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q,
+                          int* __restrict__ scores)
 {
   __shared__ int M[1024];
   __shared__ uint8_t ring[128];
@@ -741,7 +742,10 @@ swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* _
     const int ob = __shfl_down(best, sh), oc = __shfl_down(bcol, sh), orow = __shfl_down(brow, sh);
     if (ob > best || (ob == best && ob > 0 && (oc < bcol || (oc == bcol && orow < brow)))) { best = ob; bcol = oc; brow = orow; }
   }
-  if (g == 0) { out_score[w] = best; out_pos[w] = bcol; out_q[w] = brow; }
+  if (g == 0) {
+    if (scores) scores[ids[w]] = best;           // re-queue use: the score of the sequence, in place
+    else { out_score[w] = best; out_pos[w] = bcol; out_q[w] = brow; }
+  }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -943,16 +947,17 @@ extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_
                      Hs, Es, out, out + n, out + 2 * (size_t)n);
   return hipGetLastError();
 }
-// wave-per-sequence end points; bh/bf/boff may be null when qlen <= 64 * rows-per-lane(qlen) (single pass)
+// wave-per-sequence end points; bh/bf/boff may be null when qlen <= 64 * rows-per-lane(qlen) (single pass).
+// scores != null: re-queue use - only scores[ids[i]] is written (out may be null)
 extern "C" int swa_endpoints_rows_for(int qlen) { return qlen <= 256 ? 4 : qlen <= 512 ? 8 : qlen <= 1024 ? 16 : 32; }
 extern "C" hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
                                                 const uint8_t* minus, int n, const uint8_t* qseq, int qlen,
                                                 const int32_t* matrix, int Q, int R, int* bh, int* bf,
-                                                const int64_t* boff, long long* out, hipStream_t st)
+                                                const int64_t* boff, long long* out, int* scores, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
 #define SWA_EPW(KK) hipLaunchKernelGGL(swa_endpoints_wave_kernel<KK>, dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
-                                       qseq, qlen, matrix, Q, R, bh, bf, boff, out, out + n, out + 2 * (size_t)n)
+                                       qseq, qlen, matrix, Q, R, bh, bf, boff, out, out ? out + n : out, out ? out + 2 * (size_t)n : out, scores)
   switch (swa_endpoints_rows_for(qlen)) {
     case 4: SWA_EPW(4); break;
     case 8: SWA_EPW(8); break;

@@ -44,7 +44,8 @@ hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets,
 int swa_endpoints_rows_for(int qlen);
 hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
                                      const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix,
-                                     int Q, int R, int* bh, int* bf, const int64_t* boff, long long* out, hipStream_t st);
+                                     int Q, int R, int* bh, int* bf, const int64_t* boff, long long* out, int* scores,
+                                     hipStream_t st);
 hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
 hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
@@ -144,6 +145,7 @@ struct swa_db {
   DevBuf<int32_t> ovf_list2;
   DevBuf<int32_t> scores2;                 // second query of a dual search
   DevBuf<uint8_t> qseq2;
+  DevBuf<int32_t> rq_ids;                  // re-queue list of the wave-per-sequence path
   DevBuf<unsigned char> boundary;          // per-wave pass hand-over columns of the multi-pass kernel
   DevBuf<int32_t> ctl;                     // [0] work counter, [1] overflow count, [2] candidate count, [3] overflow count of query 2
   DevBuf<unsigned long long> tallies;      // totalhits, obvious
@@ -613,6 +615,24 @@ int read_requeue(swa_db* db, int ctl_index, const int32_t* list, std::vector<int
 int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int64_t qlen, int32_t* scores,
              int64_t* n32, int64_t* n64, hipStream_t st)
 {
+  // A short list is latency-bound in the batch kernels (one 16-lane chain per sequence, the longest sequence sets the
+  // time): a wave per sequence - the end-point kernel of the alignment phase, 64 lanes on one sequence - finishes the
+  // 1 500 sequences the bound build sends back for the bench query in 0.3 ms instead of 1.5.  int32 is exact when
+  // qlen x highest score stays below 2^30 (then nothing can reach the 64-bit hop either).
+  const char* wq = std::getenv("SWA_WAVE_REQUEUE");
+  if (!requeue.empty() && requeue.size() <= (size_t(1) << 16) && int64_t(requeue.size()) < db->nseq &&
+      qlen <= 64 * swa_endpoints_rows_for(int(std::min<int64_t>(qlen, 1 << 20))) && !(wq && std::atoi(wq) == 0) &&
+      std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1) < (int64_t(1) << 30) && db->goe < (int64_t(1) << 30) &&
+      db->ge < (int64_t(1) << 30)) {
+    HIP_TRY(db->rq_ids.reserve(requeue.size()));
+    HIP_TRY(hipMemcpyAsync(db->rq_ids.p, requeue.data(), requeue.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(swa_launch_endpoints_wave(db->residues.p, db->offsets.p, db->rq_ids.p, nullptr, int(requeue.size()), qdev, int(qlen),
+                                      db->matrix.p, int(db->goe), int(db->ge), nullptr, nullptr, nullptr, nullptr, scores, st));
+    HIP_TRY(hipStreamSynchronize(st));                 // the id list lives in the caller's vector
+    *n32 += int64_t(requeue.size());
+    requeue.clear();
+    return SWA_OK;
+  }
   for (int bits = 32; !requeue.empty() && bits <= 64; bits += 32) {
     const BatchSet* set = &db->scratch;
     if (int64_t(requeue.size()) == db->nseq) {
@@ -1514,7 +1534,7 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
     }
     HIP_TRY(swa_launch_endpoints_wave(db->residues.p, db->offsets.p, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
                                       db->matrix.p, int(db->goe), int(db->ge), passes ? d_bh.p : nullptr,
-                                      passes ? d_bf.p : nullptr, passes ? d_boff.p : nullptr, d_out.p, st));
+                                      passes ? d_bf.p : nullptr, passes ? d_boff.p : nullptr, d_out.p, nullptr, st));
     out.resize(3 * size_t(n));
     HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

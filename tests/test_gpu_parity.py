@@ -211,6 +211,26 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db.close()
 
 
+@pytest.mark.parametrize("wave", ["0", "1"])
+@pytest.mark.parametrize("qlen", [300, 1300, 2048, 2500])
+def test_requeue_by_batches_and_by_wave(qlen, wave, monkeypatch):
+    """sequences that leave the packed range are recomputed in 32 bits: a short list by one wave per sequence (queries up
+    to 2 048 rows), otherwise by the batch kernel (SWA_WAVE_REQUEUE=0 forces it) - same scores"""
+    monkeypatch.setenv("SWA_WAVE_REQUEUE", wave)
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(808 + qlen, 1, qlen, rtab)
+    res, off = swipe_amd.synth_db(12, 1200, query=q)
+    seqs = [res[off[i]:off[i + 1]] for i in range(1200)]
+    seqs += [q, q[::-1].copy(), np.concatenate([q, q]), q[: qlen // 2].copy(), synth._random_residues(5, 1, 9000, rtab), np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    scores, c = db.search(q)
+    assert c["wide"] >= 3 and c["full"] == 0
+    assert np.array_equal(scores, oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS))
+    db.close()
+
+
 def test_bound_build_is_dropped_when_too_much_comes_back(monkeypatch):
     """auto mode: the bound build runs only for thresholds well above its slack, and a search that sends more than 2 % of
     the sequences back switches it off until the scoring system changes; results are exact either way"""
