@@ -212,7 +212,7 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
 
 
 @pytest.mark.parametrize("wave", ["0", "1"])
-@pytest.mark.parametrize("qlen", [300, 1300, 2048, 2500])
+@pytest.mark.parametrize("qlen", [600, 1300, 2048, 2500])
 def test_requeue_by_batches_and_by_wave(qlen, wave, monkeypatch):
     """sequences that leave the packed range are recomputed in 32 bits: a short list by one wave per sequence (queries up
     to 2 048 rows), otherwise by the batch kernel (SWA_WAVE_REQUEUE=0 forces it) - same scores"""
@@ -226,7 +226,7 @@ def test_requeue_by_batches_and_by_wave(qlen, wave, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     scores, c = db.search(q)
-    assert c["wide"] >= 3 and c["full"] == 0
+    assert c["wide"] >= 2 and c["full"] == 0
     assert np.array_equal(scores, oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS))
     db.close()
 
