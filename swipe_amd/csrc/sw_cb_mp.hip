@@ -1,0 +1,23 @@
+// Bound builds of the row-shifted kernel, one pass of a long query per launch (see sw_cb_kernel.inc).
+#include "sw_common.cuh"
+#include "sw_cb_kernel.inc"
+
+template <int K>
+static hipError_t launch_bound_pass(const swa_narrow_params& p, int blocks, hipStream_t st)
+{
+  const size_t lds = (size_t)32 * ((K + 7) / 8) * 256;
+  auto kern = swa_narrow_bound_kernel<K, 2, 16, SWA_CB_PERIOD, true>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_narrow_bound_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_CBK(KK) case KK: return launch_bound_pass<KK>(*p, blocks, st);
+  switch (K) {
+    SWA_CBK(30) SWA_CBK(31) SWA_CBK(32) SWA_CBK(33) SWA_CBK(34) SWA_CBK(35) SWA_CBK(36) SWA_CBK(37) SWA_CBK(38) SWA_CBK(39) SWA_CBK(40) SWA_CBK(41) SWA_CBK(42) SWA_CBK(43) SWA_CBK(44) SWA_CBK(45) SWA_CBK(46) SWA_CBK(47)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_CBK
+}

@@ -40,7 +40,7 @@ struct swa_narrow_params {
                                   -1 = whichever measured fastest for this K */
   float gapextend_f;           /* R, added to every profile entry */
   uint32_t negQR, negKR;       /* packed f16 pairs: -(gapopen) = -(Q - R), -K R */
-  uint32_t rowc[68];           /* packed f16 pairs r*R for r = 0..K+1 */
+  uint32_t rowc[80];           /* packed f16 pairs r*R for r = 0..K+1 (bound build: ..K+period+1) */
   /* one pass of a long query (MP build of swa_narrow_split_kernel) */
   void* boundary;              /* (H, F) f16 pairs of the pass's last row: 8 bytes per stream element, stream layout */
   long long boundary_base;     /* stream chunk (swa_batch.offset units) that boundary[0] belongs to */

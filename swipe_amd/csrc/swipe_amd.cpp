@@ -29,6 +29,7 @@ int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
+hipError_t swa_launch_narrow_bound_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g16(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -145,7 +146,9 @@ struct swa_db {
   DevBuf<int32_t> ovf_list2;
   DevBuf<int32_t> scores2;                 // second query of a dual search
   DevBuf<uint8_t> qseq2;
-  DevBuf<int32_t> rq_ids;                  // re-queue list of the wave-per-sequence path
+  DevBuf<int32_t> rq_ids;                  // re-queue list of the wave-per-sequence path, and its pass hand-over
+  DevBuf<int> rq_bh, rq_bf;
+  DevBuf<int64_t> rq_boff;
   DevBuf<unsigned char> boundary;          // per-wave pass hand-over columns of the multi-pass kernel
   DevBuf<int32_t> ctl;                     // [0] work counter, [1] overflow count, [2] candidate count, [3] overflow count of query 2
   DevBuf<unsigned long long> tallies;      // totalhits, obvious
@@ -476,9 +479,8 @@ int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
 // (13 GB for a 10 M-sequence protein database: HBM is the one thing this box has to spare, and at 26 GB of extra
 // traffic per pass boundary it costs 3 ms of a 130 ms pass).  The buffer is capped (64 GB or a quarter of the free memory); batches are taken in runs
 // that fit it, all passes of a run before the next run.
-void split_pass_shape(int64_t qlen, int* npass, int* K)
+void split_pass_shape(int64_t qlen, int* npass, int* K, int kmax = 56)   // 57+ rows of a pass build spill (bound build: 48+)
 {
-  const int kmax = 56;                                 // 57+ rows of a pass build spill
   const int64_t np = (qlen + 16 * kmax - 1) / (16 * kmax);
   *npass = int(np);
   *K = int(std::max<int64_t>(30, (qlen + 16 * np - 1) / (16 * np)));
@@ -491,10 +493,12 @@ int split_pass_rows(int64_t qlen)
   return K;
 }
 
-int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st)
+// bound: the passes are bound builds (top-K searches, see run_search) of at most 47 rows per lane
+int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st, bool bound, int64_t bound_min)
 {
   int npass = 0, K = 0;
-  split_pass_shape(qlen, &npass, &K);
+  split_pass_shape(qlen, &npass, &K, bound ? 47 : 56);
+  const int Nb = bound ? swa_bound_period() : 0;
   const BatchSet& bs = db->main;
   swa_narrow_params p{};
   p.query = db->query.p;
@@ -506,11 +510,11 @@ int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st)
   p.negQ = f16_pair(-float(db->goe));
   p.negR = f16_pair(-float(db->ge));
   p.shifted = 1;
-  p.limit = int32_t(f16_limit(db, K));
+  p.limit = int32_t(bound ? std::min<int64_t>(f16_limit(db, K + Nb), bound_min) : f16_limit(db, K));
   p.gapextend_f = float(db->ge);
   p.negQR = f16_pair(-float(db->goe - db->ge));
   p.negKR = f16_pair(-float(int64_t(K) * db->ge));
-  for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
+  for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
 
   PassRuns runs;
   const int prc = plan_pass_runs(db, bs, runs);
@@ -528,7 +532,8 @@ int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st)
       p.pass = pass;
       p.last = pass + 1 == npass;
       HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
-      HIP_TRY(swa_launch_narrow_pass(K, &p, persistent_blocks(db, p.nbatches), st));
+      HIP_TRY(bound ? swa_launch_narrow_bound_pass(K, &p, persistent_blocks(db, p.nbatches), st)
+                    : swa_launch_narrow_pass(K, &p, persistent_blocks(db, p.nbatches), st));
     }
   }
   return SWA_OK;
@@ -617,17 +622,33 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
 {
   // A short list is latency-bound in the batch kernels (one 16-lane chain per sequence, the longest sequence sets the
   // time): a wave per sequence - the end-point kernel of the alignment phase, 64 lanes on one sequence - finishes the
-  // 1 500 sequences the bound build sends back for the bench query in 0.3 ms instead of 1.5.  int32 is exact when
+  // 1 500 sequences the bound build sends back for the bench query in 1.3 ms instead of 1.5, the 390 of a 5 000-row
+  // query in a fraction of the batch kernel's 20 passes.  int32 is exact when
   // qlen x highest score stays below 2^30 (then nothing can reach the 64-bit hop either).
   const char* wq = std::getenv("SWA_WAVE_REQUEUE");
   if (!requeue.empty() && requeue.size() <= (size_t(1) << 16) && int64_t(requeue.size()) < db->nseq &&
-      qlen <= 64 * swa_endpoints_rows_for(int(std::min<int64_t>(qlen, 1 << 20))) && !(wq && std::atoi(wq) == 0) &&
+      qlen < (int64_t(1) << 24) && !(wq && std::atoi(wq) == 0) &&
       std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1) < (int64_t(1) << 30) && db->goe < (int64_t(1) << 30) &&
       db->ge < (int64_t(1) << 30)) {
     HIP_TRY(db->rq_ids.reserve(requeue.size()));
     HIP_TRY(hipMemcpyAsync(db->rq_ids.p, requeue.data(), requeue.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const bool passes = qlen > 64 * swa_endpoints_rows_for(int(qlen));      // queries of more than 2 048 rows: hand-over per column
+    std::vector<int64_t> boff;
+    if (passes) {
+      boff.resize(requeue.size());
+      int64_t total = 0;
+      for (size_t i = 0; i < requeue.size(); ++i) {
+        boff[i] = total;
+        total += db->h_offsets[size_t(requeue[i]) + 1] - db->h_offsets[size_t(requeue[i])];
+      }
+      HIP_TRY(db->rq_bh.reserve(size_t(total) + 1));
+      HIP_TRY(db->rq_bf.reserve(size_t(total) + 1));
+      HIP_TRY(db->rq_boff.reserve(requeue.size()));
+      HIP_TRY(hipMemcpyAsync(db->rq_boff.p, boff.data(), boff.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(swa_launch_endpoints_wave(db->residues.p, db->offsets.p, db->rq_ids.p, nullptr, int(requeue.size()), qdev, int(qlen),
-                                      db->matrix.p, int(db->goe), int(db->ge), nullptr, nullptr, nullptr, nullptr, scores, st));
+                                      db->matrix.p, int(db->goe), int(db->ge), passes ? db->rq_bh.p : nullptr,
+                                      passes ? db->rq_bf.p : nullptr, passes ? db->rq_boff.p : nullptr, nullptr, scores, st));
     HIP_TRY(hipStreamSynchronize(st));                 // the id list lives in the caller's vector
     *n32 += int64_t(requeue.size());
     requeue.clear();
@@ -800,11 +821,18 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     HIP_TRY(swa_launch_narrow(K, &p, persistent_blocks(db, p.nbatches), st));
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen > 16 * 58 && f16_limit(db, split_pass_rows(qlen)) >= 1024) {
-    rc = launch_split_passes(db, qlen, st);            // long query: passes of the tuned kernel
+    int np = 0, Kp = 0;                                // long query: passes of the tuned kernel, or of its bound build
+    split_pass_shape(qlen, &np, &Kp, 47);
+    const int Nb = swa_bound_period();
+    const char* be = std::getenv("SWA_BOUND");
+    const int bmode = be ? std::atoi(be) : -1;
+    used_bound = bound_min > 0 && bmode != 0 && f16_limit(db, Kp + Nb) >= 1024 &&
+                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge));
+    rc = launch_split_passes(db, qlen, st, used_bound, bound_min);
     if (rc != SWA_OK) return rc;
-    const int Kp = split_pass_rows(qlen);
+    if (!used_bound) Kp = split_pass_rows(qlen);
     c.narrow_rows = Kp;
-    c.narrow_shifted = 5;
+    c.narrow_shifted = used_bound ? 9 : 5;
     c.narrow = db->nseq;
   } else if (f16 && f16_limit(db, mp_rows_for(0, qlen)) >= 1024) {
     MpRun r;                                           // multi-pass pair kernel (short passes: large gap-extension penalties)

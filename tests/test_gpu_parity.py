@@ -173,13 +173,13 @@ def _expected_topk(scores, keep, minscore, maxscore=1 << 62):
 @pytest.mark.parametrize("lanes", [16, 8, 4])
 def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     """top-K searches may run the bound build of the row-shifted kernel (6.5 instructions per cell pair, result at most
-    15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (50)
+    15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (54)
     of every chain length, hits planted at every distance from the threshold, thresholds from "everything comes back"
     to "nothing does", gap extension penalties 1..3 - hit list, totalhits and obvious must equal the exact ones"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     monkeypatch.setenv("SWA_BOUND", "1")
     rtab = synth.residue_table_protein()
-    full = synth._random_residues(99, 1, 800, rtab)
+    full = synth._random_residues(99, 1, 870, rtab)
     rng = np.random.default_rng(lanes)
     res, off = swipe_amd.synth_db(6, 1500, query=full)
     seqs = [res[off[i]:off[i + 1]] for i in range(1500)]
@@ -194,7 +194,7 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
     n = 0
-    for K in range(25, (50 if lanes == 16 else 48) + 1):
+    for K in range(25, (54 if lanes == 16 else 48) + 1):
         go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         q = full[:lanes * K - (K % lanes)]
@@ -211,11 +211,47 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db.close()
 
 
+def test_bound_build_of_the_passes_of_long_queries(monkeypatch):
+    """top-K searches of queries longer than 928 rows: passes of the bound build, 16 x K rows with K = 30..47, the hand-over
+    stored without the step bias and re-biased on arrival; every K with two passes, then up to seven passes, hits that
+    straddle the pass boundaries, several runs of batches - hit list, totalhits, obvious equal to the exact ones"""
+    monkeypatch.setenv("SWA_BOUND", "1")
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(1234, 1, 5200, rtab)
+    res, off = swipe_amd.synth_db(9, 600, query=full[:1200])
+    base = [res[off[i]:off[i + 1]] for i in range(600)]
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    rng = np.random.default_rng(3)
+    lens = [32 * K for K in range(30, 48)] + [929, 1505, 48 * 40, 2256, 2257, 5200]
+    for n, qlen in enumerate(lens):
+        monkeypatch.setenv("SWA_BOUNDARY_MB", "1" if n % 3 == 0 else "4096")
+        q = full[:qlen]
+        npass = -(-qlen // (16 * 47))
+        K = max(30, -(-qlen // (16 * npass)))
+        edge = 16 * K
+        planted = [q, q[edge - 120:edge + 130].copy(), q[:300].copy(), q[qlen - 320:].copy(), q[edge - 12:edge + 12].copy(),
+                   q[edge * (npass - 1) - 200:edge * (npass - 1) + 60].copy(), np.concatenate([base[0], q[edge - 40:edge + 30], base[1]]),
+                   q[100:qlen - 100:2].copy(), np.zeros(0, np.uint8)]
+        for k in range(40):                                # short pieces: scores around every threshold
+            a = int(rng.integers(0, qlen - 100))
+            planted.append(np.concatenate([base[k][:30], q[a:a + int(rng.integers(8, 70))], base[k + 1][:30]]))
+        r2, o2 = oracle.pack(base + planted)
+        go, ge = ((11, 1), (10, 2))[n % 2]
+        db = swipe_amd.Database.from_arrays(r2, o2)
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
+        want = oracle.search_all63(r2, o2, q, Mo, go + ge, ge, threads=THREADS)
+        for minscore, maxscore in ((1, 1 << 62), (45, 200), (90, 1 << 62), (700, 1 << 62)):
+            hits, tot, obv, c = db.search_topk(q, keep=40, minscore=minscore, maxscore=maxscore)
+            assert c["narrow_shifted"] == 9 and c["narrow_rows"] == K, (qlen, c)
+            assert (hits, tot, obv) == _expected_topk(want, 40, minscore, maxscore), (qlen, minscore)
+        db.close()
+
+
 @pytest.mark.parametrize("wave", ["0", "1"])
-@pytest.mark.parametrize("qlen", [600, 1300, 2048, 2500])
+@pytest.mark.parametrize("qlen", [600, 1300, 2048, 2049, 4500])
 def test_requeue_by_batches_and_by_wave(qlen, wave, monkeypatch):
-    """sequences that leave the packed range are recomputed in 32 bits: a short list by one wave per sequence (queries up
-    to 2 048 rows), otherwise by the batch kernel (SWA_WAVE_REQUEUE=0 forces it) - same scores"""
+    """sequences that leave the packed range are recomputed in 32 bits: a short list by one wave per sequence (in passes of
+    2 048 rows), otherwise by the batch kernel (SWA_WAVE_REQUEUE=0 forces it) - same scores"""
     monkeypatch.setenv("SWA_WAVE_REQUEUE", wave)
     rtab = synth.residue_table_protein()
     q = synth._random_residues(808 + qlen, 1, qlen, rtab)

@@ -5,13 +5,14 @@ sys.path.insert(0, '.')
 import swipe_amd
 from swipe_amd import synth
 rtab = synth.residue_table_protein()
-full = synth._random_residues(7, 1, 900, rtab)
+full = synth._random_residues(7, 1, 1000, rtab)
 res, off = swipe_amd.synth_db(1, 2_000_000)
 db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
-for G in (4, 8, 16):
+want = [int(x) for x in sys.argv[1:]]            # optional: G K0 K1
+for G in ((want[0],) if want else (4, 8, 16)):
     os.environ["SWA_LANES"] = str(G)
-    for K in range(25, (50 if G == 16 else 48) + 1):
+    for K in range(want[1] if want else 25, (want[2] if want else (58 if G == 16 else 48)) + 1):
         q = full[:G * K]
         out, ref = [], None
         for mode in ("0", "1"):
