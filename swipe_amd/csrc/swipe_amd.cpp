@@ -1463,10 +1463,10 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
   for (int i = 0; i < nq;) {
     swa_counters_t c{};
     bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
-    int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c) : run_search(db, queries[i], qlens[i], &c);
+    int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c) : run_search(db, queries[i], qlens[i], &c, minscore);
     if (pair && rc == SWA_ERANGE) {          // scores beyond 32 bits in the second half: one frame at a time
       pair = false;
-      rc = run_search(db, queries[i], qlens[i], &c);
+      rc = run_search(db, queries[i], qlens[i], &c, minscore);
     }
     if (rc != SWA_OK) return rc;
     if (db->nseq) {

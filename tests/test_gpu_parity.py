@@ -211,6 +211,26 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db.close()
 
 
+def test_bound_build_under_a_translated_search(monkeypatch):
+    """tblastn: a protein query against a nucleotide shard held as its six translations goes through swa_search_frames_topk
+    - same frame-tagged hits with the bound build as with the exact first pass"""
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(3, 3000, protein=False)
+    db = swipe_amd.Database.from_arrays(res, off, translate_gencode=1)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SWA_BOUND", mode)
+        for minscore in (30, 45, 70):
+            hits, tot, obv, c = db.search_frames_topk([q], keep=100, minscore=minscore)
+            assert c["narrow_shifted"] == (8 if mode == "1" else 2)
+            out[(mode, minscore)] = (hits, tot, obv)
+    for minscore in (30, 45, 70):
+        assert out[("0", minscore)] == out[("1", minscore)] and out[("0", minscore)][1] > 0 or minscore == 70
+        assert out[("0", minscore)] == out[("1", minscore)]
+    db.close()
+
+
 def test_bound_build_of_the_passes_of_long_queries(monkeypatch):
     """top-K searches of queries longer than 928 rows: passes of the bound build, 16 x K rows with K = 30..47, the hand-over
     stored without the step bias and re-biased on arrival; every K with two passes, then up to seven passes, hits that
