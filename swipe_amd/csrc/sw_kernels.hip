@@ -648,7 +648,8 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
 // LDS.  Queries longer than 64*K rows take several passes; the bottom row of a pass is handed over through
 // bh/bf (one int pair per column, in place: lane 63 writes column t - 63 long after lane 0 read it).
 // Ties as search16s.cc:391-405: among the cells holding the maximum, the smallest column, then the smallest row.
-template <int K>
+// POS = false: the score only (re-queue use) - no position bookkeeping in the inner loop
+template <int K, bool POS = true>
 __global__ void __launch_bounds__(64)
 swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
                           const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
@@ -713,7 +714,11 @@ swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* _
           int e = ee[k];
           int h = hd + (qs[k] >= 0 ? mrow[qs[k]] : -1);
           h = max(max(h, f), max(e, 0));
-          if (qs[k] >= 0 && h > pbest) { pbest = h; pcol = c; prow = row0 + g * K + k; }
+          if constexpr (POS) {
+            if (qs[k] >= 0 && h > pbest) { pbest = h; pcol = c; prow = row0 + g * K + k; }
+          } else {
+            pbest = max(pbest, qs[k] >= 0 ? h : 0);
+          }
           hp[k] = h;
           const int tt = h - Q;
           e = max(e - R, tt);
@@ -949,19 +954,30 @@ extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_
 }
 // wave-per-sequence end points; bh/bf/boff may be null when qlen <= 64 * rows-per-lane(qlen) (single pass).
 // scores != null: re-queue use - only scores[ids[i]] is written (out may be null)
-extern "C" int swa_endpoints_rows_for(int qlen) { return qlen <= 256 ? 4 : qlen <= 512 ? 8 : qlen <= 1024 ? 16 : 32; }
+extern "C" int swa_endpoints_rows_for(int qlen)
+{
+  static const int rows[] = {2, 4, 6, 8, 12, 16, 24, 32};
+  for (int r : rows) if (qlen <= 64 * r) return r;
+  return 32;
+}
 extern "C" hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
                                                 const uint8_t* minus, int n, const uint8_t* qseq, int qlen,
                                                 const int32_t* matrix, int Q, int R, int* bh, int* bf,
                                                 const int64_t* boff, long long* out, int* scores, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-#define SWA_EPW(KK) hipLaunchKernelGGL(swa_endpoints_wave_kernel<KK>, dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
-                                       qseq, qlen, matrix, Q, R, bh, bf, boff, out, out ? out + n : out, out ? out + 2 * (size_t)n : out, scores)
+#define SWA_EPW(KK) { if (scores) hipLaunchKernelGGL((swa_endpoints_wave_kernel<KK, false>), dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
+                                       qseq, qlen, matrix, Q, R, bh, bf, boff, out, out, out, scores); \
+                      else hipLaunchKernelGGL((swa_endpoints_wave_kernel<KK, true>), dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
+                                       qseq, qlen, matrix, Q, R, bh, bf, boff, out, out + n, out + 2 * (size_t)n, scores); }
   switch (swa_endpoints_rows_for(qlen)) {
+    case 2: SWA_EPW(2); break;
     case 4: SWA_EPW(4); break;
+    case 6: SWA_EPW(6); break;
     case 8: SWA_EPW(8); break;
+    case 12: SWA_EPW(12); break;
     case 16: SWA_EPW(16); break;
+    case 24: SWA_EPW(24); break;
     default: SWA_EPW(32); break;
   }
 #undef SWA_EPW
