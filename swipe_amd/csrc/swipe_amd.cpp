@@ -546,7 +546,7 @@ void dual_pass_shape(int64_t qlen, int nres, int* npass, int* K)
   const int kmax = nres == 16 ? 56 : 32;
   const int64_t np = (qlen + 16 * kmax - 1) / (16 * kmax);
   *npass = int(np);
-  *K = int(std::max<int64_t>(nres == 16 ? 31 : 17, (qlen + 16 * np - 1) / (16 * np)));
+  *K = int(std::max<int64_t>(nres == 16 ? 32 : 17, (qlen + 16 * np - 1) / (16 * np)));
 }
 int dual_pass_rows(int64_t qlen, int nres)
 {
@@ -898,7 +898,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (rc != SWA_OK) return rc;
   std::vector<int32_t> rq1, rq2;
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  // single pass with the whole query in registers when it fits (nucleotide alphabets: 976 rows, others 512);
+  // single pass with the whole query in registers when it fits (nucleotide alphabets: 1008 rows, others 512);
   // SWA_DUAL_MP=1 forces the multi-pass kernel (A/B, tests)
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
   const bool dual_mp = std::getenv("SWA_DUAL_MP") && std::atoi(std::getenv("SWA_DUAL_MP")) == 1;

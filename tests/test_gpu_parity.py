@@ -490,7 +490,7 @@ def test_dual_query_kernel_both_strands(qlen):
 @pytest.mark.parametrize("lanes", [16, 8, 4, 2])
 @pytest.mark.parametrize("protein", [False, True])
 def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monkeypatch):
-    """two queries of equal length in one pass, K = ceil(qlen / lanes): every K of the nucleotide build (1..61 with
+    """two queries of equal length in one pass, K = ceil(qlen / lanes): every K of the nucleotide build (1..63 with
     16-lane chains, 1..32 with 8 / 4) and of the protein build (1..32), and the multi-pass kernel as cross-check"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     tab = synth.residue_table_protein() if protein else synth.residue_table_nucleotide()
@@ -507,7 +507,7 @@ def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monk
     else:
         db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
         Mo, goe, ge = oracle.matrix_nucleotide(1, -3), 7, 2
-    for K in range(1, (32 if (protein or lanes < 16) else 61) + 1):
+    for K in range(1, (32 if (protein or lanes < 16) else 63) + 1):
         qlen = lanes * K - (K % lanes)
         q1 = full[:qlen]
         q2 = q1[::-1].copy() if protein else blastdb.revcomp_nt16(q1)
@@ -600,8 +600,8 @@ def test_multipass_pair_kernel_rows_per_lane(monkeypatch, K):
 
 @pytest.mark.parametrize("protein", [False, True])
 def test_every_pass_build_of_the_dual_kernel(protein, monkeypatch):
-    """two queries longer than one pass of the dual kernel (976 rows for nucleotides, 512 otherwise): passes of 16 x K rows,
-    K = 31..56 (nucleotide) / 17..32, one launch per pass; every K with two passes, then more passes; sequences that straddle
+    """two queries longer than one pass of the dual kernel (1008 rows for nucleotides, 512 otherwise): passes of 16 x K rows,
+    K = 32..56 (nucleotide) / 17..32, one launch per pass; every K with two passes, then more passes; sequences that straddle
     the pass boundaries and ones that overflow in one query only; SWA_BOUNDARY_MB = 1 cuts the batches into several runs"""
     tab = synth.residue_table_protein() if protein else synth.residue_table_nucleotide()
     full = synth._random_residues(321, 1, 4200, tab)
@@ -610,7 +610,7 @@ def test_every_pass_build_of_the_dual_kernel(protein, monkeypatch):
     if protein:
         Mo, goe, ge, kmax, kmin = oracle.matrix_builtin("BLOSUM62"), 12, 1, 32, 17
     else:
-        Mo, goe, ge, kmax, kmin = oracle.matrix_nucleotide(1, -3), 7, 2, 56, 31
+        Mo, goe, ge, kmax, kmin = oracle.matrix_nucleotide(1, -3), 7, 2, 56, 32
     lens = [32 * K for K in range(kmin, kmax + 1)] + [32 * kmax + 1, 48 * (kmax - 3), 64 * kmax + 7, 4200]
     for n, qlen in enumerate(lens):
         monkeypatch.setenv("SWA_BOUNDARY_MB", "1" if n % 3 == 0 else "4096")

@@ -12,7 +12,7 @@ db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
 for qlen in map(int, sys.argv[1:]):
     q = full[:qlen]; qm = blastdb.revcomp_nt16(q)
     out = []
-    for kmax in ("63", "56"):
+    for kmax in ("63", "61", "56"):
         os.environ["SWA_DUAL_KMAX"] = kmax
         db.search2(q, qm, want_scores=False)
         best, c = 1e9, None
