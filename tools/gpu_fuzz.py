@@ -42,6 +42,21 @@ for it in range(n):
     want2 = oracle.search_all63(r2, o2, q2, Mo, go + ge, ge, threads=T)
     g1, g2, c2 = db.search2(q, q2)
     ok2 = np.array_equal(g1, want) and np.array_equal(g2, want2)
+    # top-K searches: random threshold and cap, automatic choice of the first pass and the bound build forced
+    ok4, forms = True, []
+    for force in (None, "1"):
+        if force: os.environ["SWA_BOUND"] = force
+        else: os.environ.pop("SWA_BOUND", None)
+        lo = int(rng.choice([1, rng.integers(1, 60), rng.integers(60, 200), max(1, int(want.max()) - int(rng.integers(0, 40)))]))
+        hi = int(rng.choice([1 << 62, lo + int(rng.integers(0, 300))]))
+        keep = int(rng.integers(1, 300))
+        hits, tot, obv, ck = db.search_topk(q, keep=keep, minscore=lo, maxscore=hi)
+        order = sorted((i for i in range(len(want)) if want[i] >= lo), key=lambda i: (-int(want[i]), -i))
+        exp = [(i, int(want[i])) for i in order if want[i] <= hi][:keep]
+        ok4 = ok4 and hits == exp and tot == len(order) and obv == int((want > hi).sum())
+        forms.append(ck["narrow_shifted"])
+    os.environ.pop("SWA_BOUND", None)
+    ok = ok and ok4
     inc = (rng.random(len(seqs)) < 0.6).astype(np.uint8)
     db.set_inclusion(inc)
     g3, _ = db.search(q)
@@ -51,5 +66,5 @@ for it in range(n):
         bad += 1
     print("%3d %s %-9s go=%2d ge=%d qlen=%4d nseq=%4d max=%6d narrow_rows=%2d shifted=%d wide=%d full=%d : %s %s %s" % (
         it, "aa" if protein else "nt", m, go, ge, qlen, len(seqs), int(want.max()), c["narrow_rows"], c["narrow_shifted"], c["wide"], c["full"],
-        "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH2", "ok" if ok3 else "MISMATCH3"), flush=True)
+        "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH2", "ok" if ok3 else "MISMATCH3"), "topk forms", forms, flush=True)
 print("fuzz done:", n, "configs,", bad, "bad")
