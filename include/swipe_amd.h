@@ -90,7 +90,8 @@ typedef struct {
                             6: two-query kernel, one launch per pass (queries > 1008 nucleotide / 512 other rows);
                             7: row-shifted form with 2 lanes per sequence pair (queries of at most 40 rows);
                             8: bound build of the row-shifted form (swa_search_topk only, see there);
-                            9: bound build, one launch per pass (queries > 928 rows) */
+                            9: bound build, one launch per pass (queries > 928 rows);
+                            10: bound build of the two-query kernel (non-nucleotide pairs of 129..512 rows) */
 } swa_counters_t;
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;

@@ -29,6 +29,8 @@ int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
+hipError_t swa_launch_dual_bound(int G, int K, const swa_mp_params* p, int cus, hipStream_t st);
+int swa_dual_bound_available(int G, int K, int nres);
 hipError_t swa_launch_narrow_bound_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -876,7 +878,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
 // Two queries of equal length against every sequence in one pass (nucleotide plus/minus strand).
 // Scores of query 1 end up in db->scores, of query 2 in db->scores2 (64-bit values in scores64
 // would collide between the two, so the 64-bit hop is only taken for query 1 - see below).
-int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, swa_counters_t* counters)
+int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, swa_counters_t* counters, int64_t bound_min = 0)
 {
   int rc = check_query(db, q1, qlen);
   if (rc == SWA_OK) rc = check_query(db, q2, qlen);
@@ -936,14 +938,30 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     p.negR = f16_pair(-float(db->ge));
     p.negKR = f16_pair(-float(int64_t(Kd) * db->ge));
     for (int i = 0; i <= Kd + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
-    HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
+    // bound build (sw_cb_dual.hip) under the same rule as in run_search
+    const int Nb = swa_bound_period();
+    const char* be = std::getenv("SWA_BOUND");
+    const int bmode = be ? std::atoi(be) : -1;
+    const bool used_bound = bound_min > 0 && bmode != 0 && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024 &&
+                            (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge));
+    if (used_bound) {
+      p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
+      for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
+      HIP_TRY(swa_launch_dual_bound(Gd, Kd, &p, db->cus, st));
+    } else {
+      HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
+    }
     c.narrow_rows = Kd;
-    c.narrow_shifted = 4;                                // single-pass dual kernel
+    c.narrow_shifted = used_bound ? 10 : 4;              // single-pass dual kernel / its bound build
     c.narrow = db->nseq;
     HIP_TRY(hipEventRecord(db->ev[2], st));
     rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
     if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
     if (rc != SWA_OK) return rc;
+    if (used_bound && int64_t(rq1.size() + rq2.size()) * 50 > 2 * db->nseq && bmode != 1) {
+      db->bound_off = true;
+      return run_search2(db, q1, q2, qlen, counters, 0);
+    }
   } else if (f16_applicable(db) && !dual_mp && Gd == 16 && f16_limit(db, dual_pass_rows(qlen, nres)) >= 1024) {
     rc = launch_dual_passes(db, qlen, nres, st);         // long queries: one launch per pass of the same kernel
     if (rc != SWA_OK) return rc;
@@ -1427,7 +1445,7 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
 {
   if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
-  int rc = run_search2(db, query1, query2, qlen, counters);
+  int rc = run_search2(db, query1, query2, qlen, counters, minscore);
   if (rc != SWA_OK) return rc;
   *nhits = 0;
   int64_t tot = 0, obv = 0;
@@ -1463,7 +1481,7 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
   for (int i = 0; i < nq;) {
     swa_counters_t c{};
     bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
-    int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c) : run_search(db, queries[i], qlens[i], &c, minscore);
+    int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c, minscore) : run_search(db, queries[i], qlens[i], &c, minscore);
     if (pair && rc == SWA_ERANGE) {          // scores beyond 32 bits in the second half: one frame at a time
       pair = false;
       rc = run_search(db, queries[i], qlens[i], &c, minscore);

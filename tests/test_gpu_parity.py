@@ -231,6 +231,48 @@ def test_bound_build_under_a_translated_search(monkeypatch):
     db.close()
 
 
+@pytest.mark.parametrize("lanes", [16, 8])
+def test_bound_build_of_the_two_query_kernel(lanes, monkeypatch):
+    """pairs of protein queries (frames of a translated search) with a score threshold: bound build of swa_dual_kernel,
+    K = 17..32 rows per lane for chains of 16 and 8 lanes - the merged hit list of both queries, totalhits and obvious
+    equal the exact ones for thresholds from "everything comes back" to "nothing does" """
+    monkeypatch.setenv("SWA_LANES", str(lanes))
+    monkeypatch.setenv("SWA_BOUND", "1")
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(4321, 1, 520, rtab)
+    rng = np.random.default_rng(lanes + 1)
+    res, off = swipe_amd.synth_db(16, 1200, query=full)
+    seqs = [res[off[i]:off[i + 1]] for i in range(1200)]
+    rev = full[::-1].copy()
+    for k in range(100):
+        src = full if k % 2 else rev
+        a = int(rng.integers(0, 430))
+        piece = src[a:a + int(rng.integers(8, 90))].copy()
+        mut = rng.random(len(piece)) < rng.random() * 0.4
+        piece[mut] = rtab[rng.integers(0, len(rtab), int(mut.sum()))]
+        seqs.append(np.concatenate([seqs[k][:int(rng.integers(0, 50))], piece, seqs[k + 1][:int(rng.integers(0, 50))]]))
+    seqs += [full, rev, np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    for K in range(17, 33):
+        go, ge = ((11, 1), (10, 2))[K % 2]
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
+        qlen = lanes * K - (K % lanes)
+        q1 = full[:qlen]
+        q2 = rev[:qlen].copy()
+        w1 = oracle.search_all63(r2, o2, q1, Mo, go + ge, ge, threads=THREADS)
+        w2 = oracle.search_all63(r2, o2, q2, Mo, go + ge, ge, threads=THREADS)
+        for minscore, maxscore in ((1, 1 << 62), (40, 120), (70, 1 << 62), (500, 1 << 62)):
+            hits, tot, obv, c = db.search2_topk(q1, q2, keep=30, minscore=minscore, maxscore=maxscore)
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == 10, (K, c)
+            want = sorted([(int(s), i, 0) for i, s in enumerate(w1) if minscore <= s <= maxscore] +
+                          [(int(s), i, 1) for i, s in enumerate(w2) if minscore <= s <= maxscore], key=lambda t: (-t[0], -t[1], t[2]))[:30]
+            assert hits == [(i, s, w) for s, i, w in want], (K, minscore)
+            assert tot == int((w1 >= minscore).sum() + (w2 >= minscore).sum()) and obv == int((w1 > maxscore).sum() + (w2 > maxscore).sum())
+    db.close()
+
+
 def test_bound_build_of_the_passes_of_long_queries(monkeypatch):
     """top-K searches of queries longer than 928 rows: passes of the bound build, 16 x K rows with K = 30..47, the hand-over
     stored without the step bias and re-biased on arrival; every K with two passes, then up to seven passes, hits that
@@ -728,6 +770,11 @@ def test_cli_alignment_output_equals_reference_cli(tmp_path, name):
     run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
     assert run(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]
     assert run(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
+    # the same with the bound build of the first pass forced wherever a build exists for the query
+    forced = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True,
+                                          env=dict(os.environ, SWA_BOUND="1")).stdout
+    assert forced(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]
+    assert forced(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
     t9 = run(["-m", "9", "-b", str(case.keep)]).split("\n")[1:]
     want = g["tsv9"].split("\n")
     assert t9[0] == want[0] and t9[1].startswith("# Database: ") and t9[2:] == want[2:]
