@@ -99,7 +99,7 @@ swa_dual_bound_kernel(swa_mp_params p)
             const h2 t = h + negQR;                                                            \
             const h2 hold = H[r];                                                              \
             if (r + 1 < K) a = hold + as_h2(w1);                                               \
-            if ((U) & 1) SR[r] = (U) == 1 ? pk_max(hold, h) : pk_max3(SR[r], hold, h);         \
+            if ((U) & 1) SR[r] = pk_max3(SR[r], hold, h);                                             \
             H[r] = h;                                                                          \
             F = pk_max(F, t);                                                                  \
             E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2 + (U)]));                               \
@@ -127,16 +127,17 @@ swa_dual_bound_kernel(swa_mp_params p)
           if constexpr (G >= 16) { SWA_DB_PAIR(blk * G + 8) SWA_DB_PAIR(blk * G + 10) SWA_DB_PAIR(blk * G + 12) SWA_DB_PAIR(blk * G + 14) }
         }
       }
-#pragma unroll
-      for (int r = 0; r < K; r += 2) {
-        if (r + 1 < K) S = pk_max3(S, SR[r] - as_h2(p.rowc[r + 1]), SR[r + 1] - as_h2(p.rowc[r + 2]));
-        else S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
-      }
+      // end of the period: bring the state back by N R; the row maxima carry on and are folded after the last step
 #pragma unroll
       for (int r = 0; r < K; ++r) { H[r] = H[r] + negNR; E[r] = E[r] + negNR; }
       diag = diag + negNR;
       hsend = hsend + negNR;
       fsend = fsend + negNR;
+    }
+#pragma unroll
+    for (int r = 0; r < K; r += 2) {
+      if (r + 1 < K) S = pk_max3(S, SR[r] - as_h2(p.rowc[r + 1]), SR[r + 1] - as_h2(p.rowc[r + 2]));
+      else S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
     }
 #undef SWA_DB_PAIR
 #undef SWA_DB_STEP
