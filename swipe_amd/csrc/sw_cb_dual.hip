@@ -1,7 +1,7 @@
 // Bound build of the two-query kernel (swa_dual_kernel, sw_mp_kernel.inc) for the non-nucleotide alphabets: the
 // column-biased recurrence of sw_cb_kernel.inc - every value of step u of a 16-step period stored + u R, so that the
 // horizontal gap state needs no "- R" - on one database sequence per chain against TWO queries in the two f16 halves:
-// 5.5 instead of 6.5 instructions per cell pair.  As there, the result is an upper bound at most 15 R above the score
+// 5 instead of 6.5 instructions per cell pair (no row maxima either: the bound is read off E at each period's end).  As there, the result is an upper bound at most 15 R above the score
 // and only serves searches with a score threshold (swa_search2_topk, swa_search_frames_topk: pairs of equally long
 // query frames of a translated search); sequences whose bound reaches the threshold are recomputed exactly.
 // Nucleotide searches have thresholds of 20..30 at R = 2 - inside the slack - and keep the exact kernel.
@@ -67,9 +67,9 @@ swa_dual_bound_kernel(swa_mp_params p)
     const int total = steps + G;
     const int shift = 8 * half;
 
-    h2 H[K], E[K], SR[K];
+    h2 H[K], E[K];
 #pragma unroll
-    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r]); E[r] = as_h2(p.rowc[r + 1]); SR[r] = zero; }
+    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r]); E[r] = as_h2(p.rowc[r + 1]); }
     h2 diag = zero - as_h2(p.rowc[1]), hsend = zero, fsend = zero;
     h2 S = zero;
     u32 cur = PADOFF;
@@ -99,7 +99,6 @@ swa_dual_bound_kernel(swa_mp_params p)
             const h2 t = h + negQR;                                                            \
             const h2 hold = H[r];                                                              \
             if (r + 1 < K) a = hold + as_h2(w1);                                               \
-            if ((U) & 1) SR[r] = pk_max3(SR[r], hold, h);                                             \
             H[r] = h;                                                                          \
             F = pk_max(F, t);                                                                  \
             E[r] = pk_max3(E[r], t, as_h2(p.rowc[r + 2 + (U)]));                               \
@@ -129,16 +128,17 @@ swa_dual_bound_kernel(swa_mp_params p)
       }
       // end of the period: bring the state back by N R; the row maxima carry on and are folded after the last step
 #pragma unroll
+      for (int r = 0; r < K; r += 2) {
+        if (r + 1 < K) S = pk_max3(S, E[r] - as_h2(p.rowc[r + 1]), E[r + 1] - as_h2(p.rowc[r + 2]));
+        else S = pk_max(S, E[r] - as_h2(p.rowc[r + 1]));
+      }
+#pragma unroll
       for (int r = 0; r < K; ++r) { H[r] = H[r] + negNR; E[r] = E[r] + negNR; }
       diag = diag + negNR;
       hsend = hsend + negNR;
       fsend = fsend + negNR;
     }
-#pragma unroll
-    for (int r = 0; r < K; r += 2) {
-      if (r + 1 < K) S = pk_max3(S, SR[r] - as_h2(p.rowc[r + 1]), SR[r + 1] - as_h2(p.rowc[r + 2]));
-      else S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
-    }
+    S = S - negQR;                                      // the bound was kept on H - Q (see above)
 #undef SWA_DB_PAIR
 #undef SWA_DB_STEP
 

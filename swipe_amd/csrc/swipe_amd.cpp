@@ -794,7 +794,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     const char* be = std::getenv("SWA_BOUND");
     const int bmode = be ? std::atoi(be) : -1;
     used_bound = bound_min > 0 && bmode != 0 && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024 &&
-                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge));
+                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
     if (used_bound) {
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
@@ -829,7 +829,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     const char* be = std::getenv("SWA_BOUND");
     const int bmode = be ? std::atoi(be) : -1;
     used_bound = bound_min > 0 && bmode != 0 && f16_limit(db, Kp + Nb) >= 1024 &&
-                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge));
+                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
     rc = launch_split_passes(db, qlen, st, used_bound, bound_min);
     if (rc != SWA_OK) return rc;
     if (!used_bound) Kp = split_pass_rows(qlen);
@@ -943,7 +943,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     const char* be = std::getenv("SWA_BOUND");
     const int bmode = be ? std::atoi(be) : -1;
     const bool used_bound = bound_min > 0 && bmode != 0 && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024 &&
-                            (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge));
+                            (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
     if (used_bound) {
       p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
       for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
