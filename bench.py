@@ -208,7 +208,7 @@ def main():
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
-        OPS = {0: 8.5, 1: 7.5, 2: 7.5, 3: 7.5, 7: 7.5, 8: 6.5}        # VALU instructions per cell pair of each form
+        OPS = {0: 8.5, 1: 7.5, 2: 7.5, 3: 7.5, 7: 7.5, 8: 6.0}        # VALU instructions per cell pair of each form
         out = {
             "metric": "GCUPS, 375-aa query vs 10M-seq protein db at 1/2/4/8 GPUs; bit-exact scores",
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

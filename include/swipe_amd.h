@@ -179,7 +179,7 @@ SWA_API int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* 
    minscore <= score <= maxscore; *totalhits counts scores >= minscore, *obvious counts scores
    > maxscore (hits.cc:174-178).  hits[] receives *nhits entries, already ordered.
    Only scores >= minscore are observable here, so when minscore is well above the spread of unrelated
-   sequences the first pass may be the BOUND build of the kernel (6.5 instead of 7.5 instructions per
+   sequences the first pass may be the BOUND build of the kernel (6 instead of 7.5 instructions per
    cell pair; it yields an upper bound at most 15 x gapextend above the score) and every sequence whose
    bound reaches minscore is recomputed exactly before the list is made: hits, *totalhits and *obvious
    are identical to the exact pass's (counters.narrow_shifted = 8; SWA_BOUND=0 in the environment

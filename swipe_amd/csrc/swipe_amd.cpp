@@ -481,7 +481,7 @@ int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
 // (13 GB for a 10 M-sequence protein database: HBM is the one thing this box has to spare, and at 26 GB of extra
 // traffic per pass boundary it costs 3 ms of a 130 ms pass).  The buffer is capped (64 GB or a quarter of the free memory); batches are taken in runs
 // that fit it, all passes of a run before the next run.
-void split_pass_shape(int64_t qlen, int* npass, int* K, int kmax = 56)   // 57+ rows of a pass build spill (bound build: 48+)
+void split_pass_shape(int64_t qlen, int* npass, int* K, int kmax = 56)   // 57+ rows of a pass build spill
 {
   const int64_t np = (qlen + 16 * kmax - 1) / (16 * kmax);
   *npass = int(np);
@@ -495,11 +495,11 @@ int split_pass_rows(int64_t qlen)
   return K;
 }
 
-// bound: the passes are bound builds (top-K searches, see run_search) of at most 47 rows per lane
+// bound: the passes are bound builds (top-K searches, see run_search)
 int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st, bool bound, int64_t bound_min)
 {
   int npass = 0, K = 0;
-  split_pass_shape(qlen, &npass, &K, bound ? 47 : 56);
+  split_pass_shape(qlen, &npass, &K);
   const int Nb = bound ? swa_bound_period() : 0;
   const BatchSet& bs = db->main;
   swa_narrow_params p{};
@@ -824,7 +824,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen > 16 * 58 && f16_limit(db, split_pass_rows(qlen)) >= 1024) {
     int np = 0, Kp = 0;                                // long query: passes of the tuned kernel, or of its bound build
-    split_pass_shape(qlen, &np, &Kp, 47);
+    split_pass_shape(qlen, &np, &Kp);
     const int Nb = swa_bound_period();
     const char* be = std::getenv("SWA_BOUND");
     const int bmode = be ? std::atoi(be) : -1;
@@ -832,7 +832,6 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
                  (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
     rc = launch_split_passes(db, qlen, st, used_bound, bound_min);
     if (rc != SWA_OK) return rc;
-    if (!used_bound) Kp = split_pass_rows(qlen);
     c.narrow_rows = Kp;
     c.narrow_shifted = used_bound ? 9 : 5;
     c.narrow = db->nseq;

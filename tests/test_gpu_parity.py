@@ -173,13 +173,13 @@ def _expected_topk(scores, keep, minscore, maxscore=1 << 62):
 @pytest.mark.parametrize("lanes", [16, 8, 4])
 def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     """top-K searches may run the bound build of the row-shifted kernel (6.5 instructions per cell pair, result at most
-    15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (54)
+    15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (58)
     of every chain length, hits planted at every distance from the threshold, thresholds from "everything comes back"
     to "nothing does", gap extension penalties 1..3 - hit list, totalhits and obvious must equal the exact ones"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     monkeypatch.setenv("SWA_BOUND", "1")
     rtab = synth.residue_table_protein()
-    full = synth._random_residues(99, 1, 870, rtab)
+    full = synth._random_residues(99, 1, 930, rtab)
     rng = np.random.default_rng(lanes)
     res, off = swipe_amd.synth_db(6, 1500, query=full)
     seqs = [res[off[i]:off[i + 1]] for i in range(1500)]
@@ -194,7 +194,7 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
     n = 0
-    for K in range(25, (54 if lanes == 16 else 48) + 1):
+    for K in range(25, (58 if lanes == 16 else 48) + 1):
         go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         q = full[:lanes * K - (K % lanes)]
@@ -274,7 +274,7 @@ def test_bound_build_of_the_two_query_kernel(lanes, monkeypatch):
 
 
 def test_bound_build_of_the_passes_of_long_queries(monkeypatch):
-    """top-K searches of queries longer than 928 rows: passes of the bound build, 16 x K rows with K = 30..47, the hand-over
+    """top-K searches of queries longer than 928 rows: passes of the bound build, 16 x K rows with K = 30..56, the hand-over
     stored without the step bias and re-biased on arrival; every K with two passes, then up to seven passes, hits that
     straddle the pass boundaries, several runs of batches - hit list, totalhits, obvious equal to the exact ones"""
     monkeypatch.setenv("SWA_BOUND", "1")
@@ -284,11 +284,11 @@ def test_bound_build_of_the_passes_of_long_queries(monkeypatch):
     base = [res[off[i]:off[i + 1]] for i in range(600)]
     Mo = oracle.matrix_builtin("BLOSUM62")
     rng = np.random.default_rng(3)
-    lens = [32 * K for K in range(30, 48)] + [929, 1505, 48 * 40, 2256, 2257, 5200]
+    lens = [32 * K for K in range(30, 57)] + [929, 1793, 48 * 40, 2688, 2689, 5200]
     for n, qlen in enumerate(lens):
         monkeypatch.setenv("SWA_BOUNDARY_MB", "1" if n % 3 == 0 else "4096")
         q = full[:qlen]
-        npass = -(-qlen // (16 * 47))
+        npass = -(-qlen // (16 * 56))
         K = max(30, -(-qlen // (16 * npass)))
         edge = 16 * K
         planted = [q, q[edge - 120:edge + 130].copy(), q[:300].copy(), q[qlen - 320:].copy(), q[edge - 12:edge + 12].copy(),
