@@ -1,0 +1,13 @@
+// Bound builds of the row-shifted kernel for chains of 2 lanes (see sw_cb_kernel.inc).
+#include "sw_common.cuh"
+#include "sw_cb_kernel.inc"
+
+extern "C" hipError_t swa_launch_narrow_bound_g2(int K, const swa_narrow_params* p, int blocks, hipStream_t st)
+{
+#define SWA_CBK(KK) case KK: return launch_bound<KK, 2>(*p, blocks, st);
+  switch (K) {
+    SWA_CBK(5) SWA_CBK(6) SWA_CBK(7) SWA_CBK(8) SWA_CBK(9) SWA_CBK(10) SWA_CBK(11) SWA_CBK(12) SWA_CBK(13) SWA_CBK(14) SWA_CBK(15) SWA_CBK(16) SWA_CBK(17) SWA_CBK(18) SWA_CBK(19) SWA_CBK(20)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_CBK
+}

@@ -32,6 +32,7 @@ hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus
 hipError_t swa_launch_dual_bound(int G, int K, const swa_mp_params* p, int cus, hipStream_t st);
 int swa_dual_bound_available(int G, int K, int nres);
 hipError_t swa_launch_narrow_bound_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_bound_g2(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g16(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -799,7 +800,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
       c.narrow_shifted = 8;
-      HIP_TRY(G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
+      HIP_TRY(G == 2 ? swa_launch_narrow_bound_g2(K, &p, blocks, st) : G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
                      : swa_launch_narrow_bound_g16(K, &p, blocks, st));
     } else {
       HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));

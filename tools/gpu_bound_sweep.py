@@ -10,7 +10,7 @@ res, off = swipe_amd.synth_db(1, 2_000_000)
 db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
 want = [int(x) for x in sys.argv[1:]]            # optional: G K0 K1
-for G in ((want[0],) if want else (4, 8, 16)):
+for G in ((want[0],) if want else (2, 4, 8, 16)):
     os.environ["SWA_LANES"] = str(G)
     for K in range(want[1] if want else 25, (want[2] if want else (58 if G == 16 else 48)) + 1):
         q = full[:G * K]
