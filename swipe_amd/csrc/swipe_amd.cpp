@@ -754,6 +754,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   // rows per lane (SWA_LANES = 2 / 4 / 8 / 16 picks the chain length if the query fits it: A/B runs and tests)
   // (2 lanes: measured ahead of 4 up to 40 rows - 10 aa 4.5 -> 5.7, 30 aa 7.3 -> 7.9 TCUPS - and level or behind beyond)
   int G = qlen <= 40 ? 2 : qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
+  // Bound build (top-K searches, see below): wanted when the threshold is far enough above its slack.  It keeps two
+  // values per row instead of three, and with them 2-lane chains stay ahead of 4 lanes up to 96 rows (+2..8 %)
+  const int Nb = swa_bound_period();
+  const char* be = std::getenv("SWA_BOUND");
+  const int bmode = be ? std::atoi(be) : -1;           // 0 never, 1 whenever a build exists
+  const bool bound_wanted = bound_min > 0 && bmode != 0 &&
+      (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
+  if (bound_wanted && qlen <= 2 * 48) G = 2;
   if (const char* e = std::getenv("SWA_LANES")) {
     G = std::atoi(e) >= 16 ? 16 : std::atoi(e) >= 8 ? 8 : std::atoi(e) >= 4 ? 4 : 2;
     while (G < 16 && qlen > G * 48) G *= 2;
@@ -791,11 +799,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     // everything at or above bound_min is recomputed by the 32-bit kernel.  Used when the threshold is far enough above
     // that slack for the recomputed share to be negligible (SWA_BOUND = 0 never, 1 whenever a build exists); if more
     // than 2 % of the sequences come back it is switched off for this scoring system and the exact kernel runs
-    const int Nb = swa_bound_period();
-    const char* be = std::getenv("SWA_BOUND");
-    const int bmode = be ? std::atoi(be) : -1;
-    used_bound = bound_min > 0 && bmode != 0 && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024 &&
-                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
+    used_bound = bound_wanted && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
     if (used_bound) {
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
@@ -826,11 +830,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   } else if (f16 && !force_mp && qlen > 16 * 58 && f16_limit(db, split_pass_rows(qlen)) >= 1024) {
     int np = 0, Kp = 0;                                // long query: passes of the tuned kernel, or of its bound build
     split_pass_shape(qlen, &np, &Kp);
-    const int Nb = swa_bound_period();
-    const char* be = std::getenv("SWA_BOUND");
-    const int bmode = be ? std::atoi(be) : -1;
-    used_bound = bound_min > 0 && bmode != 0 && f16_limit(db, Kp + Nb) >= 1024 &&
-                 (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
+    used_bound = bound_wanted && f16_limit(db, Kp + Nb) >= 1024;
     rc = launch_split_passes(db, qlen, st, used_bound, bound_min);
     if (rc != SWA_OK) return rc;
     c.narrow_rows = Kp;

@@ -174,7 +174,7 @@ def _expected_topk(scores, keep, minscore, maxscore=1 << 62):
 def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     """top-K searches may run the bound build of the row-shifted kernel (6.5 instructions per cell pair, result at most
     15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (58)
-    of every chain length (4 lanes from 11, 2 lanes 5..20), hits planted at every distance from the threshold, thresholds from "everything comes back"
+    of every chain length (4 lanes from 11, 2 lanes from 5), hits planted at every distance from the threshold, thresholds from "everything comes back"
     to "nothing does", gap extension penalties 1..3 - hit list, totalhits and obvious must equal the exact ones"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     monkeypatch.setenv("SWA_BOUND", "1")
@@ -194,7 +194,7 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
     n = 0
-    for K in range({16: 25, 8: 25, 4: 11, 2: 5}[lanes], {16: 58, 8: 48, 4: 48, 2: 20}[lanes] + 1):
+    for K in range({16: 25, 8: 25, 4: 11, 2: 5}[lanes], {16: 58, 8: 48, 4: 48, 2: 48}[lanes] + 1):
         go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         q = full[:lanes * K - (K % lanes)]
