@@ -191,6 +191,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The same step with the exact first pass (every score of the shard exact on the device, what swa_search
+    # returns): reported beside the headline, and the two hit lists must be identical.  The headline step may run
+    # the bound build, which computes exact scores only for sequences that can reach the E <= 10 threshold -
+    # hits_enter drops every other score unseen (hits.cc:174-184).
+    exact = None
+    if "SWA_BOUND" not in os.environ and c["narrow_shifted"] in (8, 9):
+        os.environ["SWA_BOUND"] = "0"
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            hits_x, tot_x, c_x = step()
+        fence()
+        el_x = time.perf_counter() - t1
+        del os.environ["SWA_BOUND"]
+        if use_dist:
+            t = torch.tensor([el_x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_x = float(t.item())
+        exact = {"value": round(tot_sym * len(q) * 2 / el_x / 1e9, 1), "unit": "GCUPS", "steps": 2,
+                 "ms_per_step": round(el_x / 2 * 1e3, 3), "kernel_ms": round(float(c_x["kernel_ms"]), 3),
+                 "hits_identical": bool(hits_x == hits and tot_x == tot),
+                 "note": "same step with SWA_BOUND=0: all scores of the shard exact on the device (7.5 instructions "
+                         "per cell pair); the headline step recomputes exactly only what can reach the threshold"}
+        if not exact["hits_identical"]:
+            raise SystemExit("bench: the bound build and the exact first pass disagree on the hit list")
+
     if rank == 0:
         cells_per_step = tot_sym * len(q)
         value = cells_per_step * a.steps / elapsed / 1e9
@@ -238,6 +265,8 @@ def main():
                        "requeued_64bit": int(c["full"])},
             "setup_s": {"generate": round(t_gen, 2), "load_format": round(t_load, 2)},
         }
+        if exact:
+            out["exact_first_pass"] = exact
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(res, off, synth.QUERY_P07327, cores)
