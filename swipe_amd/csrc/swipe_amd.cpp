@@ -629,23 +629,27 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
   // query in a fraction of the batch kernel's 20 passes.  int32 is exact when
   // qlen x highest score stays below 2^30 (then nothing can reach the 64-bit hop either).
   const char* wq = std::getenv("SWA_WAVE_REQUEUE");
-  if (!requeue.empty() && requeue.size() <= (size_t(1) << 16) && int64_t(requeue.size()) < db->nseq &&
-      qlen < (int64_t(1) << 24) && !(wq && std::atoi(wq) == 0) &&
-      std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1) < (int64_t(1) << 30) && db->goe < (int64_t(1) << 30) &&
-      db->ge < (int64_t(1) << 30)) {
+  bool by_wave = !requeue.empty() && requeue.size() <= (size_t(1) << 16) && int64_t(requeue.size()) < db->nseq &&
+                 qlen < (int64_t(1) << 24) && !(wq && std::atoi(wq) == 0) &&
+                 std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1) < (int64_t(1) << 30) &&
+                 db->goe < (int64_t(1) << 30) && db->ge < (int64_t(1) << 30);
+  const bool passes = by_wave && qlen > 64 * swa_endpoints_rows_for(int(qlen));   // over 2 048 rows: hand-over per column
+  std::vector<int64_t> boff;
+  int64_t columns = 0;
+  if (passes) {
+    boff.resize(requeue.size());
+    for (size_t i = 0; i < requeue.size(); ++i) {
+      boff[i] = columns;
+      columns += db->h_offsets[size_t(requeue[i]) + 1] - db->h_offsets[size_t(requeue[i])];
+    }
+    by_wave = columns <= (int64_t(1) << 28);           // 2 x 4 bytes of hand-over per column: at most 2 GB
+  }
+  if (by_wave) {
     HIP_TRY(db->rq_ids.reserve(requeue.size()));
     HIP_TRY(hipMemcpyAsync(db->rq_ids.p, requeue.data(), requeue.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    const bool passes = qlen > 64 * swa_endpoints_rows_for(int(qlen));      // queries of more than 2 048 rows: hand-over per column
-    std::vector<int64_t> boff;
     if (passes) {
-      boff.resize(requeue.size());
-      int64_t total = 0;
-      for (size_t i = 0; i < requeue.size(); ++i) {
-        boff[i] = total;
-        total += db->h_offsets[size_t(requeue[i]) + 1] - db->h_offsets[size_t(requeue[i])];
-      }
-      HIP_TRY(db->rq_bh.reserve(size_t(total) + 1));
-      HIP_TRY(db->rq_bf.reserve(size_t(total) + 1));
+      HIP_TRY(db->rq_bh.reserve(size_t(columns) + 1));
+      HIP_TRY(db->rq_bf.reserve(size_t(columns) + 1));
       HIP_TRY(db->rq_boff.reserve(requeue.size()));
       HIP_TRY(hipMemcpyAsync(db->rq_boff.p, boff.data(), boff.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     }
