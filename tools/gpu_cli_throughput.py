@@ -34,8 +34,8 @@ db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
 kms = []
 for i in pick:
-    db.search_topk(res[off[i]:off[i + 1]], keep=250, minscore=60)
-    kms.append(db.search_topk(res[off[i]:off[i + 1]], keep=250, minscore=60)[3]["total_ms"])
+    db.search_topk(res[off[i]:off[i + 1]], keep=250, minscore=80)
+    kms.append(db.search_topk(res[off[i]:off[i + 1]], keep=250, minscore=80)[3]["total_ms"])
 db.close()
 print("library search step (device time, top-250): mean %.1f ms per query over %d queries" % (np.mean(kms), len(pick)))
 for mode, extra in (("-m 8", ["-m", "8"]), ("-m 0 (250 alignments)", ["-m", "0"]), ("-m 7 xml", ["-m", "7"])):
