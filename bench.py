@@ -196,7 +196,12 @@ def main():
     # the bound build, which computes exact scores only for sequences that can reach the E <= 10 threshold -
     # hits_enter drops every other score unseen (hits.cc:174-184).
     exact = None
-    if "SWA_BOUND" not in os.environ and c["narrow_shifted"] in (8, 9):
+    want_exact = int("SWA_BOUND" not in os.environ and c["narrow_shifted"] in (8, 9))
+    if use_dist:                                         # every rank takes the same branch (the steps hold collectives)
+        t = torch.tensor([want_exact], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        want_exact = int(t.item())
+    if want_exact:
         os.environ["SWA_BOUND"] = "0"
         step()
         fence()
