@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
-"""Headline benchmark of BASELINE.json: GCUPS of a 375-aa query against a 10M-sequence synthetic
-protein database per MI355X (configs[1]); N GPUs = N read-only shards of an N x 10M database
-(weak scaling), per-shard top-K merged by one all_gather over RCCL.
+"""Headline benchmark of BASELINE.json: GCUPS of a 375-aa query against ONE 10M-sequence synthetic protein
+database (configs[1]) on N MI355X.  N > 1: the database is cut into N read-only shards of near-equal RESIDUE
+count (parallel.shard_bounds), one per GPU - strong scaling, the metric's "at 1/2/4/8 GPUs" -
+and the per-shard top-K lists are merged after one all_gather over RCCL.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one complete search of the resident shard: query + scoring upload, first-pass kernel,
-re-queue kernels, device-side hit filter, top-250 back on the host, (N>1) all_gather + merge.
-The database is already formatted in HBM when the timed region starts.  Rank 0 prints ONE JSON
-line.  See DESIGN.md "Measurement" for the roofline arithmetic.
+    --weak                      every rank its own --nseq sequences (N x 10M database)
+    --workload protein100M      BASELINE.json configs[4]: 100 M proteins over the N ranks (12.5 M each at N = 8)
+    --workload nucleotide       configs[3] as the only section (it also runs as a secondary section by default)
+
+A step = one complete search of the resident shard: query + scoring upload, first-pass kernel, re-queue kernel,
+device-side hit filter, top-250 back on the host, (N>1) all_gather + merge.  The database is already formatted in
+HBM when the timed region starts.  Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement".
 """
 import argparse
 import json
@@ -30,102 +34,258 @@ np.seterr(over="ignore")
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 KEEP = 250                       # reference default hit list length (max(-v,-b), hits.cc:287)
+CLOCK_GHZ = 2.4
+# VALU instructions per cell pair of each first-pass form (counters.narrow_shifted, include/swipe_amd.h)
+OPS = {0: 8.5, 1: 7.5, 2: 7.5, 3: 7.5, 4: 6.5, 5: 7.5, 6: 6.5, 7: 7.5, 8: 6.0, 9: 6.0, 10: 5.0}
+KERNEL = {0: "swa_narrow_kernel<%d>", 1: "swa_narrow_split_kernel<%d, W, 16>", 2: "swa_narrow_split_kernel<%d, W, 8>",
+          3: "swa_narrow_split_kernel<%d, W, 4>", 4: "swa_dual_kernel<%d, W, NRES, G>",
+          5: "swa_narrow_split_kernel<%d, 2, 16, PIPE, DEFER, MP> (one launch per pass)",
+          6: "swa_dual_kernel<%d, W, NRES, 16, MP> (one launch per pass)", 7: "swa_narrow_split_kernel<%d, W, 2>",
+          8: "swa_narrow_bound_kernel<%d, W, G, 16> (bound build of the first pass; sequences at or above the score "
+             "threshold recomputed exactly by the 32-bit wave kernel inside the step)",
+          9: "swa_narrow_bound_kernel<%d, 2, 16, 16, MP> (one launch per pass)", 10: "swa_dual_bound_kernel<%d>"}
 
 
-def cpu_baseline(res, off, query_text, cores, sample_seqs=1_000_000):
-    """Rank 0, N=1 only: the reference SSSE3 path (oracle/_ref/swipe) on the host cores, on a
-    bounded sample of the same database; falls back to the oracle port if the binary is absent."""
-    from swipe_amd import blastdb
-    n = min(sample_seqs, len(off) - 1)
-    cells1 = int(off[n] - off[0]) * len(query_text)
+def roofline_blocks(nsym, nseq, cells, k_ms, form, rows, bytes_per_residue=1.0, traffic=None, traffic_source=None):
+    """roofline (HBM, SURVEY.md 8(d): 1 B per residue + 12 B per sequence per launch) and the VALU-issue model"""
+    alg_bytes = int(nsym * bytes_per_residue) + 12 * nseq
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    ops = OPS.get(form, 7.5)
+    r = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+         "kernel": KERNEL.get(form, "first-pass kernel, %d rows per lane") % rows, "kernel_ms": round(k_ms, 3),
+         "algorithmic_bytes_per_launch": alg_bytes,
+         "note": "integer DP at hundreds of cells per residue byte is VALU-issue-bound, not HBM-bound; see valu_roofline"}
+    if traffic_source:
+        r["traffic_source"] = traffic_source
+    v = {"achieved_gcups_kernel": round(cells / (k_ms * 1e-3) / 1e9, 1),
+         "peak_gcups": round(256 * 4 * CLOCK_GHZ * 1e9 / 4 * 128 / ops / 1e9, 1),
+         "model": "256 CU x 4 SIMD x %.1f GHz / 4 cycles per VOP3P wave64 op x 128 cells / %.1f ops per cell pair" % (CLOCK_GHZ, ops)}
+    v["frac"] = round(v["achieved_gcups_kernel"] / v["peak_gcups"], 4)
+    return r, v
+
+
+def committed_traffic(key, nseq):
+    """HBM bytes per launch from the committed PMC pass of this command (profiles/hbm_traffic.json): counters cannot be
+    collected inside a timed run, so the line says where the number comes from"""
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tf))
+        rec = rec.get(key, rec) if isinstance(rec.get(key, None), dict) else rec
+        if rec.get("nseq") == nseq:
+            return rec.get("bytes_per_launch"), rec.get("source", "profiles/hbm_traffic.json (rocprofv3 --pmc pass of this "
+                                                                  "command, committed; not re-measured in this run)")
+    except Exception:
+        pass
+    return None, None
+
+
+def reference_cli_rate(d, base, query_text, threads, extra, cells1, budget_s):
+    """GCUPS of oracle/_ref/swipe (the reference, compiled from /root/reference by oracle/Makefile) at `threads`"""
     exe = os.path.join(ROOT, "oracle", "_ref", "swipe")
-    threads = max(1, min(cores, 256))
+
+    def run(reps):
+        qf = os.path.join(d, f"q{threads}_{reps}.fa")
+        with open(qf, "w") as f:
+            for i in range(reps):
+                f.write(f">q{i}\n{query_text}\n")
+        out = subprocess.run([exe, "-d", base, "-i", qf, "-a", str(threads), "-v", "5", "-b", "0"] + extra,
+                             capture_output=True, text=True, check=True).stdout
+        return [float(x) for x in re.findall(r"Elapsed:\s+([0-9.]+)s", out)]
+
+    first = run(1)
+    per = max(first[0], 0.01)
+    reps = int(min(200, max(2, round(budget_s / per))))
+    el = run(reps)
+    total = sum(el)
+    return (cells1 * len(el) / total / 1e9, len(el), total) if total > 0 else (0.0, 0, 0.0)
+
+
+def cpu_baseline(res, off, query_text, cores, *, protein=True, sample_seqs=3_000_000):
+    """Rank 0, N=1 only: the reference SSSE3 path (oracle/_ref/swipe) on the host cores over a bounded sample of the same
+    database, swept over its -a thread counts (the reference takes hitsmutex once per database sequence, hits.cc:172, so
+    it has a knee): the BEST setting is reported, with the per-thread figure and the whole sweep.
+    Falls back to the oracle port if the binary is absent."""
+    import swipe_amd
+    n = min(sample_seqs, len(off) - 1)
+    nres = int(off[n] - off[0])
+    cells1 = nres * len(query_text) * (1 if protein else 2)
+    exe = os.path.join(ROOT, "oracle", "_ref", "swipe")
     if os.path.exists(exe):
         d = tempfile.mkdtemp(prefix="swa_cpu_")
         try:
             base = os.path.join(d, "sample")
-            blastdb.write_protein_volume_arrays(base, res, off[: n + 1])
-
-            def run(reps):
-                qf = os.path.join(d, f"q{reps}.fa")
-                with open(qf, "w") as f:
-                    for i in range(reps):
-                        f.write(f">q{i}\n{query_text}\n")
-                out = subprocess.run([exe, "-d", base, "-i", qf, "-a", str(threads), "-v", "5", "-b", "0"],
-                                     capture_output=True, text=True, check=True).stdout
-                return [float(x) for x in re.findall(r"Elapsed:\s+([0-9.]+)s", out)]
-
-            first = run(1)
-            per = max(first[0], 0.01)
-            reps = int(min(400, max(3, round(12.0 / per))))
-            el = run(reps)
-            total = sum(el)
-            if total <= 0:
-                return None
-            return {"value": round(cells1 * len(el) / total / 1e9, 2), "unit": "GCUPS", "cores": threads,
-                    "kind": "reference",
-                    "sample": f"oracle/_ref/swipe (SSSE3 path) -a {threads}: {len(el)} x 375-aa query vs the first "
-                              f"{n} sequences ({int(off[n] - off[0])} residues) of the same db; sum of its own "
-                              f"'Elapsed' = {total:.2f}s"}
+            swipe_amd.write_blastdb(base, res, off[: n + 1], symtype=1 if protein else 0)
+            extra = [] if protein else ["-p", "0", "-r", "1", "-q", "-3", "-G", "5", "-E", "2"]
+            sweep = {}
+            cand = sorted({t for t in (16, 32, 64, 128, 256) if t <= max(cores, 16)} | {min(cores, 256)})
+            for t in cand:
+                g, k, tot = reference_cli_rate(d, base, query_text, t, extra, cells1, budget_s=4.0)
+                sweep[t] = (round(g, 2), k, round(tot, 2))
+            best = max(sweep, key=lambda t: sweep[t][0])
+            return {"value": sweep[best][0], "unit": "GCUPS", "cores": best, "kind": "reference",
+                    "per_thread": round(sweep[best][0] / best, 3), "host_cores": cores,
+                    "sweep": {str(t): v[0] for t, v in sweep.items()},
+                    "sample": f"oracle/_ref/swipe (SSSE3 path), best of -a {cand}: {sweep[best][1]} x {len(query_text)}-"
+                              f"{'aa' if protein else 'nt (both strands)'} query vs the first {n} sequences ({nres} residues) of "
+                              f"the same db; sum of its own 'Elapsed' = {sweep[best][2]}s"}
         finally:
             subprocess.run(["rm", "-rf", d])
     import oracle
     from swipe_amd import blastdb as b
     n = min(200_000, len(off) - 1)
-    q = b.encode_protein(query_text)
+    q = b.encode_protein(query_text) if protein else b.encode_nucleotide(query_text)
+    M = oracle.matrix_builtin("BLOSUM62") if protein else oracle.matrix_nucleotide(1, -3)
     t = time.time()
-    oracle.search_all63(res[: off[n]], off[: n + 1], q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=cores)
+    oracle.search_all63(res[: off[n]], off[: n + 1], q, M, 12 if protein else 7, 1 if protein else 2, threads=cores)
     dt = time.time() - t
     return {"value": round(int(off[n]) * len(q) / dt / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": "port",
-            "sample": f"oracle scalar 63-bit recurrence, {cores} threads, first {n} sequences"}
+            "per_thread": round(int(off[n]) * len(q) / dt / 1e9 / cores, 3),
+            "sample": f"oracle scalar 63-bit recurrence (one strand), {cores} threads, first {n} sequences"}
 
 
-def nucleotide_main(a, rank, local, world):
-    """BASELINE.json configs[3]: 1 kb DNA query vs a synthetic nucleotide db, both strands in one pass
-    (dual-query kernel).  Single GPU probe; prints its own JSON line."""
+def verify_against_oracle(db, res, off, lo, q, M_name, goe, ge, hits, tot, minscore, maxscore, sample, threads):
+    """The checker leg: all scores of the shard from the exact first pass (swa_search), then (1) the hit list and
+    totalhits recomputed on the host from those scores over EVERY sequence of the shard, (2) the oracle's scalar 63-bit
+    recurrence on the hits' sequences and a seeded random sample.  Returns (verified, mismatches)."""
+    import oracle
+    scores, _ = db.search(q)
+    n = len(off) - 1
+    idx = np.flatnonzero(scores >= minscore)
+    order = idx[np.lexsort((-idx, -scores[idx]))]
+    kept = order[scores[order] <= maxscore][:KEEP]
+    bad = 0
+    mine = [(int(s), int(v)) for s, v in hits if lo <= s < lo + n]
+    want = [(int(lo + i), int(scores[i])) for i in kept]
+    # the local list is what this shard contributes: with one shard it must equal the merged list
+    if want[: len(mine)] != mine:
+        bad += 1
+    rng = np.random.default_rng(20260929 + lo)
+    pick = np.unique(np.concatenate([rng.integers(0, n, size=min(sample, n)), np.array([s - lo for s, _ in mine], dtype=np.int64)]))
+    lens = off[pick + 1] - off[pick]
+    o2 = np.zeros(len(pick) + 1, dtype=np.int64)
+    np.cumsum(lens, out=o2[1:])
+    r2 = np.empty(int(o2[-1]), dtype=np.uint8)
+    for k, i in enumerate(pick):
+        r2[o2[k]:o2[k + 1]] = res[off[i]:off[i + 1]]
+    Mo = oracle.matrix_builtin(M_name) if isinstance(M_name, str) else M_name
+    ref = oracle.search_all63(r2, o2, q, Mo, goe, ge, threads=threads)
+    bad += int((ref != scores[pick]).sum())
+    hit_scores = dict(mine)
+    for k, i in enumerate(pick):
+        s = int(lo + i)
+        if s in hit_scores and hit_scores[s] != int(ref[k]):
+            bad += 1
+    return len(pick), bad, int((scores >= minscore).sum())
+
+
+def cold_open(res, off, device):
+    """disk -> HBM: the shard written as BLAST v4 volumes to local disk, page cache dropped if allowed, swa_db_open"""
+    import swipe_amd
+    from swipe_amd import blastdb
+    d = tempfile.mkdtemp(prefix="swa_cold_")
+    try:
+        base = os.path.join(d, "db")
+        n = len(off) - 1
+        # .psq offsets are 32 bit: volumes of at most ~3.9 G residues behind an alias
+        cuts, vols = [0], []
+        while cuts[-1] < n:
+            hi = int(np.searchsorted(off, off[cuts[-1]] + 3_900_000_000, side="right")) - 1
+            cuts.append(min(n, max(hi, cuts[-1] + 1)))
+        for v in range(len(cuts) - 1):
+            name = f"{base}.{v:02d}"
+            swipe_amd.write_blastdb(name, res, off[cuts[v]: cuts[v + 1] + 1], first_id=cuts[v])
+            vols.append(name)
+        if len(vols) > 1:
+            blastdb.write_alias(base, vols, protein=True)
+        else:
+            base = vols[0]
+        os.sync()
+        dropped = False
+        try:
+            with open("/proc/sys/vm/drop_caches", "w") as f:
+                f.write("3\n")
+            dropped = True
+        except OSError:
+            pass
+        t0 = time.time()
+        db = swipe_amd.Database.open(base, device=device)
+        dt = time.time() - t0
+        db.close()
+        return {"open_s": round(dt, 2), "page_cache_dropped": dropped, "volumes": len(vols),
+                "what": "swa_db_open of the shard from BLAST v4 volumes on the box's local disk: index walk, copy out of "
+                        "the mmap, H2D, format kernel"}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+
+
+def nucleotide_section(a, rank, local, world, nseq, steps, want_cpu):
+    """BASELINE.json configs[3]: 1 kb DNA query vs a synthetic nucleotide db, +1/-3, gap 5+2, both strands in one pass of
+    the two-query kernel (plus strand | reverse complement in the two halves of the packed lanes).  Single shard."""
+    import torch
     import swipe_amd
     from swipe_amd import blastdb, synth
     rtab = synth.residue_table_nucleotide()
     q = synth._random_residues(99, 1, 1000, rtab)
     qm = blastdb.revcomp_nt16(q)
-    res, off = swipe_amd.synth_db(3, a.nseq, first=rank * a.nseq, protein=False, threads=os.cpu_count() or 1)
+    res, off = swipe_amd.synth_db(3, nseq, protein=False, threads=os.cpu_count() or 1)
+    t0 = time.time()
     db = swipe_amd.Database.from_arrays(res, off, symtype=0, device=local)
+    t_load = time.time() - t0
     db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
     st = swipe_amd.stats_init(symtype=0, match=1, mismatch=-3, gapopen=5, gapextend=2, qlen=len(q),
-                              db_seqcount=a.nseq, db_symcount=int(off[-1]))
-    for _ in range(a.warmup):
+                              db_seqcount=nseq, db_symcount=int(off[-1]))
+    for _ in range(max(1, a.warmup)):
         db.search2_topk(q, qm, keep=KEEP, minscore=st.scorethreshold)
-    import torch
     torch.cuda.synchronize()
+    kms, per = [], []
     t0 = time.perf_counter()
-    kms = []
-    for _ in range(a.steps):
+    for _ in range(steps):
+        t1 = time.perf_counter()
         hits, tot, obv, c = db.search2_topk(q, qm, keep=KEEP, minscore=st.scorethreshold)
+        per.append(time.perf_counter() - t1)
         kms.append(c["kernel_ms"])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    cells = 2 * int(off[-1]) * len(q)
-    print(json.dumps({"metric": "GCUPS, 1 kb DNA query vs synthetic nt db, both strands (BASELINE.json configs[3])",
-                      "value": round(cells * a.steps / el / 1e9, 1), "unit": "GCUPS", "n_gpus": 1, "steps": a.steps,
-                      "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True,
-                      "dtype": "f16x2 (plus strand | minus strand)", "data": "synthetic",
-                      "config": {"workload": f"1000-nt query, both strands, vs {a.nseq} nt sequences ({int(off[-1])} bases), "
-                                             "+1/-3, gap 5+2", "kernel": {4: "swa_dual_kernel<%d, W, 16, G>", 6: "swa_dual_kernel<%d, W, 16, 16, MP>, one launch per pass of 16 x %d rows"}.get(
-                                     c["narrow_shifted"], "swa_mp_kernel<pol_f16_dual, %d>").replace("%d", str(c["narrow_rows"]))},
-                      "kernel_ms": round(float(np.mean(kms)), 3), "totalhits": int(tot)}), flush=True)
+    nsym = int(off[-1])
+    cells = 2 * nsym * len(q)
+    k_ms = float(np.mean(kms))
+    info = db.info()
+    traffic, tsrc = committed_traffic("nucleotide", nseq)
+    roof, valu = roofline_blocks(nsym, nseq, cells, k_ms, c["narrow_shifted"], c["narrow_rows"], traffic=traffic, traffic_source=tsrc)
+    roof["algorithmic_bytes_note"] = ("1 B per base + 12 B per sequence, read ONCE for both strands (the reference makes one pass per "
+                                      "strand, swipe.cc:1403); at the .nsq format's 2 bits per base it would be %d" % (nsym // 4 + 12 * nseq))
+    out = {"metric": "GCUPS, 1 kb DNA query vs synthetic nt db, both strands (BASELINE.json configs[3])",
+           "value": round(cells * steps / el / 1e9, 1), "unit": "GCUPS", "n_gpus": 1, "steps": steps,
+           "ms_per_step": round(el / steps * 1e3, 3), "ms_median": round(float(np.median(per)) * 1e3, 3),
+           "overhead_ms": round(el / steps * 1e3 - k_ms, 3), "dtype": "f16x2 (plus strand | minus strand)", "data": "synthetic",
+           "config": {"workload": f"1000-nt query, both strands, vs {nseq} nt sequences ({nsym} bases), +1/-3, gap 5+2, "
+                                  f"top-{KEEP} hits by E<=10 (score >= {st.scorethreshold})"},
+           "roofline": roof, "valu_roofline": valu, "totalhits": int(tot),
+           "hbm_bytes_per_base": round(info["hbm_bytes"] / max(1, nsym), 3), "setup_s": {"load_format": round(t_load, 2)}}
+    if want_cpu:
+        try:
+            qtext = "".join("-ACMGRSVTWYHKDBN"[int(x)] for x in q)
+            out["cpu_baseline"] = cpu_baseline(res, off, qtext, os.cpu_count() or 1, protein=False, sample_seqs=300_000)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "GCUPS", "kind": "reference", "sample": f"failed: {e}"}
     db.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=7)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nseq", type=int, default=10_000_000, help="sequences per GPU")
+    ap.add_argument("--nseq", type=int, default=0, help="sequences of the database (default: 10 M; protein100M: 100 M)")
+    ap.add_argument("--weak", action="store_true", help="every rank its own --nseq sequences instead of a shard of one database")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["protein", "nucleotide"], default="protein",
-                    help="protein = BASELINE.json configs[1] (the headline); nucleotide = configs[3] "
-                         "(1 kb DNA query, both strands, +1/-3, gap 5+2) - not the contract line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the exact-first-pass, nucleotide and cold-open sections")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify-sample", type=int, default=10_000)
+    ap.add_argument("--workload", choices=["protein", "protein100M", "nucleotide"], default="protein",
+                    help="protein = BASELINE.json configs[1] (the headline); protein100M = configs[4]; nucleotide = configs[3]")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,33 +302,53 @@ def main():
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    cores = os.cpu_count() or 1
 
     if a.workload == "nucleotide":
-        return nucleotide_main(a, rank, local, world)
+        out = nucleotide_section(a, rank, local, world, a.nseq or 10_000_000, a.steps, not a.no_cpu_baseline and world == 1)
+        if rank == 0:
+            out.update({"warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None})
+            print(json.dumps(out), flush=True)
+        return
+
+    nseq_total = a.nseq or (100_000_000 if a.workload == "protein100M" else 10_000_000)
     q = blastdb.encode_protein(synth.QUERY_P07327)
-    cores = os.cpu_count() or 1
     gen_threads = max(1, cores // max(1, world))
     t0 = time.time()
-    res, off = swipe_amd.synth_db(1, a.nseq, first=rank * a.nseq, query=q, threads=gen_threads)
+    if a.weak:
+        lo, n_local = rank * nseq_total, nseq_total
+        db_seqs = world * nseq_total
+    else:
+        # ONE database: every rank derives the same length table, takes its residue-balanced slice of sequence numbers
+        # and generates only that slice (the generator is counter-based, keyed by the global sequence number)
+        goff = swipe_amd.synth_offsets(1, nseq_total, query=q, threads=gen_threads)
+        lo, hi = parallel.shard_bounds(goff, world)[rank]
+        n_local = hi - lo
+        db_seqs = nseq_total
+        tot_sym_known = int(goff[-1])
+        del goff
+    res, off = swipe_amd.synth_db(1, n_local, first=lo, query=q, threads=gen_threads)
     t_gen = time.time() - t0
-    t0 = time.time()
-    db = swipe_amd.Database.from_arrays(res, off, device=local, first_seqno=rank * a.nseq,
-                                        total_seqcount=world * a.nseq)
-    t_load = time.time() - t0
     nsym = int(off[-1])
     tot_sym = nsym
     if use_dist:
         t = torch.tensor([nsym], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         tot_sym = int(t.item())
+    if not a.weak and tot_sym != tot_sym_known:
+        raise SystemExit("bench: the shards do not add up to the database")
+    t0 = time.time()
+    db = swipe_amd.Database.from_arrays(res, off, device=local, first_seqno=lo, total_seqcount=db_seqs, total_symcount=tot_sym)
+    t_load = time.time() - t0
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
-    st = swipe_amd.stats_init(qlen=len(q), db_seqcount=world * a.nseq, db_symcount=tot_sym)
+    st = swipe_amd.stats_init(qlen=len(q), db_seqcount=db_seqs, db_symcount=tot_sym)
     dev = torch.device("cuda", local) if use_dist else None
+    minscore, maxscore = st.scorethreshold, st.upperscorethreshold
 
     def step():
-        hits, tot, obv, c = db.search_topk(q, keep=KEEP, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
+        hits, tot, obv, c = db.search_topk_array(q, keep=KEEP, minscore=minscore, maxscore=maxscore)
         if use_dist:
-            hits, tot, obv = parallel.gather_topk(hits, KEEP, tot, obv, device=dev)
+            hits, tot, obv = parallel.gather_topk_array(hits, KEEP, tot, obv, device=dev)
         return hits, tot, c
 
     def fence():
@@ -176,110 +356,123 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(steps):
+        kms, per = [], []
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            hits, tot, c = step()
+            per.append(time.perf_counter() - t1)
+            kms.append(c["kernel_ms"])
+        fence()
+        el = time.perf_counter() - t0
+        return all_max(el), hits, tot, c, float(np.mean(kms)), float(np.median(per))
+
     for _ in range(a.warmup):
         step()
-    kernel_ms = []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        hits, tot, c = step()
-        kernel_ms.append(c["kernel_ms"])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, hits, tot, c, k_ms, med = timed(a.steps)
 
-    # The same step with the exact first pass (every score of the shard exact on the device, what swa_search
-    # returns): reported beside the headline, and the two hit lists must be identical.  The headline step may run
-    # the bound build, which computes exact scores only for sequences that can reach the E <= 10 threshold -
+    # The same step with the exact first pass (every score of the shard exact on the device, what swa_search returns),
+    # over the same number of steps, reported beside the headline; the two hit lists must be identical.  The headline step
+    # may run the bound build, which computes exact scores only for sequences that can reach the E <= 10 threshold -
     # hits_enter drops every other score unseen (hits.cc:174-184).
     exact = None
-    want_exact = int("SWA_BOUND" not in os.environ and c["narrow_shifted"] in (8, 9))
+    want_exact = int(c["narrow_shifted"] in (8, 9) and not a.no_secondary)
     if use_dist:                                         # every rank takes the same branch (the steps hold collectives)
         t = torch.tensor([want_exact], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         want_exact = int(t.item())
     if want_exact:
-        os.environ["SWA_BOUND"] = "0"
+        db.set_option("bound", 0)
         step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            hits_x, tot_x, c_x = step()
-        fence()
-        el_x = time.perf_counter() - t1
-        del os.environ["SWA_BOUND"]
-        if use_dist:
-            t = torch.tensor([el_x], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_x = float(t.item())
-        exact = {"value": round(tot_sym * len(q) * 2 / el_x / 1e9, 1), "unit": "GCUPS", "steps": 2,
-                 "ms_per_step": round(el_x / 2 * 1e3, 3), "kernel_ms": round(float(c_x["kernel_ms"]), 3),
-                 "hits_identical": bool(hits_x == hits and tot_x == tot),
-                 "note": "same step with SWA_BOUND=0: all scores of the shard exact on the device (7.5 instructions "
-                         "per cell pair); the headline step recomputes exactly only what can reach the threshold"}
-        if not exact["hits_identical"]:
+        el_x, hits_x, tot_x, c_x, k_x, med_x = timed(a.steps)
+        db.set_option("bound", None)
+        same = bool(np.array_equal(hits_x, hits) and tot_x == tot)
+        if not same:
             raise SystemExit("bench: the bound build and the exact first pass disagree on the hit list")
+        r_x, v_x = roofline_blocks(nsym, n_local, nsym * len(q), k_x, c_x["narrow_shifted"], c_x["narrow_rows"])
+        exact = {"value": round(tot_sym * len(q) * a.steps / el_x / 1e9, 1), "unit": "GCUPS", "steps": a.steps,
+                 "ms_per_step": round(el_x / a.steps * 1e3, 3), "ms_median": round(med_x * 1e3, 3),
+                 "overhead_ms": round(el_x / a.steps * 1e3 - k_x, 3), "hits_identical": same, "roofline": r_x, "valu_roofline": v_x,
+                 "note": "the same step with swa_set_option(bound, 0): ALL scores of the shard exact on the device (what "
+                         "swa_search returns, 7.5 instructions per cell pair); the headline step recomputes exactly only "
+                         "what can reach the threshold"}
 
+    verified = None
+    if not a.no_verify:
+        nver, bad, tot_local = verify_against_oracle(db, res, off, lo, q, "BLOSUM62", 12, 1, [tuple(h) for h in hits.tolist()],
+                                                     tot, minscore, maxscore, max(1, a.verify_sample // world), gen_threads)
+        v = torch.tensor([nver, bad, tot_local], dtype=torch.int64, device="cuda")
+        if use_dist:
+            dist.all_reduce(v)
+        nver, bad, tot_all = (int(x) for x in v.tolist())
+        if bad or tot_all != tot:
+            raise SystemExit(f"bench: {bad} scores differ from the oracle (totalhits {tot} vs {tot_all} recounted)")
+        verified = nver
+
+    line = None
     if rank == 0:
         cells_per_step = tot_sym * len(q)
         value = cells_per_step * a.steps / elapsed / 1e9
-        k_ms = float(np.mean(kernel_ms))
-        # algorithmic HBM bytes of one first-pass launch on this rank: 1 B per residue
-        # + 12 B per sequence (8 B offset in, 4 B score out)
-        alg_bytes = nsym + 12 * a.nseq
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                rec = json.load(open(tf))
-                if rec.get("nseq") == a.nseq:
-                    traffic = rec.get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        OPS = {0: 8.5, 1: 7.5, 2: 7.5, 3: 7.5, 7: 7.5, 8: 6.0}        # VALU instructions per cell pair of each form
+        form = c["narrow_shifted"]
+        traffic, tsrc = committed_traffic("protein", n_local)
+        roof, valu = roofline_blocks(nsym, n_local, nsym * len(q), k_ms, form, c["narrow_rows"], traffic=traffic, traffic_source=tsrc)
+        what = "top-%d search, bound first pass" % KEEP if form in (8, 9, 10) else "top-%d search, exact first pass" % KEEP
         out = {
             "metric": "GCUPS, 375-aa query vs 10M-seq protein db at 1/2/4/8 GPUs; bit-exact scores",
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_median": round(med * 1e3, 3),
+            "overhead_ms": round(elapsed / a.steps * 1e3 - k_ms, 3),
+            "higher_is_better": True, "scaling": "weak" if a.weak else "strong",
             "vs_baseline": None, "dtype": "f16x2 (exact integers; re-queue to i32/i64)", "data": "synthetic",
-            "config": {"workload": f"375-aa query (P07327) vs {a.nseq} synthetic protein sequences per GPU "
-                                   f"({nsym} residues on rank 0), BLOSUM62, gap 11+1, top-{KEEP} hits by E<=10",
-                       "sequences_per_gpu": a.nseq, "residues_total": tot_sym, "query_len": len(q),
-                       "sharding": f"{world} read-only shard(s) by seqno range; one all_gather of {KEEP}x2 int64 per step"
-                       if world > 1 else "single shard"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": {2: "swa_narrow_split_kernel<%d, W, 8>", 3: "swa_narrow_split_kernel<%d, W, 4>",
-                                    1: "swa_narrow_split_kernel<%d, W, 16>", 0: "swa_narrow_kernel<%d>",
-                                    8: "swa_narrow_bound_kernel<%d, 2, 8, 16> (bound build of the first pass; sequences "
-                                       "at or above the score threshold recomputed by the 32-bit kernel inside the step)"}[
-                                        c["narrow_shifted"]] % c["narrow_rows"],
-                         "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "integer DP at 375 cells per residue byte is VALU-issue-bound, not HBM-bound; "
-                                 "see valu_roofline"},
-            "valu_roofline": {"achieved_gcups_kernel": round(nsym * len(q) / (k_ms * 1e-3) / 1e9, 1),
-                              "peak_gcups": round(256 * 4 * 2.4e9 / 4 * 128 / OPS[c["narrow_shifted"]] / 1e9, 1),
-                              "model": "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per VOP3P wave64 op x 128 cells / "
-                                       "%.1f ops per cell pair" % OPS[c["narrow_shifted"]]},
-            "search": {"totalhits": int(tot), "top_hit": list(hits[0]) if hits else None, "requeued_32bit": int(c["wide"]),
-                       "requeued_64bit": int(c["full"])},
+            "value_is": what + ": hit list, totalhits and every listed score bit-exact (verified_vs_oracle); the all-scores-"
+                               "exact rate of swa_search is exact_first_pass.value",
+            "config": {"workload": f"375-aa query (P07327) vs ONE database of {db_seqs} synthetic protein sequences "
+                                   f"({tot_sym} residues), BLOSUM62, gap 11+1, top-{KEEP} hits by E<=10 (score >= {minscore})",
+                       "sequences_total": db_seqs, "residues_total": tot_sym, "query_len": len(q),
+                       "sequences_rank0": n_local, "residues_rank0": nsym,
+                       "sharding": (f"{world} read-only shards of the one database by residue count (parallel.shard_bounds); "
+                                    f"one all_gather of {KEEP}x2+3 int64 per step" if not a.weak else
+                                    f"{world} shards of {nseq_total} sequences each (weak)") if world > 1 else "single shard"},
+            "roofline": roof, "valu_roofline": valu,
+            "search": {"totalhits": int(tot), "top_hit": [int(x) for x in hits[0]] if len(hits) else None,
+                       "requeued_32bit": int(c["wide"]), "requeued_64bit": int(c["full"])},
             "setup_s": {"generate": round(t_gen, 2), "load_format": round(t_load, 2)},
+            "hits_sha1": __import__("hashlib").sha1(np.ascontiguousarray(hits, dtype=np.int64).tobytes()).hexdigest(),
         }
+        if verified is not None:
+            out["verified_vs_oracle"] = verified
+            out["verified_how"] = ("after the timed region: all scores of every shard from the exact pass; hit list and totalhits "
+                                   "recomputed on the host over every sequence; the hits + a seeded random sample recomputed by "
+                                   "oracle/ (scalar 63-bit recurrence, search63.cc:28-89) - 0 mismatches or the bench fails")
         if exact:
             out["exact_first_pass"] = exact
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(res, off, synth.QUERY_P07327, cores)
-            except Exception as e:   # a missing baseline must not lose the measurement
-                out["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": cores, "kind": "reference",
-                                       "sample": f"failed: {e}"}
-        line = json.dumps(out)
+        line = out
+    if world == 1 and rank == 0 and not a.no_secondary and a.workload == "protein":
+        try:
+            line["cold_open"] = cold_open(res, off, local)
+        except Exception as e:
+            line["cold_open"] = {"open_s": None, "what": f"failed: {e}"}
+    if world == 1 and rank == 0 and not a.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(res, off, synth.QUERY_P07327, cores)
+        except Exception as e:   # a missing baseline must not lose the measurement
+            line["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": cores, "kind": "reference", "sample": f"failed: {e}"}
     db.close()
+    del res, off
+    if world == 1 and rank == 0 and not a.no_secondary and a.workload == "protein":
+        try:
+            line["secondary"] = [nucleotide_section(a, rank, local, world, 10_000_000, 3, not a.no_cpu_baseline)]
+        except Exception as e:
+            line["secondary"] = [{"metric": "nucleotide section", "value": None, "error": str(e)}]
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -288,7 +481,7 @@ def main():
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(line, flush=True)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -130,6 +130,13 @@ SWA_API int swa_blastdb_read(const char* basename, int symtype, int64_t first_se
                      uint8_t** residues, int64_t** offsets, int64_t* nseq,
                      int64_t* total_seqcount, int64_t* total_symcount, int64_t* longest);
 SWA_API void swa_free(void* p);
+/* Host-only: write sequences (reference symbol codes) as ONE BLAST v4 volume basename.{pin,psq,phr} /
+   {nin,nsq,nhr} that the reference's db_open accepts (database.cc:566-601) - streaming, O(1) extra memory.  The image
+   has no makeblastdb; the benchmark uses this to hand the same synthetic database to the reference CLI (CPU baseline)
+   and to time a cold swa_db_open.  Definition lines render as "lcl|s<first_id + i> seq<first_id + i>".  Nucleotide
+   input must be A/C/G/T masks (1, 2, 4, 8): ambiguity runs are not written (SWA_EINVAL).  At most 4 GiB per volume. */
+SWA_API int swa_blastdb_write(const char* basename, int symtype, const uint8_t* residues, const int64_t* offsets,
+                      int64_t nseq, int64_t first_id, const char* title);
 /* Host-only: first definition line of sequence `seqno` rendered as the reference's db_showheader does
    for hit lists ("lcl|id title", asnparse.cc:753-887) and the sequence's length. */
 SWA_API int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen,
@@ -162,6 +169,22 @@ SWA_API int swa_headers_inclusion(const swa_headers* h, int64_t first_seqno, int
    by itself; a taxid list goes through swa_headers_inclusion + this call. */
 SWA_API int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t n);
 SWA_API void swa_db_close(swa_db* db);
+/* Tuning and test knobs of one handle.  None of them changes a result; the defaults are the measured choices of
+   DESIGN.md 4.9, so a SWIPE integration never needs this call - it exists for the A/B tools and so that the parity
+   tests reach every kernel build.  key / value are text ("bound", "0"); value NULL restores the default.  Keys:
+     bound            top-K searches: -1 auto, 0 exact first pass always, 1 bound build whenever one exists
+     lanes            lanes per sequence pair of the first-pass kernel (2, 4, 8, 16) if the query fits; 0 auto
+     pipe             profile-load build of the first-pass kernel: -1 measured best, 0 / 1 / 2
+     blocks_per_cu    persistent blocks per CU of the first-pass kernel; 0 = 8
+     narrow_variant   1 plain (8.5-instruction) form, 2 row-shifted form, 0 auto
+     force_mp, mp_k, mp_w, dual_mp, dual_kmax      block-synchronous multi-pass kernels and their shapes
+     boundary_mb      cap of the pass hand-over buffer of long queries, MiB; -1 = from free memory
+     wave_requeue     0: re-queued sequences always by the batch kernels; -1 auto
+     requeue_host     1: the host reads the re-queue list between the passes (two more stream synchronisations)
+     endpoints_thread 1 ("thread"): one-thread 64-bit end-point kernel; 0 ("wave")
+   A new handle takes its initial values from the environment variables SWA_<KEY> ONCE, at creation; the search path
+   never reads the environment.  Unknown keys and unparsable values return SWA_EINVAL. */
+SWA_API int swa_set_option(swa_db* db, const char* key, const char* value);
 
 /* ---- scoring ------------------------------------------------------------------------------ */
 /* matrix: 32*32 scores, index (db_symbol << 5) | query_symbol, as score_matrix_63
@@ -182,8 +205,9 @@ SWA_API int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* 
    sequences the first pass may be the BOUND build of the kernel (6 instead of 7.5 instructions per
    cell pair; it yields an upper bound at most 15 x gapextend above the score) and every sequence whose
    bound reaches minscore is recomputed exactly before the list is made: hits, *totalhits and *obvious
-   are identical to the exact pass's (counters.narrow_shifted = 8; SWA_BOUND=0 in the environment
-   disables it). */
+   are identical to the exact pass's (counters.narrow_shifted = 8; swa_set_option(db, "bound", "0")
+   disables it).  First pass, re-queue kernels and the filter are enqueued back to back; the call synchronises with
+   the device once. */
 SWA_API int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep,
                     int64_t minscore, int64_t maxscore, swa_hit_t* hits, int64_t* nhits,
                     int64_t* totalhits, int64_t* obvious, swa_counters_t* counters);

@@ -52,8 +52,8 @@ EXPORTS = [
     "swa_db_open_translated", "swa_db_from_memory_translated", "swa_search_frames_topk",
     "swa_gencode_name", "swa_translate_table", "swa_translate",
     "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_time", "swa_headers_get", "swa_headers_inclusion",
-    "swa_db_set_inclusion",
-    "swa_db_close", "swa_blastdb_read", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
+    "swa_db_set_inclusion", "swa_set_option",
+    "swa_db_close", "swa_blastdb_read", "swa_blastdb_write", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
     "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge", "swa_fhits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
@@ -80,11 +80,13 @@ def load():
     L.swa_blastdb_read.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(vp), C.POINTER(vp), i64p, i64p, i64p, i64p]
     L.swa_blastdb_defline.argtypes = [C.c_char_p, C.c_int, i64, C.c_char_p, i64, i64p]
     L.swa_blastdb_deflines.argtypes = [C.c_char_p, C.c_int, i64, C.c_char_p, i64, i64p]
+    L.swa_blastdb_write.argtypes = [C.c_char_p, C.c_int, vp, vp, i64, i64, C.c_char_p]
     L.swa_free.argtypes = [vp]
     L.swa_free.restype = None
     L.swa_db_close.argtypes = [vp]
     L.swa_db_close.restype = None
     L.swa_set_scoring.argtypes = [vp, vp, i64, i64]
+    L.swa_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.swa_search.argtypes = [vp, vp, i64, vp, C.POINTER(Counters)]
     L.swa_search_topk.argtypes = [vp, vp, i64, i64, i64, i64, C.POINTER(Hit), i64p, i64p, i64p, C.POINTER(Counters)]
     L.swa_search2.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(Counters)]

@@ -93,6 +93,19 @@ def merge_hits(lists: Sequence[Sequence[tuple]], keep: int):
     return [(out[i].seqno, out[i].score) for i in range(nout.value)]
 
 
+def merge_hit_arrays(lists: np.ndarray, counts: np.ndarray, keep: int) -> np.ndarray:
+    """merge_hits on arrays: lists int64 [nlists, stride, 2] of (seqno, score) rows, counts int64 [nlists];
+    returns int64 [n, 2].  No Python-level loop: the buffers go straight to swa_hits_merge."""
+    lists = np.ascontiguousarray(lists, dtype=np.int64)
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    n, stride = lists.shape[0], lists.shape[1]
+    out = np.empty((max(1, keep), 2), dtype=np.int64)
+    nout = C.c_int64()
+    _check(_lib.load().swa_hits_merge(C.cast(lists.ctypes.data, C.POINTER(_lib.Hit)), C.cast(counts.ctypes.data, C.POINTER(C.c_int64)),
+                                      n, stride, keep, C.cast(out.ctypes.data, C.POINTER(_lib.Hit)), C.byref(nout)))
+    return out[: nout.value]
+
+
 def merge_frame_hits(lists: Sequence[Sequence[tuple]], keep: int):
     """merge_hits for (seqno, score, qstrand, qframe, dstrand, dframe) tuples"""
     n = len(lists)
@@ -174,6 +187,10 @@ class Database:
         M = _i64(matrix)
         _check(_lib.load().swa_set_scoring(self._h, M.ctypes.data, gapopen + gapextend, gapextend))
 
+    def set_option(self, key: str, value=None):
+        """swa_set_option: a tuning / test knob of this handle ("bound", "lanes", ...); None restores the default."""
+        _check(_lib.load().swa_set_option(self._h, key.encode(), None if value is None else str(value).encode()))
+
     def search(self, query: np.ndarray, *, want_scores: bool = True):
         q = np.ascontiguousarray(query, dtype=np.uint8)
         c = _lib.Counters()
@@ -192,6 +209,18 @@ class Database:
                                            C.byref(n), C.byref(tot), C.byref(obv), C.byref(c)))
         return ([(hits[i].seqno, hits[i].score) for i in range(n.value)], tot.value, obv.value,
                 {f: getattr(c, f) for f, _ in c._fields_})
+
+    def search_topk_array(self, query: np.ndarray, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
+        """search_topk with the hits as one int64 [n, 2] array of (seqno, score) rows (the layout of swa_hit_t):
+        what the multi-GPU gather exchanges."""
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        c = _lib.Counters()
+        hits = np.empty((max(1, keep), 2), dtype=np.int64)
+        n, tot, obv = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(_lib.load().swa_search_topk(self._h, q.ctypes.data, len(q), keep, minscore, maxscore,
+                                           C.cast(hits.ctypes.data, C.POINTER(_lib.Hit)), C.byref(n), C.byref(tot),
+                                           C.byref(obv), C.byref(c)))
+        return hits[: n.value], tot.value, obv.value, {f: getattr(c, f) for f, _ in c._fields_}
 
     def search2(self, query1: np.ndarray, query2: np.ndarray, *, want_scores: bool = True):
         """Two equal-length queries in one pass (nucleotide: plus strand and its reverse complement)."""
@@ -398,6 +427,28 @@ def read_blastdb(basename: str, *, symtype: int = 1, first_seqno: int = 0, last_
         L.swa_free(r)
         L.swa_free(o)
     return res, off, {"total_seqcount": ts.value, "total_symcount": ty.value, "longest": lg.value}
+
+
+def write_blastdb(basename: str, residues: np.ndarray, offsets: np.ndarray, *, symtype: int = 1, first_id: int = 0,
+                  title: str = "swipe_amd synthetic") -> None:
+    """One BLAST v4 volume from (residues, offsets) through the streaming C++ writer (swa_blastdb_write)."""
+    res = np.ascontiguousarray(residues, dtype=np.uint8)
+    off = _i64(offsets)
+    _check(_lib.load().swa_blastdb_write(os.fsencode(basename), symtype, res.ctypes.data, off.ctypes.data, len(off) - 1,
+                                         first_id, title.encode()))
+
+
+def synth_offsets(seed: int, nseq: int, *, first: int = 0, query: Optional[np.ndarray] = None, threads: int = 0) -> np.ndarray:
+    """int64 [nseq + 1] prefix sums of the lengths of synthetic sequences [first, first + nseq) - the lengths only,
+    so that every rank can place its shard of ONE database without generating the others' residues."""
+    from . import synth
+    L = _lib.load()
+    ltab = np.ascontiguousarray(synth.length_table(), dtype=np.int32)
+    q = np.ascontiguousarray(query, dtype=np.uint8) if query is not None else np.zeros(0, np.uint8)
+    off = np.zeros(nseq + 1, dtype=np.int64)
+    L.swa_synth_offsets(seed, first, nseq, ltab.ctypes.data, q.ctypes.data if len(q) else None, len(q), off.ctypes.data,
+                        threads or os.cpu_count() or 1)
+    return off
 
 
 def synth_db(seed: int, nseq: int, *, first: int = 0, query: Optional[np.ndarray] = None, protein: bool = True,

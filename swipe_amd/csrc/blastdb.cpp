@@ -719,3 +719,115 @@ int swa::read_blast_deflines(const char* basename, int symtype, const std::vecto
   swa_headers_close(h);
   return rc;
 }
+
+// ---- BLAST v4 volume writer ------------------------------------------------------------------------------------
+// The image has no makeblastdb / formatdb; the benchmark's CPU baseline and cold-open figures need
+// the synthetic database as files the REFERENCE opens (database.cc:566-601, 1082-1131).  One streaming pass, O(1)
+// extra memory, so a 10 M-sequence volume costs seconds - the Python writer (swipe_amd/blastdb.py) builds index
+// arrays of 8 bytes per residue and is kept for the small fixtures.  Headers are the smallest Blast-def-line-set
+// parse_blast_def_line accepts (asnparse.cc:753): they render as "lcl|s<N> seq<N>".
+// Nucleotide volumes: 2 bits per base, last byte = remainder count (database.cc:1260-1261); ambiguity codes are not
+// written by this fast path (SWA_EINVAL) - synthetic databases hold A, C, G, T only.
+namespace {
+inline void put_be32(std::vector<uint8_t>& v, uint32_t x)
+{
+  v.push_back(uint8_t(x >> 24)); v.push_back(uint8_t(x >> 16)); v.push_back(uint8_t(x >> 8)); v.push_back(uint8_t(x));
+}
+inline void ber_string(std::vector<uint8_t>& v, const std::string& s)
+{
+  v.push_back(0x1a);
+  if (s.size() < 128) v.push_back(uint8_t(s.size()));
+  else { v.push_back(0x82); v.push_back(uint8_t(s.size() >> 8)); v.push_back(uint8_t(s.size())); }
+  v.insert(v.end(), s.begin(), s.end());
+}
+}  // namespace
+
+extern "C" int swa_blastdb_write(const char* basename, int symtype, const uint8_t* residues, const int64_t* offsets,
+                                 int64_t nseq, int64_t first_id, const char* title)
+{
+  if (!basename || !offsets || nseq < 0 || (nseq > 0 && !residues)) return swa::fail(SWA_EINVAL, "bad argument");
+  if (symtype != SWA_SYMTYPE_PROTEIN && symtype != SWA_SYMTYPE_NUCLEOTIDE) return swa::fail(SWA_EINVAL, "symtype must be 0 or 1");
+  const bool protein = symtype == SWA_SYMTYPE_PROTEIN;
+  const std::string base(basename);
+  const char* ext = protein ? "p" : "n";
+  FILE* fsq = std::fopen((base + "." + ext + "sq").c_str(), "wb");
+  FILE* fhr = std::fopen((base + "." + ext + "hr").c_str(), "wb");
+  if (!fsq || !fhr) { if (fsq) std::fclose(fsq); if (fhr) std::fclose(fhr); return swa::fail(SWA_EIO, "cannot create " + base); }
+  std::vector<uint32_t> hdr_off(size_t(nseq) + 1), seq_off(size_t(nseq) + 1), amb_off;
+  if (!protein) amb_off.resize(size_t(nseq) + 1);
+  std::vector<uint8_t> buf, hb;
+  buf.reserve(1 << 22);
+  uint64_t sq_pos = 1, hr_pos = 0, total = 0, longest = 0;
+  std::fputc(0, fsq);
+  int rc = SWA_OK;
+  for (int64_t s = 0; s < nseq && rc == SWA_OK; ++s) {
+    const int64_t len = offsets[s + 1] - offsets[s];
+    const uint8_t* p = residues + offsets[s];
+    if (len < 0) { rc = swa::fail(SWA_EINVAL, "sequence offsets must be non-decreasing"); break; }
+    total += uint64_t(len);
+    longest = std::max<uint64_t>(longest, uint64_t(len));
+    seq_off[size_t(s)] = uint32_t(sq_pos);
+    buf.clear();
+    if (protein) {
+      buf.insert(buf.end(), p, p + len);
+      buf.push_back(0);
+    } else {
+      static const int8_t two[16] = {-1, 0, 1, -1, 2, -1, -1, -1, 3, -1, -1, -1, -1, -1, -1, -1};
+      const int64_t full = len / 4;
+      for (int64_t k = 0; k < full; ++k) {
+        const int a = two[p[4 * k] & 15], b = two[p[4 * k + 1] & 15], c = two[p[4 * k + 2] & 15], d = two[p[4 * k + 3] & 15];
+        if ((a | b | c | d) < 0) { rc = swa::fail(SWA_EINVAL, "swa_blastdb_write: ambiguity codes are not supported"); break; }
+        buf.push_back(uint8_t(a << 6 | b << 4 | c << 2 | d));
+      }
+      uint8_t last = uint8_t(len - 4 * full);
+      for (int64_t k = 4 * full; k < len && rc == SWA_OK; ++k) {
+        const int a = two[p[k] & 15];
+        if (a < 0) { rc = swa::fail(SWA_EINVAL, "swa_blastdb_write: ambiguity codes are not supported"); break; }
+        last |= uint8_t(a << (6 - 2 * (k - 4 * full)));
+      }
+      buf.push_back(last);
+      amb_off[size_t(s)] = uint32_t(sq_pos + buf.size());
+    }
+    if (sq_pos + buf.size() >= (uint64_t(1) << 32)) { rc = swa::fail(SWA_EINVAL, "volume exceeds the 4 GiB offset limit of the v4 format"); break; }
+    if (std::fwrite(buf.data(), 1, buf.size(), fsq) != buf.size()) { rc = swa::fail(SWA_EIO, "write failed"); break; }
+    sq_pos += buf.size();
+    // 30 80 | 30 80 | A0 80 1A n title 00 00 | A1 80 30 80 A0 80 A1 80 1A n id 00 00 x4 | 00 00 | 00 00
+    hdr_off[size_t(s)] = uint32_t(hr_pos);
+    hb.clear();
+    const std::string id = "s" + std::to_string(first_id + s), ti = "seq" + std::to_string(first_id + s);
+    const uint8_t open1[] = {0x30, 0x80, 0x30, 0x80, 0xa0, 0x80};
+    hb.insert(hb.end(), open1, open1 + 6);
+    ber_string(hb, ti);
+    const uint8_t mid[] = {0x00, 0x00, 0xa1, 0x80, 0x30, 0x80, 0xa0, 0x80, 0xa1, 0x80};
+    hb.insert(hb.end(), mid, mid + 10);
+    ber_string(hb, id);
+    for (int k = 0; k < 12; ++k) hb.push_back(0);
+    if (std::fwrite(hb.data(), 1, hb.size(), fhr) != hb.size()) { rc = swa::fail(SWA_EIO, "write failed"); break; }
+    hr_pos += hb.size();
+    if (hr_pos >= (uint64_t(1) << 32)) { rc = swa::fail(SWA_EINVAL, "header file exceeds 4 GiB"); break; }
+  }
+  std::fclose(fsq);
+  std::fclose(fhr);
+  if (rc != SWA_OK) return rc;
+  seq_off[size_t(nseq)] = uint32_t(sq_pos);
+  hdr_off[size_t(nseq)] = uint32_t(hr_pos);
+  if (!protein) amb_off[size_t(nseq)] = uint32_t(sq_pos);
+  std::vector<uint8_t> pin;
+  const std::string t = title ? title : "swipe_amd synthetic", d = "Jan 1, 2026  0:00 AM";
+  put_be32(pin, 4);
+  put_be32(pin, protein ? 1 : 0);
+  put_be32(pin, uint32_t(t.size())); pin.insert(pin.end(), t.begin(), t.end());
+  put_be32(pin, uint32_t(d.size())); pin.insert(pin.end(), d.begin(), d.end());
+  while (pin.size() % 4) pin.push_back(0);
+  put_be32(pin, uint32_t(nseq));
+  for (int k = 0; k < 8; ++k) pin.push_back(uint8_t(total >> (8 * k)));        // little-endian (database.cc:595)
+  put_be32(pin, uint32_t(longest));
+  for (uint32_t v : hdr_off) put_be32(pin, v);
+  for (uint32_t v : seq_off) put_be32(pin, v);
+  if (!protein) for (uint32_t v : amb_off) put_be32(pin, v);
+  FILE* fin = std::fopen((base + "." + ext + "in").c_str(), "wb");
+  if (!fin) return swa::fail(SWA_EIO, "cannot create " + base);
+  const bool ok = std::fwrite(pin.data(), 1, pin.size(), fin) == pin.size();
+  std::fclose(fin);
+  return ok ? SWA_OK : swa::fail(SWA_EIO, "write failed");
+}

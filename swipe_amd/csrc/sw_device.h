@@ -15,6 +15,12 @@ struct swa_batch {
                                   the stream holds ceil(steps / 16) chunks of 16 columns */
 };
 
+struct swa_cand {              /* one survivor of the hit filter (hits_enter's acceptance test on the device) */
+  long long score;
+  int32_t idx;                 /* shard-local sequence index */
+  int32_t which;               /* 0 / 1: first / second score array of a two-query search */
+};
+
 struct swa_query {
   const uint8_t* qseq;         /* query residues, reference symbol codes (< 32) */
   const int32_t* matrix;       /* 32x32, (db symbol << 5) | query symbol */

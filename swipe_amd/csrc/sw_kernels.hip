@@ -562,10 +562,9 @@ swa_narrow_split_kernel(swa_narrow_params p)
 // The hits_enter acceptance test (hits.cc:174-184) over all scores of the shard: counts
 // totalhits / obvious and compacts candidates (index, score) for the host-side top-K.
 extern "C" __global__ void __launch_bounds__(256)
-swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ scores64, int n,
+swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ scores64, int n, int which,
                 long long minscore, long long maxscore, int* __restrict__ cand_count,
-                int cand_cap, int* __restrict__ cand_idx, long long* __restrict__ cand_score,
-                unsigned long long* __restrict__ tallies)
+                int cand_cap, swa_cand* __restrict__ cand, unsigned long long* __restrict__ tallies)
 {
   const int lane = threadIdx.x & 63;
   unsigned long long total = 0, obvious = 0;
@@ -586,7 +585,7 @@ swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ sc
       if (lane == 0) base = atomicAdd(cand_count, nk);
       base = __builtin_amdgcn_readfirstlane(base);
       const int pos = base + __popcll(mk & ((1ull << lane) - 1));
-      if (keep && pos < cand_cap) { cand_idx[pos] = i; cand_score[pos] = sc; }
+      if (keep && pos < cand_cap) cand[pos] = swa_cand{sc, i, which};
     }
   }
   for (int sh = 32; sh > 0; sh >>= 1) { total += __shfl_down(total, sh); obvious += __shfl_down(obvious, sh); }
@@ -649,30 +648,19 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
 // bh/bf (one int pair per column, in place: lane 63 writes column t - 63 long after lane 0 read it).
 // Ties as search16s.cc:391-405: among the cells holding the maximum, the smallest column, then the smallest row.
 // POS = false: the score only (re-queue use) - no position bookkeeping in the inner loop
-template <int K, bool POS = true>
-__global__ void __launch_bounds__(64)
-swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                          const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
-                          const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
-                          int* __restrict__ bh, int* __restrict__ bf, const int64_t* __restrict__ boff,
-                          long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q,
-                          int* __restrict__ scores)
+// one sequence [o, o + len) against the query, by the 64 lanes of the calling wave (a block of its own: M and ring are
+// its LDS); returns the wave-wide best / first column / smallest row in every lane
+template <int K, bool POS>
+__device__ __forceinline__ void endpoints_wave_one(const int* M, uint8_t* ring, const uint8_t* __restrict__ residues, int64_t o,
+                                                   int len, bool rc, const uint8_t* __restrict__ qseq, int qlen, int Q, int R,
+                                                   int* mybh, int* mybf, int& best, int& bcol, int& brow)
 {
-  __shared__ int M[1024];
-  __shared__ uint8_t ring[128];
-  const int w = blockIdx.x, g = threadIdx.x;
-  if (w >= n) return;
-  for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
-  const int64_t o = offsets[ids[w]];
-  const int len = (int)(offsets[ids[w] + 1] - o);
-  const bool rc = minus && minus[w];
-  int* mybh = bh ? bh + boff[w] : nullptr;
-  int* mybf = bf ? bf + boff[w] : nullptr;
+  const int g = threadIdx.x;
   auto residue = [&](int c) -> u32 {
     if (c >= len) return 0;
     return rc ? (__brev((u32)residues[o + len - 1 - c]) >> 28) : (u32)residues[o + c];
   };
-  int best = 0, bcol = 0, brow = -1;
+  best = 0; bcol = 0; brow = -1;
   for (int row0 = 0; row0 < qlen; row0 += 64 * K) {
     const bool first_pass = row0 == 0, more = row0 + 64 * K < qlen;
     int qs[K], hp[K], ee[K];
@@ -747,9 +735,64 @@ swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* _
     const int ob = __shfl_down(best, sh), oc = __shfl_down(bcol, sh), orow = __shfl_down(brow, sh);
     if (ob > best || (ob == best && ob > 0 && (oc < bcol || (oc == bcol && orow < brow)))) { best = ob; bcol = oc; brow = orow; }
   }
+}
+
+template <int K, bool POS = true>
+__global__ void __launch_bounds__(64)
+swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
+                          const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
+                          const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
+                          int* __restrict__ bh, int* __restrict__ bf, const int64_t* __restrict__ boff,
+                          long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q,
+                          int* __restrict__ scores)
+{
+  __shared__ int M[1024];
+  __shared__ uint8_t ring[128];
+  const int w = blockIdx.x, g = threadIdx.x;
+  if (w >= n) return;
+  for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
+  const int64_t o = offsets[ids[w]];
+  const int len = (int)(offsets[ids[w] + 1] - o);
+  const bool rc = minus && minus[w];
+  int best, bcol, brow;
+  endpoints_wave_one<K, POS>(M, ring, residues, o, len, rc, qseq, qlen, Q, R, bh ? bh + boff[w] : nullptr,
+                             bf ? bf + boff[w] : nullptr, best, bcol, brow);
   if (g == 0) {
     if (scores) scores[ids[w]] = best;           // re-queue use: the score of the sequence, in place
     else { out_score[w] = best; out_pos[w] = bcol; out_q[w] = brow; }
+  }
+}
+
+// The re-queue list worked off WITHOUT the host: the first-pass kernel left `*count` sequence indices in `list`
+// (ballot-compacted, one atomic per wave); a persistent grid of single-wave blocks takes entries off a work-queue head
+// until min(*count, cap) and writes the exact int32 score of each in place.  The host learns the count only when the
+// whole search has been enqueued and synchronises once (swipe_amd.cpp settle_search); lists longer than cap are taken
+// over by the host there.  Single pass of the wave kernel only: qlen <= 64 K.
+template <int K>
+__global__ void __launch_bounds__(64)
+swa_requeue_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
+                        const int32_t* __restrict__ list, const int32_t* __restrict__ count, int cap, int32_t* __restrict__ work,
+                        const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
+                        int* __restrict__ scores)
+{
+  __shared__ int M[1024];
+  __shared__ uint8_t ring[128];
+  const int g = threadIdx.x;
+  int n = *count;
+  if (n > cap) n = cap;
+  if (n <= 0) return;
+  for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
+  for (;;) {
+    int w = 0;
+    if (g == 0) w = atomicAdd(work, 1);
+    w = __builtin_amdgcn_readfirstlane(w);
+    if (w >= n) break;
+    const int id = list[w];
+    const int64_t o = offsets[id];
+    const int len = (int)(offsets[id + 1] - o);
+    int best, bcol, brow;
+    endpoints_wave_one<K, false>(M, ring, residues, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
+    if (g == 0) scores[id] = best;
   }
 }
 
@@ -983,14 +1026,33 @@ extern "C" hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const i
 #undef SWA_EPW
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, long long minscore,
-                                        long long maxscore, int* cand_count, int cand_cap, int* cand_idx,
-                                        long long* cand_score, unsigned long long* tallies, hipStream_t st)
+extern "C" hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* list,
+                                              const int32_t* count, int cap, int32_t* work, const uint8_t* qseq, int qlen,
+                                              const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
+{
+#define SWA_RQW(KK) hipLaunchKernelGGL((swa_requeue_wave_kernel<KK>), dim3(blocks), dim3(64), 0, st, residues, offsets, list, count, \
+                                       cap, work, qseq, qlen, matrix, Q, R, scores)
+  switch (swa_endpoints_rows_for(qlen)) {
+    case 2: SWA_RQW(2); break;
+    case 4: SWA_RQW(4); break;
+    case 6: SWA_RQW(6); break;
+    case 8: SWA_RQW(8); break;
+    case 12: SWA_RQW(12); break;
+    case 16: SWA_RQW(16); break;
+    case 24: SWA_RQW(24); break;
+    default: SWA_RQW(32); break;
+  }
+#undef SWA_RQW
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,
+                                        long long maxscore, int* cand_count, int cand_cap, swa_cand* cand,
+                                        unsigned long long* tallies, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(swa_filter_hits, dim3(blocks), dim3(256), 0, st, scores, scores64, n, minscore, maxscore,
-                     cand_count, cand_cap, cand_idx, cand_score, tallies);
+  hipLaunchKernelGGL(swa_filter_hits, dim3(blocks), dim3(256), 0, st, scores, scores64, n, which, minscore, maxscore,
+                     cand_count, cand_cap, cand, tallies);
   return hipGetLastError();
 }

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -58,9 +59,12 @@ hipError_t swa_launch_dual(int K, int nres, int G, const swa_mp_params* p, int c
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
                              const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
-hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, long long minscore,
-                             long long maxscore, int* cand_count, int cand_cap, int* cand_idx,
-                             long long* cand_score, unsigned long long* tallies, hipStream_t st);
+hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,
+                             long long maxscore, int* cand_count, int cand_cap, swa_cand* cand,
+                             unsigned long long* tallies, hipStream_t st);
+hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* list, const int32_t* count,
+                                   int cap, int32_t* work, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
+                                   int* scores, int blocks, hipStream_t st);
 }
 
 namespace swa {
@@ -108,6 +112,54 @@ struct BatchSet {
   std::vector<int32_t> h_steps;             // steps of every batch (non-increasing: batches are cut from a length-sorted list)
 };
 
+// Tuning / test knobs of one handle (swa_set_option).  The defaults are what the measurements in DESIGN.md chose;
+// none of them changes a result.  A handle takes its initial values from the environment ONCE, when it is created
+// (SWA_<KEY>, upper case) - a convenience for the A/B tools; the search path itself never reads the environment.
+struct Options {
+  int64_t bound = -1;            // bound build of the first pass of top-K searches: -1 auto, 0 never, 1 whenever a build exists
+  int64_t lanes = 0;             // lanes per sequence pair (2 / 4 / 8 / 16) if the query fits; 0 = by query length
+  int64_t pipe = -1;             // profile-load build of the split kernel: -1 measured best, 0 staged, 1 pipelined, 2 across steps
+  int64_t blocks_per_cu = 0;     // persistent blocks per CU of the first-pass kernel; 0 = 8
+  int64_t force_mp = 0;          // 1: block-synchronous multi-pass kernel for any query length
+  int64_t mp_k = 0, mp_w = 0;    // its rows per lane / waves per SIMD; 0 = default
+  int64_t boundary_mb = -1;      // cap of the pass hand-over buffer in MiB; -1 = from free memory
+  int64_t wave_requeue = -1;     // re-queued sequences one wave each: -1 when the list is short, 0 never
+  int64_t dual_mp = 0;           // 1: multi-pass policy for two queries
+  int64_t dual_kmax = 0;         // largest rows-per-lane of the single-pass two-query kernel; 0 = no cap
+  int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
+  int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
+  int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
+};
+struct OptionKey { const char* key; int64_t Options::*field; };
+const OptionKey kOptionKeys[] = {
+  {"bound", &Options::bound}, {"lanes", &Options::lanes}, {"pipe", &Options::pipe},
+  {"blocks_per_cu", &Options::blocks_per_cu}, {"force_mp", &Options::force_mp}, {"mp_k", &Options::mp_k},
+  {"mp_w", &Options::mp_w}, {"boundary_mb", &Options::boundary_mb}, {"wave_requeue", &Options::wave_requeue},
+  {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
+  {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
+};
+bool parse_option_value(const char* key, const char* value, int64_t* out)
+{
+  if (!value || !*value) return false;
+  if (!std::strcmp(key, "endpoints_thread") && !std::strcmp(value, "thread")) { *out = 1; return true; }
+  if (!std::strcmp(key, "endpoints_thread") && !std::strcmp(value, "wave")) { *out = 0; return true; }
+  char* end = nullptr;
+  const long long v = std::strtoll(value, &end, 10);
+  if (end == value || *end) return false;
+  *out = v;
+  return true;
+}
+void options_from_environment(Options& o)
+{
+  for (const OptionKey& k : kOptionKeys) {
+    std::string name = "SWA_";
+    for (const char* c = k.key; *c; ++c) name += char(std::toupper(static_cast<unsigned char>(*c)));
+    if (!std::strcmp(k.key, "endpoints_thread")) name = "SWA_ENDPOINTS";
+    int64_t v = 0;
+    if (const char* e = std::getenv(name.c_str())) if (parse_option_value(k.key, e, &v)) o.*(k.field) = v;
+  }
+}
+
 uint16_t f16_bits(float f)
 {
   _Float16 h = (_Float16)f;
@@ -145,6 +197,7 @@ struct swa_db {
   bool single_built = false;
   DevBuf<int32_t> scores;
   DevBuf<long long> scores64;
+  DevBuf<long long> scores64b;              // 64-bit scores of the second query of a dual search
   DevBuf<int32_t> ovf_list;
   DevBuf<int32_t> ovf_list2;
   DevBuf<int32_t> scores2;                 // second query of a dual search
@@ -153,31 +206,43 @@ struct swa_db {
   DevBuf<int> rq_bh, rq_bf;
   DevBuf<int64_t> rq_boff;
   DevBuf<unsigned char> boundary;          // per-wave pass hand-over columns of the multi-pass kernel
-  DevBuf<int32_t> ctl;                     // [0] work counter, [1] overflow count, [2] candidate count, [3] overflow count of query 2
-  DevBuf<unsigned long long> tallies;      // totalhits, obvious
-  DevBuf<int32_t> cand_idx;
-  DevBuf<long long> cand_score;
-  DevBuf<uint8_t> qseq;
+  DevBuf<int32_t> ctl;                     // counters + candidate records of the hit filter (layout: "control block" below)
+  int cand_cap = 0;                        // candidate records ctl has room for
+  DevBuf<uint8_t> qseq;                    // query of the alignment-phase entry points
+  DevBuf<uint8_t> qblock;                  // [swa_query | query 1 | query 2] of the search in flight, one upload
+  const uint8_t* qseq_p = nullptr;         // -> query 1 / 2 inside qblock
+  const uint8_t* qseq2_p = nullptr;
   DevBuf<int32_t> matrix;
-  DevBuf<swa_query> query;
 
   bool scoring_set = false;
   int32_t h_matrix[1024];
   int64_t goe = 0, ge = 0, hi = 0, lo = 0;
-  int narrow_variant = 0;                  // 0 auto, 1 plain, 2 row-shifted (SWA_NARROW_VARIANT, for A/B runs)
-  bool bound_off = false;                  // the bound build sent back too many sequences under this scoring system
+  Options opt;                             // swa_set_option
+  // (query length, threshold) pairs for which the bound build sent back more than 2 % of the shard under the current
+  // scoring system: those searches take the exact first pass at once; other queries still try the bound build
+  std::vector<std::pair<int64_t, int64_t>> bound_off;
+  bool bound_is_off(int64_t qlen, int64_t minscore) const
+  {
+    for (const auto& b : bound_off) if (b.first == qlen && minscore <= b.second) return true;
+    return false;
+  }
+  // page-locked staging block for everything a search reads back (counters, tallies, the first candidates): one
+  // asynchronous copy and ONE stream synchronisation per search
+  unsigned char* pin = nullptr;
+  size_t pin_bytes = 0;
 
   ~swa_db()
   {
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
+    if (pin) (void)hipHostFree(pin);
   }
   size_t hbm_bytes() const
   {
     return residues.bytes() + offsets.bytes() + main.slots.bytes() + main.batches.bytes() + main.stream.bytes() +
            scratch.slots.bytes() + scratch.batches.bytes() + scratch.stream.bytes() + single.slots.bytes() +
            single.batches.bytes() + single.stream.bytes() + scores2.bytes() + boundary.bytes() + scores.bytes() +
-           scores64.bytes() + ovf_list.bytes() + cand_idx.bytes() + cand_score.bytes();
+           scores64.bytes() + scores64b.bytes() + ovf_list.bytes() + ovf_list2.bytes() + ctl.bytes();
   }
 };
 
@@ -280,6 +345,35 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
     if (len < 0) return fail(SWA_EINVAL, "sequence offsets must be non-decreasing");
     db->longest = std::max(db->longest, len);
   }
+  // Residue codes index the LDS profile (code x row stride) and the 32 x 32 matrix: a code outside the alphabet - a
+  // corrupt .psq, a caller's array - would read out of bounds and score silently wrong.  One OR over all bytes.
+  if (residues && db->nsym) {
+    const uint8_t bad_bits = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 0xF0 : 0xE0;
+    const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, db->nsym >> 24}));
+    std::vector<uint8_t> acc(size_t(nthreads), 0);
+    auto scan = [&](int64_t t) {
+      const uint8_t* p = residues + base + db->nsym * t / nthreads;
+      const uint8_t* e = residues + base + db->nsym * (t + 1) / nthreads;
+      uint64_t a8 = 0;
+      uint8_t a = 0;
+      for (; p < e && (reinterpret_cast<uintptr_t>(p) & 7); ++p) a |= *p;
+      for (; p + 8 <= e; p += 8) { uint64_t v; std::memcpy(&v, p, 8); a8 |= v; }
+      for (; p < e; ++p) a |= *p;
+      for (int k = 0; k < 8; ++k) a |= uint8_t(a8 >> (8 * k));
+      acc[size_t(t)] = a;
+    };
+    if (nthreads == 1) scan(0);
+    else {
+      std::vector<std::thread> pool;
+      for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(scan, t);
+      for (std::thread& t : pool) t.join();
+    }
+    uint8_t any = 0;
+    for (uint8_t a : acc) any |= a;
+    if (any & bad_bits)
+      return fail(SWA_EINVAL, db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? "database residue code out of range (nucleotide codes are 4-bit masks, < 16)"
+                                                                   : "database residue code out of range (must be < 32)");
+  }
   HIP_TRY(hipSetDevice(db->device));
   if (!db->stream) {
     hipDeviceProp_t prop;
@@ -296,10 +390,9 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   HIP_TRY(hipMemcpyAsync(db->offsets.p, db->h_offsets.data(), (size_t(nseq) + 1) * sizeof(int64_t), hipMemcpyHostToDevice, db->stream));
   HIP_TRY(db->scores.reserve(size_t(nseq)));
   HIP_TRY(db->ovf_list.reserve(size_t(nseq)));
-  HIP_TRY(db->ctl.reserve(8));
-  HIP_TRY(db->tallies.reserve(2));
+  db->cand_cap = int(std::max<int64_t>(1, std::min<int64_t>(nseq, 1 << 20)));
+  HIP_TRY(db->ctl.reserve(16 + size_t(db->cand_cap) * (sizeof(swa_cand) / sizeof(int32_t))));
   HIP_TRY(db->matrix.reserve(1024));
-  HIP_TRY(db->query.reserve(1));
   order_by_length(db->h_offsets, nullptr, nseq, db->h_order);
   return build_batches(db, db->h_order.data(), nseq, 2, db->main);
 }
@@ -330,6 +423,7 @@ struct MpRun {
   int32_t* ovf_list = nullptr;
   int32_t* ovf_count2 = nullptr;
   int32_t* ovf_list2 = nullptr;
+  long long* scores64 = nullptr;  // 64-bit results (mode 3); null = db->scores64
 };
 
 int mp_rows_for(int mode, int64_t qlen)
@@ -354,7 +448,7 @@ int64_t f16_limit(const swa_db* db, int K) { return 2048 - db->hi - int64_t(K + 
 int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
 {
   int K = mp_rows_for(r.mode, qlen);
-  if (const char* e = std::getenv("SWA_MP_K")) if (r.mode <= 1) K = std::atoi(e);
+  if (db->opt.mp_k > 0 && r.mode <= 1) K = int(db->opt.mp_k);
   swa_mp_params p{};
   p.qseq = r.q1;
   p.qseq2 = r.q2;
@@ -369,7 +463,7 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   p.counter = db->ctl.p + 0;
   p.scores = r.scores;
   p.scores2 = r.scores2;
-  p.scores64 = db->scores64.p;
+  p.scores64 = r.scores64 ? r.scores64 : db->scores64.p;
   p.limit = r.mode <= 1 ? f16_limit(db, K) : (1ll << 31) - db->hi - int64_t(K + 1) * db->ge;
   p.ovf_count = r.ovf_count;
   p.ovf_list = r.ovf_list;
@@ -387,7 +481,7 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   const size_t lds = size_t(32) * ((K + rpu - 1) / rpu) * 256;
   // resident waves per SIMD the kernel's VGPR count allows (-Rpass-analysis=kernel-resource-usage)
   int wps = swa_mp_waves(r.mode, K);
-  if (const char* e = std::getenv("SWA_MP_W")) { p.tune_w = std::atoi(e); if (r.mode == 1 && K == 32) wps = p.tune_w; }
+  if (db->opt.mp_w > 0) { p.tune_w = int(db->opt.mp_w); if (r.mode == 1 && K == 32) wps = p.tune_w; }
   const int waves_cu = 4 * wps;
   const int by_lds = std::max(1, int(160 * 1024 / lds));
   int nw = 4;
@@ -405,7 +499,7 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t budget = std::min<size_t>(size_t(4) << 30, (free_b + db->boundary.bytes()) / 4);
-    if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
+    if (db->opt.boundary_mb >= 0) budget = size_t(db->opt.boundary_mb) << 20;     // tests
     const int64_t need = int64_t(r.set->h_steps.empty() ? db->longest : r.set->h_steps[0]) + 48;
     const int64_t cols_all = int64_t(budget / (size_t(blocks) * nw * per_col));
     if (need <= cols_all) {
@@ -453,7 +547,7 @@ int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const size_t avail = free_b + db->boundary.bytes();
   size_t budget = std::min<size_t>(size_t(64) << 30, avail / 4);
-  if (const char* e = std::getenv("SWA_BOUNDARY_MB")) budget = size_t(std::atol(e)) << 20;     // tests
+  if (db->opt.boundary_mb >= 0) budget = size_t(db->opt.boundary_mb) << 20;     // tests
   const size_t per_chunk = 64 * 8;
   const int nb = bs.nbatches;
   size_t largest = 0, bytes = 0;
@@ -504,7 +598,7 @@ int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st, bool bound, in
   const int Nb = bound ? swa_bound_period() : 0;
   const BatchSet& bs = db->main;
   swa_narrow_params p{};
-  p.query = db->query.p;
+  p.query = reinterpret_cast<const swa_query*>(db->qblock.p);
   p.stream = bs.stream.p;
   p.counter = db->ctl.p + 0;
   p.scores = db->scores.p;
@@ -564,8 +658,8 @@ int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
   dual_pass_shape(qlen, nres, &npass, &K);
   const BatchSet& bs = db->single;
   swa_mp_params p{};
-  p.qseq = db->qseq.p;
-  p.qseq2 = db->qseq2.p;
+  p.qseq = db->qseq_p;
+  p.qseq2 = db->qseq2_p;
   p.matrix = db->matrix.p;
   p.qlen = int32_t(qlen);
   p.rows_per_lane = K;
@@ -604,6 +698,62 @@ int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
   return SWA_OK;
 }
 
+// ---- control block -------------------------------------------------------------------------------------------
+// db->ctl is ONE device allocation: 16 ints of counters followed by the candidate records of the hit filter, so that
+// one asynchronous copy into the page-locked block db->pin brings back everything a search wants on the host and
+// the search synchronises with the stream ONCE:
+//   [0] work-queue head of the first-pass kernel     [1] re-queue count, query 1     [3] re-queue count, query 2
+//   [4] [5] work-queue heads of the device-driven re-queue kernels                   [8] candidate count
+//   [10..13] two 64-bit tallies (totalhits, obvious)                                 [16..] swa_cand records
+constexpr int CTL_INTS = 16;
+constexpr int CTL_CAND = 8, CTL_TALLY = 10;
+constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
+constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
+
+inline const int32_t* ctl_host(const swa_db* db) { return reinterpret_cast<const int32_t*>(db->pin); }
+inline swa_cand* cand_dev(swa_db* db) { return reinterpret_cast<swa_cand*>(db->ctl.p + CTL_INTS); }
+
+int ensure_pin(swa_db* db, size_t bytes)
+{
+  if (bytes <= db->pin_bytes) return SWA_OK;
+  if (db->pin) { (void)hipHostFree(db->pin); db->pin = nullptr; db->pin_bytes = 0; }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&db->pin), bytes, hipHostMallocDefault));
+  db->pin_bytes = bytes;
+  return SWA_OK;
+}
+// page-locked block: [ctl copy + eager candidates | query upload area]
+constexpr size_t PIN_CTL_BYTES = CTL_INTS * sizeof(int32_t) + size_t(CAND_EAGER) * sizeof(swa_cand);
+
+// counters (+ the first `ncand` candidate records) to the host, then wait for the stream: the one synchronisation
+int sync_ctl(swa_db* db, int ncand, hipStream_t st)
+{
+  HIP_TRY(hipMemcpyAsync(db->pin, db->ctl.p, CTL_INTS * sizeof(int32_t) + size_t(ncand) * sizeof(swa_cand),
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return SWA_OK;
+}
+
+// query (+ its descriptor for the first-pass kernel) in ONE copy out of page-locked memory:
+// device layout of db->qblock = [swa_query | residues of query 1 | residues of query 2]
+int upload_queries(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, hipStream_t st)
+{
+  const size_t qpad = (size_t(qlen) + 15) & ~size_t(15);
+  const size_t bytes = 32 + qpad * (q2 ? 2 : 1);
+  int rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 2 * std::max<size_t>(qpad, 4096));
+  if (rc != SWA_OK) return rc;
+  HIP_TRY(db->qblock.reserve(32 + 2 * std::max<size_t>(qpad, 4096)));
+  unsigned char* h = db->pin + PIN_CTL_BYTES;
+  db->qseq_p = db->qblock.p + 32;
+  db->qseq2_p = db->qblock.p + 32 + qpad;
+  swa_query hq{db->qseq_p, db->matrix.p, int32_t(qlen)};
+  std::memset(h, 0, 32);
+  std::memcpy(h, &hq, sizeof hq);
+  std::memcpy(h + 32, q1, size_t(qlen));
+  if (q2) std::memcpy(h + 32 + qpad, q2, size_t(qlen));
+  HIP_TRY(hipMemcpyAsync(db->qblock.p, h, bytes, hipMemcpyHostToDevice, st));
+  return SWA_OK;
+}
+
 int read_requeue(swa_db* db, int ctl_index, const int32_t* list, std::vector<int32_t>& out, hipStream_t st)
 {
   int32_t n = 0;
@@ -618,21 +768,31 @@ int read_requeue(swa_db* db, int ctl_index, const int32_t* list, std::vector<int
   return SWA_OK;
 }
 
-// 32-bit then 64-bit kernels over a re-queue list, one query; results land in `scores`
-// (64-bit values in db->scores64 with the sentinel in `scores`).
+// int32 is exact for a wave per sequence when qlen x highest score stays below 2^30 (then nothing can reach the
+// 64-bit hop either)
+bool wave_requeue_ok(const swa_db* db, int64_t qlen)
+{
+  return db->opt.wave_requeue != 0 && qlen < (int64_t(1) << 24) &&
+         std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1) < (int64_t(1) << 30) &&
+         db->goe < (int64_t(1) << 30) && db->ge < (int64_t(1) << 30);
+}
+// ... and the list can be worked off without the host ever seeing it when one pass of the wave kernel holds the query
+bool device_requeue_ok(const swa_db* db, int64_t qlen)
+{
+  return wave_requeue_ok(db, qlen) && !db->opt.requeue_host && qlen <= 64 * swa_endpoints_rows_for(int(qlen));
+}
+
+// 32-bit then 64-bit kernels over a re-queue list the host holds, one query; results land in `scores`
+// (64-bit values in `s64` with the sentinel in `scores`).
 int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int64_t qlen, int32_t* scores,
-             int64_t* n32, int64_t* n64, hipStream_t st)
+             DevBuf<long long>& s64, int64_t* n32, int64_t* n64, hipStream_t st)
 {
   // A short list is latency-bound in the batch kernels (one 16-lane chain per sequence, the longest sequence sets the
   // time): a wave per sequence - the end-point kernel of the alignment phase, 64 lanes on one sequence - finishes the
   // 1 500 sequences the bound build sends back for the bench query in 1.3 ms instead of 1.5, the 390 of a 5 000-row
-  // query in a fraction of the batch kernel's 20 passes.  int32 is exact when
-  // qlen x highest score stays below 2^30 (then nothing can reach the 64-bit hop either).
-  const char* wq = std::getenv("SWA_WAVE_REQUEUE");
-  bool by_wave = !requeue.empty() && requeue.size() <= (size_t(1) << 16) && int64_t(requeue.size()) < db->nseq &&
-                 qlen < (int64_t(1) << 24) && !(wq && std::atoi(wq) == 0) &&
-                 std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1) < (int64_t(1) << 30) &&
-                 db->goe < (int64_t(1) << 30) && db->ge < (int64_t(1) << 30);
+  // query in a fraction of the batch kernel's 20 passes.
+  bool by_wave = !requeue.empty() && requeue.size() <= size_t(REQUEUE_CAP) && int64_t(requeue.size()) < db->nseq &&
+                 wave_requeue_ok(db, qlen);
   const bool passes = by_wave && qlen > 64 * swa_endpoints_rows_for(int(qlen));   // over 2 048 rows: hand-over per column
   std::vector<int64_t> boff;
   int64_t columns = 0;
@@ -673,13 +833,14 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
       const int rc = build_batches(db, ordered.data(), int64_t(ordered.size()), 1, db->scratch);
       if (rc != SWA_OK) return rc;
     }
-    if (bits == 64) HIP_TRY(db->scores64.reserve(size_t(db->nseq)));
+    if (bits == 64) HIP_TRY(s64.reserve(size_t(db->nseq)));
     HIP_TRY(hipMemsetAsync(db->ctl.p + 1, 0, sizeof(int32_t), st));
     MpRun r;
     r.mode = bits == 32 ? 2 : 3;
     r.set = set;
     r.q1 = qdev;
     r.scores = scores;
+    r.scores64 = s64.p;
     r.ovf_count = db->ctl.p + 1;
     r.ovf_list = db->ovf_list.p;
     const int rc = launch_mp_run(db, r, qlen, st);
@@ -711,8 +872,26 @@ bool f16_applicable(const swa_db* db)
   return db->hi >= 0 && db->hi < 512 && db->lo > -1024 && db->goe >= db->ge && db->goe <= 1024 && db->ge >= 0 &&
          db->ge <= 16;
 }
+// Chains shorter than a DPP row isolate neighbouring sequences by multiplying what a chain's last lane sends by zero
+// (v_pk_fma_f16): a state that overflowed to +-inf would turn that zero into NaN and poison the NEIGHBOUR, whose score
+// would then read 0 and never be re-queued.  f16 reaches inf beyond 65504; every value is bounded by
+// min(qlen, longest) x hi + the row / column bias, so such searches take 16-lane chains (zero fill by DPP, no product).
+bool short_chains_safe(const swa_db* db, int64_t qlen)
+{
+  const int64_t reach = std::min<int64_t>(qlen, std::max<int64_t>(db->longest, 1)) * std::max<int64_t>(db->hi, 1);
+  return reach + 80 * db->ge + db->goe < 60000;
+}
 
-int finish_empty(swa_db* db, swa_counters_t& c, swa_counters_t* counters, bool two, hipStream_t st)
+// What a search has enqueued and not yet seen on the host
+struct Pending {
+  swa_counters_t c{};
+  bool used_bound = false;
+  bool dev1 = false, dev2 = false;   // the re-queue list of query 1 / 2 was worked off by the device-driven kernel
+  bool two = false;
+  bool empty = false;
+};
+
+int finish_empty(swa_db* db, Pending& pd, bool two, hipStream_t st)
 {
   if (db->nseq) {
     HIP_TRY(hipMemsetAsync(db->scores.p, 0, size_t(db->nseq) * sizeof(int32_t), st));
@@ -723,58 +902,69 @@ int finish_empty(swa_db* db, swa_counters_t& c, swa_counters_t* counters, bool t
     }
     HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   }
-  HIP_TRY(hipStreamSynchronize(st));
-  if (counters) *counters = c;
+  HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
+  pd.empty = true;
+  pd.two = two;
   return SWA_OK;
 }
 
-// the escalation loop: packed f16 -> 32 bit -> 64 bit.  Scores end up in db->scores / scores64.
+bool bound_wanted(const swa_db* db, int64_t qlen, int64_t bound_min)
+{
+  const int Nb = swa_bound_period();
+  if (bound_min <= 0 || db->opt.bound == 0) return false;
+  if (db->opt.bound == 1) return true;
+  return !db->bound_is_off(qlen, bound_min) && bound_min >= 4 * int64_t(Nb) * db->ge &&
+         bound_min > int64_t(Nb + 2) * db->ge + db->goe;
+}
+
+// the escalation loop: packed f16 -> 32 bit -> 64 bit.  Scores end up in db->scores / scores64.  Everything is
+// ENQUEUED on the handle's stream; the caller synchronises (sync_ctl) and calls settle_search.
 // bound_min > 0: the caller only wants the sequences scoring at least bound_min (top-K searches); the first pass may
 // then be the bound build of the kernel (sw_cb_kernels.hip), which leaves placeholders below bound_min for the rest
-int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* counters, int64_t bound_min = 0)
+int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min, Pending& pd)
 {
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
-  swa_counters_t c{};
+  pd = Pending{};
+  swa_counters_t& c = pd.c;
   c.cells = db->active_sym * qlen;
-  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, c, counters, false, st);
+  rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 8192);
+  if (rc != SWA_OK) return rc;
+  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, false, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
-  HIP_TRY(db->qseq.reserve(size_t(qlen)));
-  HIP_TRY(hipMemcpyAsync(db->qseq.p, query, size_t(qlen), hipMemcpyHostToDevice, st));
-  swa_query hq{db->qseq.p, db->matrix.p, int32_t(qlen)};
-  HIP_TRY(hipMemcpyAsync(db->query.p, &hq, sizeof hq, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(db->ctl.p, 0, 8 * sizeof(int32_t), st));
+  rc = upload_queries(db, query, nullptr, qlen, st);
+  if (rc != SWA_OK) return rc;
+  const swa_query* dquery = reinterpret_cast<const swa_query*>(db->qblock.p);
+  HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
 
   std::vector<int32_t> requeue;
   bool used_bound = false;
   const bool f16 = f16_applicable(db);
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
-  const bool force_mp = std::getenv("SWA_FORCE_MP") && std::atoi(std::getenv("SWA_FORCE_MP")) == 1;
+  const bool force_mp = db->opt.force_mp == 1;
   const bool single_pass = qlen <= 16 * 58 && K > 0 && !force_mp;
   HIP_TRY(hipEventRecord(db->ev[1], st));
   // G = 2 (up to 40 rows), 4 (up to 192), 8 (up to 384) or 16 (up to 928) lanes per sequence pair, K = ceil(qlen / G)
-  // rows per lane (SWA_LANES = 2 / 4 / 8 / 16 picks the chain length if the query fits it: A/B runs and tests)
+  // rows per lane (option "lanes" = 2 / 4 / 8 / 16 picks the chain length if the query fits it: A/B runs and tests)
   // (2 lanes: measured ahead of 4 up to 40 rows - 10 aa 4.5 -> 5.7, 30 aa 7.3 -> 7.9 TCUPS - and level or behind beyond)
   int G = qlen <= 40 ? 2 : qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
   // Bound build (top-K searches, see below): wanted when the threshold is far enough above its slack.  It keeps two
   // values per row instead of three, and with them 2-lane chains stay ahead of 4 lanes up to 96 rows (+2..8 %)
   const int Nb = swa_bound_period();
-  const char* be = std::getenv("SWA_BOUND");
-  const int bmode = be ? std::atoi(be) : -1;           // 0 never, 1 whenever a build exists
-  const bool bound_wanted = bound_min > 0 && bmode != 0 &&
-      (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
-  if (bound_wanted && qlen <= 2 * 48) G = 2;
-  if (const char* e = std::getenv("SWA_LANES")) {
-    G = std::atoi(e) >= 16 ? 16 : std::atoi(e) >= 8 ? 8 : std::atoi(e) >= 4 ? 4 : 2;
+  const bool want_bound = bound_wanted(db, qlen, bound_min);
+  if (want_bound && qlen <= 2 * 48) G = 2;
+  if (db->opt.lanes > 0) {
+    G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : 2;
     while (G < 16 && qlen > G * 48) G *= 2;
   }
+  if (G < 16 && !short_chains_safe(db, qlen) && qlen <= 16 * 58) G = 16;
   const int Kg = swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
-  if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->narrow_variant != 1) {
+  if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->opt.narrow_variant != 1) {
     const int K = Kg;
     swa_narrow_params p{};
-    p.query = db->query.p;
+    p.query = dquery;
     p.stream = db->main.stream.p;
     p.batches = db->main.batches.p;
     p.slots = db->main.slots.p;
@@ -796,14 +986,13 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     const int per_wave = 16 / G;                                    // a wave takes 16 / G batches at a time
     const int items = (p.nbatches + per_wave - 1) / per_wave;
     int blocks = persistent_blocks(db, items);
-    p.pipe = -1;
-    if (const char* w = std::getenv("SWA_PIPE")) p.pipe = std::atoi(w);
-    if (const char* w = std::getenv("SWA_BLOCKS_PER_CU")) blocks = std::max(1, std::min((items + 3) / 4, db->cus * std::atoi(w)));
-    // Bound build (6.5 instead of 7.5 instructions per cell pair): its result is at most (period - 1) R above the score,
+    p.pipe = int32_t(db->opt.pipe);
+    if (db->opt.blocks_per_cu > 0) blocks = std::max(1, std::min((items + 3) / 4, db->cus * int(db->opt.blocks_per_cu)));
+    // Bound build (6 instead of 7.5 instructions per cell pair): its result is at most (period - 1) R above the score,
     // everything at or above bound_min is recomputed by the 32-bit kernel.  Used when the threshold is far enough above
-    // that slack for the recomputed share to be negligible (SWA_BOUND = 0 never, 1 whenever a build exists); if more
-    // than 2 % of the sequences come back it is switched off for this scoring system and the exact kernel runs
-    used_bound = bound_wanted && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
+    // that slack for the recomputed share to be negligible (option "bound" = 0 never, 1 whenever a build exists); if more
+    // than 2 % of the sequences come back it is switched off for this (query length, threshold) and the exact kernel runs
+    used_bound = want_bound && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
     if (used_bound) {
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
@@ -814,9 +1003,9 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
       HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));
     }
     c.narrow = db->nseq;
-  } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->narrow_variant == 1 || f16_limit(db, K) < 1024)) {
+  } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->opt.narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
-    p.query = db->query.p;
+    p.query = dquery;
     p.stream = db->main.stream.p;
     p.batches = db->main.batches.p;
     p.slots = db->main.slots.p;
@@ -834,7 +1023,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
   } else if (f16 && !force_mp && qlen > 16 * 58 && f16_limit(db, split_pass_rows(qlen)) >= 1024) {
     int np = 0, Kp = 0;                                // long query: passes of the tuned kernel, or of its bound build
     split_pass_shape(qlen, &np, &Kp);
-    used_bound = bound_wanted && f16_limit(db, Kp + Nb) >= 1024;
+    used_bound = want_bound && f16_limit(db, Kp + Nb) >= 1024;
     rc = launch_split_passes(db, qlen, st, used_bound, bound_min);
     if (rc != SWA_OK) return rc;
     c.narrow_rows = Kp;
@@ -844,7 +1033,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     MpRun r;                                           // multi-pass pair kernel (short passes: large gap-extension penalties)
     r.mode = 0;
     r.set = &db->main;
-    r.q1 = db->qseq.p;
+    r.q1 = db->qseq_p;
     r.scores = db->scores.p;
     r.ovf_count = db->ctl.p + 1;
     r.ovf_list = db->ovf_list.p;
@@ -855,72 +1044,77 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, swa_counters_t* c
     c.narrow = db->nseq;
   }
   HIP_TRY(hipEventRecord(db->ev[2], st));
-  if (c.narrow) {
-    rc = read_requeue(db, 1, db->ovf_list.p, requeue, st);
-    if (rc != SWA_OK) return rc;
-    if (used_bound && int64_t(requeue.size()) * 50 > db->nseq && !(std::getenv("SWA_BOUND") && std::atoi(std::getenv("SWA_BOUND")) == 1)) {
-      db->bound_off = true;                            // threshold too close to the bulk of the scores
-      return run_search(db, query, qlen, counters, 0);
-    }
+  pd.used_bound = used_bound;
+  if (c.narrow && device_requeue_ok(db, qlen)) {
+    // the list stays on the device: a persistent grid of waves takes entries off it until the count the first pass left
+    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
+                                    db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
+    pd.dev1 = true;
   } else {
-    requeue.assign(db->h_order.begin(), db->h_order.end());
+    if (c.narrow) {
+      rc = read_requeue(db, 1, db->ovf_list.p, requeue, st);
+      if (rc != SWA_OK) return rc;
+      if (used_bound && int64_t(requeue.size()) * 50 > db->nseq && db->opt.bound != 1) {
+        db->bound_off.emplace_back(qlen, bound_min);   // threshold too close to the bulk of the scores
+        return run_search(db, query, qlen, 0, pd);
+      }
+    } else {
+      requeue.assign(db->h_order.begin(), db->h_order.end());
+    }
+    rc = run_wide(db, requeue, db->qseq_p, qlen, db->scores.p, db->scores64, &c.wide, &c.full, st);
+    if (rc != SWA_OK) return rc;
   }
-  rc = run_wide(db, requeue, db->qseq.p, qlen, db->scores.p, &c.wide, &c.full, st);
-  if (rc != SWA_OK) return rc;
   HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(hipEventRecord(db->ev[3], st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, db->ev[1], db->ev[2]));
-  c.kernel_ms = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, db->ev[0], db->ev[3]));
-  c.total_ms = ms;
-  if (counters) *counters = c;
   return SWA_OK;
 }
 
 // Two queries of equal length against every sequence in one pass (nucleotide plus/minus strand).
-// Scores of query 1 end up in db->scores, of query 2 in db->scores2 (64-bit values in scores64
-// would collide between the two, so the 64-bit hop is only taken for query 1 - see below).
-int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, swa_counters_t* counters, int64_t bound_min = 0)
+// Scores of query 1 end up in db->scores (64-bit values in scores64), of query 2 in db->scores2 (scores64b).
+int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t bound_min, Pending& pd)
 {
   int rc = check_query(db, q1, qlen);
   if (rc == SWA_OK) rc = check_query(db, q2, qlen);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
-  swa_counters_t c{};
+  pd = Pending{};
+  pd.two = true;
+  swa_counters_t& c = pd.c;
   c.cells = 2 * db->active_sym * qlen;
-  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, c, counters, true, st);
+  rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 8192);
+  if (rc != SWA_OK) return rc;
+  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, true, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
-  HIP_TRY(db->qseq.reserve(size_t(qlen)));
-  HIP_TRY(db->qseq2.reserve(size_t(qlen)));
   HIP_TRY(db->scores2.reserve(size_t(db->nseq)));
   HIP_TRY(db->ovf_list2.reserve(size_t(db->nseq)));
-  HIP_TRY(hipMemcpyAsync(db->qseq.p, q1, size_t(qlen), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(db->qseq2.p, q2, size_t(qlen), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(db->ctl.p, 0, 8 * sizeof(int32_t), st));
+  rc = upload_queries(db, q1, q2, qlen, st);
+  if (rc != SWA_OK) return rc;
+  HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
   rc = ensure_single(db);
   if (rc != SWA_OK) return rc;
   std::vector<int32_t> rq1, rq2;
+  bool listed = false;                                   // the first pass left re-queue lists on the device
+  bool used_bound = false;
   HIP_TRY(hipEventRecord(db->ev[1], st));
   // single pass with the whole query in registers when it fits (nucleotide alphabets: 1008 rows, others 512);
-  // SWA_DUAL_MP=1 forces the multi-pass kernel (A/B, tests)
+  // option "dual_mp" = 1 forces the multi-pass kernel (A/B, tests)
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
-  const bool dual_mp = std::getenv("SWA_DUAL_MP") && std::atoi(std::getenv("SWA_DUAL_MP")) == 1;
+  const bool dual_mp = db->opt.dual_mp == 1;
   // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
   int Gd = qlen <= 2 * 32 ? 2 : qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
-  if (const char* e = std::getenv("SWA_LANES")) {
-    Gd = std::atoi(e) >= 16 ? 16 : std::atoi(e) >= 8 ? 8 : std::atoi(e) >= 4 ? 4 : 2;
+  if (db->opt.lanes > 0) {
+    Gd = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : 2;
     while (Gd < 16 && qlen > Gd * 32) Gd *= 2;
   }
+  if (Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
   int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
-  if (const char* e = std::getenv("SWA_DUAL_KMAX")) if (Kd > std::atoi(e)) Kd = 0;
+  if (db->opt.dual_kmax > 0 && Kd > db->opt.dual_kmax) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     const BatchSet& set = Gd == 16 ? db->single : db->main;
     swa_mp_params p{};
-    p.qseq = db->qseq.p;
-    p.qseq2 = db->qseq2.p;
+    p.qseq = db->qseq_p;
+    p.qseq2 = db->qseq2_p;
     p.matrix = db->matrix.p;
     p.qlen = int32_t(qlen);
     p.rows_per_lane = Kd;
@@ -944,10 +1138,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     for (int i = 0; i <= Kd + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
     // bound build (sw_cb_dual.hip) under the same rule as in run_search
     const int Nb = swa_bound_period();
-    const char* be = std::getenv("SWA_BOUND");
-    const int bmode = be ? std::atoi(be) : -1;
-    const bool used_bound = bound_min > 0 && bmode != 0 && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024 &&
-                            (bmode == 1 || (!db->bound_off && bound_min >= 4 * int64_t(Nb) * db->ge && bound_min > int64_t(Nb + 2) * db->ge + db->goe));
+    used_bound = bound_wanted(db, qlen, bound_min) && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024;
     if (used_bound) {
       p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
       for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
@@ -958,30 +1149,20 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     c.narrow_rows = Kd;
     c.narrow_shifted = used_bound ? 10 : 4;              // single-pass dual kernel / its bound build
     c.narrow = db->nseq;
-    HIP_TRY(hipEventRecord(db->ev[2], st));
-    rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
-    if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
-    if (rc != SWA_OK) return rc;
-    if (used_bound && int64_t(rq1.size() + rq2.size()) * 50 > 2 * db->nseq && bmode != 1) {
-      db->bound_off = true;
-      return run_search2(db, q1, q2, qlen, counters, 0);
-    }
+    listed = true;
   } else if (f16_applicable(db) && !dual_mp && Gd == 16 && f16_limit(db, dual_pass_rows(qlen, nres)) >= 1024) {
     rc = launch_dual_passes(db, qlen, nres, st);         // long queries: one launch per pass of the same kernel
     if (rc != SWA_OK) return rc;
     c.narrow_rows = dual_pass_rows(qlen, nres);
     c.narrow_shifted = 6;
     c.narrow = db->nseq;
-    HIP_TRY(hipEventRecord(db->ev[2], st));
-    rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
-    if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
-    if (rc != SWA_OK) return rc;
+    listed = true;
   } else if (f16_applicable(db) && f16_limit(db, mp_rows_for(1, qlen)) >= 1024) {
     MpRun r;
     r.mode = 1;
     r.set = &db->single;
-    r.q1 = db->qseq.p;
-    r.q2 = db->qseq2.p;
+    r.q1 = db->qseq_p;
+    r.q2 = db->qseq2_p;
     r.scores = db->scores.p;
     r.scores2 = db->scores2.p;
     r.ovf_count = db->ctl.p + 1;
@@ -993,31 +1174,103 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     c.narrow_rows = mp_rows_for(1, qlen);
     c.narrow_shifted = 1;
     c.narrow = db->nseq;
-    HIP_TRY(hipEventRecord(db->ev[2], st));
-    rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
-    if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
-    if (rc != SWA_OK) return rc;
-  } else {
-    HIP_TRY(hipEventRecord(db->ev[2], st));
-    rq1.assign(db->h_order.begin(), db->h_order.end());
-    rq2 = rq1;
+    listed = true;
   }
-  int64_t full2 = 0;
-  rc = run_wide(db, rq1, db->qseq.p, qlen, db->scores.p, &c.wide, &c.full, st);
-  if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2.p, qlen, db->scores2.p, &c.wide, &full2, st);
-  if (rc != SWA_OK) return rc;
-  if (full2) return fail(SWA_ERANGE, "second query needs the 64-bit kernel; search the two queries separately");
+  HIP_TRY(hipEventRecord(db->ev[2], st));
+  pd.used_bound = used_bound;
+  if (listed && device_requeue_ok(db, qlen)) {
+    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
+                                    db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
+    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list2.p, db->ctl.p + 3, REQUEUE_CAP, db->ctl.p + 5,
+                                    db->qseq2_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores2.p, db->cus * 8, st));
+    pd.dev1 = pd.dev2 = true;
+  } else {
+    if (listed) {
+      rc = read_requeue(db, 1, db->ovf_list.p, rq1, st);
+      if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
+      if (rc != SWA_OK) return rc;
+      if (used_bound && int64_t(rq1.size() + rq2.size()) * 50 > 2 * db->nseq && db->opt.bound != 1) {
+        db->bound_off.emplace_back(qlen, bound_min);
+        return run_search2(db, q1, q2, qlen, 0, pd);
+      }
+    } else {
+      rq1.assign(db->h_order.begin(), db->h_order.end());
+      rq2 = rq1;
+    }
+    int64_t full2 = 0;
+    rc = run_wide(db, rq1, db->qseq_p, qlen, db->scores.p, db->scores64, &c.wide, &c.full, st);
+    if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2_p, qlen, db->scores2.p, db->scores64b, &c.wide, &full2, st);
+    if (rc != SWA_OK) return rc;
+    c.full += full2;
+  }
   HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(swa_launch_mark_excluded(db->scores2.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(hipEventRecord(db->ev[3], st));
-  HIP_TRY(hipStreamSynchronize(st));
+  return SWA_OK;
+}
+
+// After sync_ctl: what the device-driven re-queue could not know.  *again: the search must be repeated (the bound
+// build sent back too much - it is now off for this query length and threshold); *changed: scores were rewritten
+// after the caller's filter ran, so the filter must run again.
+int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t bound_min,
+                  bool* again, bool* changed)
+{
+  *again = *changed = false;
+  hipStream_t st = db->stream;
+  if (pd.empty) return SWA_OK;
+  const int64_t n1 = pd.dev1 ? ctl_host(db)[1] : 0, n2 = pd.dev2 ? ctl_host(db)[3] : 0;
+  if (pd.dev1 || pd.dev2) {
+    const int64_t lists = pd.dev2 ? 2 : 1;
+    if (pd.used_bound && (n1 + n2) * 50 > lists * db->nseq && db->opt.bound != 1) {
+      db->bound_off.emplace_back(qlen, bound_min);
+      *again = true;
+      return SWA_OK;
+    }
+    // lists beyond the device-driven kernel's reach (it stopped at REQUEUE_CAP entries): the host takes them whole
+    for (int which = 0; which < 2; ++which) {
+      const int64_t n = which ? n2 : n1;
+      if (n <= REQUEUE_CAP) { pd.c.wide += n; continue; }
+      std::vector<int32_t> list(static_cast<size_t>(n));
+      HIP_TRY(hipMemcpy(list.data(), which ? db->ovf_list2.p : db->ovf_list.p, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      std::sort(list.begin(), list.end());
+      int64_t full = 0;
+      const int rc = run_wide(db, list, which ? db->qseq2_p : db->qseq_p, qlen, which ? db->scores2.p : db->scores.p,
+                              which ? db->scores64b : db->scores64, &pd.c.wide, &full, st);
+      if (rc != SWA_OK) return rc;
+      pd.c.full += full;
+      HIP_TRY(swa_launch_mark_excluded(which ? db->scores2.p : db->scores.p, db->excluded.p, int(db->n_excluded), st));
+      *changed = true;
+    }
+    if (*changed) {
+      HIP_TRY(hipEventRecord(db->ev[3], st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, db->ev[1], db->ev[2]));
-  c.kernel_ms = ms;
+  pd.c.kernel_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, db->ev[0], db->ev[3]));
-  c.total_ms = ms;
-  if (counters) *counters = c;
+  pd.c.total_ms = ms;
+  (void)q1; (void)q2;
   return SWA_OK;
+}
+
+// all scores of one / two queries on the device, host informed: the body of swa_search / swa_search2
+int search_all(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, swa_counters_t* counters)
+{
+  for (;;) {
+    Pending pd;
+    int rc = q2 ? run_search2(db, q1, q2, qlen, 0, pd) : run_search(db, q1, qlen, 0, pd);
+    if (rc != SWA_OK) return rc;
+    rc = sync_ctl(db, 0, db->stream);
+    if (rc != SWA_OK) return rc;
+    bool again = false, changed = false;
+    rc = settle_search(db, pd, q1, q2, qlen, 0, &again, &changed);
+    if (rc != SWA_OK) return rc;
+    if (again) continue;
+    if (counters) *counters = pd.c;
+    return SWA_OK;
+  }
 }
 
 bool hit_before(const swa_hit_t& a, const swa_hit_t& b)   // hits.cc:188-190: score desc, then seqno desc
@@ -1051,7 +1304,7 @@ extern "C" int swa_db_from_memory(const uint8_t* residues, const int64_t* offset
   if (!db) return fail(SWA_ENOMEM, "out of host memory");
   db->device = device;
   db->symtype = symtype;
-  if (const char* v = std::getenv("SWA_NARROW_VARIANT")) db->narrow_variant = std::atoi(v);
+  options_from_environment(db->opt);
   db->first_seqno = first_seqno;
   const int rc = ingest(db, residues, offsets, nseq);
   if (rc != SWA_OK) { delete db; return rc; }
@@ -1100,7 +1353,7 @@ extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const i
   db->device = device;
   db->symtype = SWA_SYMTYPE_PROTEIN;
   db->frames = 6;
-  if (const char* v = std::getenv("SWA_NARROW_VARIANT")) db->narrow_variant = std::atoi(v);
+  options_from_environment(db->opt);
   db->first_seqno = first_seqno;
   // virtual offsets: frame f of either strand holds (len - f) / 3 residues (database.cc:1188)
   const int64_t base = offsets[0];
@@ -1282,7 +1535,7 @@ extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapope
   HIP_TRY(hipMemcpyAsync(db->matrix.p, db->h_matrix, sizeof db->h_matrix, hipMemcpyHostToDevice, db->stream));
   HIP_TRY(hipStreamSynchronize(db->stream));
   db->scoring_set = true;
-  db->bound_off = false;
+  db->bound_off.clear();
   return SWA_OK;
 }
 
@@ -1291,38 +1544,25 @@ extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_
 namespace {
 struct Cand { int64_t seqno, score; int32_t which, dtag; };
 
-// hits_enter acceptance test over one score array on the device; appends the survivors
-int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t keep, int64_t minscore,
-                       int64_t maxscore, std::vector<Cand>& cand, int64_t* totalhits, int64_t* obvious)
+// hits_enter acceptance test (hits.cc:174-184) over one / two score arrays: ENQUEUES the counter reset and the filter
+// kernel(s); candidates of both arrays land in the same record list, tagged 0 / 1
+int enqueue_filter(swa_db* db, bool two, int64_t minscore, int64_t maxscore, hipStream_t st)
 {
-  hipStream_t st = db->stream;
-  const int cap = int(std::min<int64_t>(db->nseq, std::max<int64_t>(1 << 20, 8 * keep)));
-  HIP_TRY(db->cand_idx.reserve(size_t(cap)));
-  HIP_TRY(db->cand_score.reserve(size_t(cap)));
-  HIP_TRY(hipMemsetAsync(db->ctl.p + 2, 0, sizeof(int32_t), st));
-  HIP_TRY(hipMemsetAsync(db->tallies.p, 0, 2 * sizeof(unsigned long long), st));
-  HIP_TRY(swa_launch_filter(scores, db->scores64.p, int(db->nseq), minscore, maxscore, db->ctl.p + 2, cap,
-                            db->cand_idx.p, db->cand_score.p, db->tallies.p, st));
-  int32_t ncand = 0;
-  unsigned long long tl[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(&ncand, db->ctl.p + 2, sizeof ncand, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(tl, db->tallies.p, sizeof tl, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  *totalhits += int64_t(tl[0]);
-  *obvious += int64_t(tl[1]);
-  if (ncand <= cap) {
-    std::vector<int32_t> idx((size_t(ncand)));
-    std::vector<long long> sc((size_t(ncand)));
-    if (ncand) {
-      HIP_TRY(hipMemcpy(idx.data(), db->cand_idx.p, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(sc.data(), db->cand_score.p, sc.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    }
-    for (int i = 0; i < ncand; ++i)
-      cand.push_back({db->first_seqno + idx[size_t(i)] / db->frames, sc[size_t(i)], which, idx[size_t(i)] % db->frames});
-    return SWA_OK;
-  }
-  // more candidates than the compaction buffer (a very permissive threshold): take every score to the host, find
-  // the score of the keep-th best accepted entry from a histogram and keep only what can still make the list
+  HIP_TRY(hipMemsetAsync(db->ctl.p + CTL_CAND, 0, (CTL_INTS - CTL_CAND) * sizeof(int32_t), st));
+  unsigned long long* tallies = reinterpret_cast<unsigned long long*>(db->ctl.p + CTL_TALLY);
+  HIP_TRY(swa_launch_filter(db->scores.p, db->scores64.p, int(db->nseq), 0, minscore, maxscore, db->ctl.p + CTL_CAND,
+                            db->cand_cap, cand_dev(db), tallies, st));
+  if (two)
+    HIP_TRY(swa_launch_filter(db->scores2.p, db->scores64b.p, int(db->nseq), 1, minscore, maxscore, db->ctl.p + CTL_CAND,
+                              db->cand_cap, cand_dev(db), tallies, st));
+  return SWA_OK;
+}
+
+// more candidates than the compaction buffer (a very permissive threshold): take every score to the host, find
+// the score of the keep-th best accepted entry from a histogram and keep only what can still make the list
+int candidates_by_histogram(swa_db* db, const int32_t* scores, const long long* scores64, int32_t which, int32_t tag,
+                            int64_t keep, int64_t minscore, int64_t maxscore, std::vector<Cand>& cand)
+{
   std::vector<int32_t> s32(size_t(db->nseq));
   HIP_TRY(hipMemcpy(s32.data(), scores, s32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
   std::vector<long long> s64;
@@ -1333,7 +1573,7 @@ int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t
   for (int64_t i = 0; i < db->nseq && s64.empty(); ++i)
     if (s32[size_t(i)] == SWA_SCORE_IN_64) {
       s64.resize(size_t(db->nseq));
-      HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(s64.data(), scores64, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
     }
   constexpr int64_t BINS = 1 << 16;
   std::vector<int64_t> hist(size_t(BINS), 0);
@@ -1346,11 +1586,42 @@ int collect_candidates(swa_db* db, const int32_t* scores, int32_t which, int64_t
     seen += hist[size_t(b)];
     if (seen >= keep) { floor_score = std::max(minscore, b == BINS - 1 ? minscore : b); break; }
   }
+  (void)which;
   for (int64_t i = 0; i < db->nseq; ++i) {
     const int64_t v = value(i);
-    if (v >= floor_score && v <= maxscore) cand.push_back({db->first_seqno + i / db->frames, v, which, int32_t(i % db->frames)});
+    if (v >= floor_score && v <= maxscore) cand.push_back({db->first_seqno + i / db->frames, v, tag, int32_t(i % db->frames)});
   }
   return SWA_OK;
+}
+
+// after sync_ctl(db, CAND_EAGER): the filter's results out of the page-locked block (tag0 / tag1 = the `which` value
+// the caller wants on candidates of the first / second score array)
+int gather_candidates(swa_db* db, bool two, int32_t tag0, int32_t tag1, int64_t keep, int64_t minscore, int64_t maxscore,
+                      std::vector<Cand>& cand, int64_t* totalhits, int64_t* obvious)
+{
+  const int32_t* h = ctl_host(db);
+  const int64_t ncand = h[CTL_CAND];
+  unsigned long long tl[2];
+  std::memcpy(tl, h + CTL_TALLY, sizeof tl);
+  *totalhits += int64_t(tl[0]);
+  *obvious += int64_t(tl[1]);
+  if (ncand <= db->cand_cap) {
+    const swa_cand* rec = reinterpret_cast<const swa_cand*>(db->pin + CTL_INTS * sizeof(int32_t));
+    std::vector<swa_cand> rest;
+    if (ncand > CAND_EAGER) {                              // beyond what came back with the counters
+      rest.resize(size_t(ncand));
+      HIP_TRY(hipMemcpy(rest.data(), cand_dev(db), rest.size() * sizeof(swa_cand), hipMemcpyDeviceToHost));
+      rec = rest.data();
+    }
+    cand.reserve(cand.size() + size_t(ncand));
+    for (int64_t i = 0; i < ncand; ++i)
+      cand.push_back({db->first_seqno + rec[i].idx / db->frames, rec[i].score, rec[i].which ? tag1 : tag0,
+                      int32_t(rec[i].idx % db->frames)});
+    return SWA_OK;
+  }
+  int rc = candidates_by_histogram(db, db->scores.p, db->scores64.p, 0, tag0, keep, minscore, maxscore, cand);
+  if (rc == SWA_OK && two) rc = candidates_by_histogram(db, db->scores2.p, db->scores64b.p, 1, tag1, keep, minscore, maxscore, cand);
+  return rc;
 }
 
 // hits.cc:188-190 (score desc, seqno desc); entries of query 1 were entered before those of
@@ -1363,7 +1634,43 @@ bool cand_before(const Cand& a, const Cand& b)
   return a.dtag < b.dtag;      // frames of one sequence are entered in start_list order (swipe.cc:1379-1384)
 }
 
-int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
+// One top-K search of one / two queries: first pass, re-queues and the hit filter are enqueued back to back, ONE
+// copy brings counters and candidates into page-locked memory, ONE synchronisation.  Candidates are appended to
+// `cand` with `which` = tag0 / tag1.
+int search_candidates(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t keep, int64_t minscore,
+                      int64_t maxscore, int32_t tag0, int32_t tag1, std::vector<Cand>& cand, int64_t* totalhits,
+                      int64_t* obvious, swa_counters_t* counters)
+{
+  hipStream_t st = db ? db->stream : nullptr;
+  for (;;) {
+    Pending pd;
+    int rc = q2 ? run_search2(db, q1, q2, qlen, minscore, pd) : run_search(db, q1, qlen, minscore, pd);
+    if (rc != SWA_OK) return rc;
+    if (db->nseq) {
+      rc = enqueue_filter(db, q2 != nullptr, minscore, maxscore, st);
+      if (rc != SWA_OK) return rc;
+    }
+    rc = sync_ctl(db, db->nseq ? std::min(CAND_EAGER, db->cand_cap) : 0, st);
+    if (rc != SWA_OK) return rc;
+    bool again = false, changed = false;
+    rc = settle_search(db, pd, q1, q2, qlen, minscore, &again, &changed);
+    if (rc != SWA_OK) return rc;
+    if (again) continue;
+    if (changed && db->nseq) {
+      rc = enqueue_filter(db, q2 != nullptr, minscore, maxscore, st);
+      if (rc == SWA_OK) rc = sync_ctl(db, std::min(CAND_EAGER, db->cand_cap), st);
+      if (rc != SWA_OK) return rc;
+    }
+    if (db->nseq) {
+      rc = gather_candidates(db, q2 != nullptr, tag0, tag1, keep, minscore, maxscore, cand, totalhits, obvious);
+      if (rc != SWA_OK) return rc;
+    }
+    if (counters) *counters = pd.c;
+    return SWA_OK;
+  }
+}
+
+int download_scores(swa_db* db, const int32_t* dev, const DevBuf<long long>& dev64, int64_t* out)
 {
   // the int32 scores land in a host buffer the handle keeps and are widened into the caller's int64 array by a few
   // threads on disjoint ranges
@@ -1392,9 +1699,9 @@ int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
   }
   bool any = false;
   for (uint8_t w : wide) any |= w != 0;
-  if (any) {                                               // scores beyond 32 bits live in scores64
+  if (any) {                                               // scores beyond 32 bits live in the 64-bit array
     std::vector<long long> s64((size_t(n)));
-    HIP_TRY(hipMemcpy(s64.data(), db->scores64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s64.data(), dev64.p, s64.size() * sizeof(long long), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i)
       if (out[i] == SWA_SCORE_IN_64) out[i] = s64[size_t(i)];
   }
@@ -1404,9 +1711,9 @@ int download_scores(swa_db* db, const int32_t* dev, int64_t* out)
 
 extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters)
 {
-  const int rc = run_search(db, query, qlen, counters);
+  const int rc = search_all(db, query, nullptr, qlen, counters);
   if (rc != SWA_OK || !scores || db->nseq == 0) return rc;
-  return download_scores(db, db->scores.p, scores);
+  return download_scores(db, db->scores.p, db->scores64, scores);
 }
 
 extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore,
@@ -1415,15 +1722,11 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
 {
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
-  int rc = run_search(db, query, qlen, counters, minscore);
-  if (rc != SWA_OK) return rc;
   *nhits = 0;
   int64_t tot = 0, obv = 0;
   std::vector<Cand> cand;
-  if (db->nseq) {
-    rc = collect_candidates(db, db->scores.p, 0, keep, minscore, maxscore, cand, &tot, &obv);
-    if (rc != SWA_OK) return rc;
-  }
+  const int rc = search_candidates(db, query, nullptr, qlen, keep, minscore, maxscore, 0, 0, cand, &tot, &obv, counters);
+  if (rc != SWA_OK) return rc;
   if (totalhits) *totalhits = tot;
   if (obvious) *obvious = obv;
   const size_t k = std::min<size_t>(size_t(keep), cand.size());
@@ -1436,10 +1739,11 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
 extern "C" int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
                            int64_t* scores1, int64_t* scores2, swa_counters_t* counters)
 {
-  int rc = run_search2(db, query1, query2, qlen, counters);
+  if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
+  int rc = search_all(db, query1, query2 ? query2 : query1, qlen, counters);
   if (rc != SWA_OK || db->nseq == 0) return rc;
-  if (scores1) rc = download_scores(db, db->scores.p, scores1);
-  if (rc == SWA_OK && scores2) rc = download_scores(db, db->scores2.p, scores2);
+  if (scores1) rc = download_scores(db, db->scores.p, db->scores64, scores1);
+  if (rc == SWA_OK && scores2) rc = download_scores(db, db->scores2.p, db->scores64b, scores2);
   return rc;
 }
 
@@ -1449,16 +1753,13 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
 {
   if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
-  int rc = run_search2(db, query1, query2, qlen, counters, minscore);
-  if (rc != SWA_OK) return rc;
+  if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
   *nhits = 0;
   int64_t tot = 0, obv = 0;
   std::vector<Cand> cand;
-  if (db->nseq) {
-    rc = collect_candidates(db, db->scores.p, 0, keep, minscore, maxscore, cand, &tot, &obv);
-    if (rc == SWA_OK) rc = collect_candidates(db, db->scores2.p, 1, keep, minscore, maxscore, cand, &tot, &obv);
-    if (rc != SWA_OK) return rc;
-  }
+  const int rc = search_candidates(db, query1, query2 ? query2 : query1, qlen, keep, minscore, maxscore, 0, 1, cand, &tot,
+                                   &obv, counters);
+  if (rc != SWA_OK) return rc;
   if (totalhits) *totalhits = tot;
   if (obvious) *obvious = obv;
   const size_t k = std::min<size_t>(size_t(keep), cand.size());
@@ -1484,18 +1785,10 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
   // frames of equal length share a pass in the two halves of the packed lanes
   for (int i = 0; i < nq;) {
     swa_counters_t c{};
-    bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
-    int rc = pair ? run_search2(db, queries[i], queries[i + 1], qlens[i], &c, minscore) : run_search(db, queries[i], qlens[i], &c, minscore);
-    if (pair && rc == SWA_ERANGE) {          // scores beyond 32 bits in the second half: one frame at a time
-      pair = false;
-      rc = run_search(db, queries[i], qlens[i], &c, minscore);
-    }
+    const bool pair = i + 1 < nq && qlens[i] == qlens[i + 1] && qlens[i] > 0;
+    const int rc = search_candidates(db, queries[i], pair ? queries[i + 1] : nullptr, qlens[i], keep, minscore, maxscore, i,
+                                     i + 1, cand, &tot, &obv, &c);
     if (rc != SWA_OK) return rc;
-    if (db->nseq) {
-      rc = collect_candidates(db, db->scores.p, i, keep, minscore, maxscore, cand, &tot, &obv);
-      if (rc == SWA_OK && pair) rc = collect_candidates(db, db->scores2.p, i + 1, keep, minscore, maxscore, cand, &tot, &obv);
-      if (rc != SWA_OK) return rc;
-    }
     sum.narrow += c.narrow; sum.wide += c.wide; sum.full += c.full; sum.cells += c.cells;
     sum.kernel_ms += c.kernel_ms; sum.total_ms += c.total_ms;
     sum.narrow_rows = c.narrow_rows; sum.narrow_shifted = c.narrow_shifted;
@@ -1512,6 +1805,20 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
   }
   *nhits = int64_t(k);
   return SWA_OK;
+}
+
+extern "C" int swa_set_option(swa_db* db, const char* key, const char* value)
+{
+  if (!db || !key) return fail(SWA_EINVAL, "null argument");
+  for (const OptionKey& k : kOptionKeys)
+    if (!std::strcmp(k.key, key)) {
+      int64_t v = 0;
+      if (!value) { db->opt.*(k.field) = Options{}.*(k.field); return SWA_OK; }     // NULL: back to the default
+      if (!parse_option_value(key, value, &v)) return fail(SWA_EINVAL, std::string("bad value for option ") + key);
+      db->opt.*(k.field) = v;
+      return SWA_OK;
+    }
+  return fail(SWA_EINVAL, std::string("unknown option ") + key);
 }
 
 namespace {
@@ -1562,8 +1869,7 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
   HIP_TRY(hipMemcpyAsync(d_minus.p, minus.data(), size_t(n), hipMemcpyHostToDevice, st));
   // one wave per sequence in int32 whenever no score can leave 32 bits; the one-thread 64-bit form otherwise
   const int64_t span = std::max<int64_t>(qlen, 1) * std::max<int64_t>(db->hi, 1);
-  const char* force = std::getenv("SWA_ENDPOINTS");          // "thread": the 64-bit one-thread kernel (A/B, tests)
-  if (!(force && !std::strcmp(force, "thread")) && span < (int64_t(1) << 30) && db->goe < (int64_t(1) << 30) &&
+  if (!db->opt.endpoints_thread && span < (int64_t(1) << 30) && db->goe < (int64_t(1) << 30) &&
       db->ge < (int64_t(1) << 30)) {
     const int rows = swa_endpoints_rows_for(int(qlen));
     DevBuf<int> d_bh, d_bf;

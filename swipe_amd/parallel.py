@@ -65,6 +65,28 @@ def gather_topk(local_hits: Sequence[Tuple[int, ...]], keep: int, totalhits: int
     return (merge_hits(lists, keep) if W == 2 else merge_frame_hits(lists, keep)), tot, obv
 
 
+def gather_topk_array(local_hits: np.ndarray, keep: int, totalhits: int = 0, obvious: int = 0, group=None, device=None):
+    """gather_topk for (seqno, score) hits held as an int64 [n, 2] array (Database.search_topk_array): one
+    all_gather of keep x 2 + 3 int64 per rank, merged by swa_hits_merge straight from the gathered buffer - no
+    per-hit Python objects anywhere.  Returns (int64 [m, 2], totalhits_sum, obvious_sum), identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    from .api import merge_hit_arrays
+    world = dist.get_world_size(group)
+    n = min(len(local_hits), keep)
+    row = np.zeros(2 * keep + 3, dtype=np.int64)
+    row[: 2 * n] = np.asarray(local_hits[:n], dtype=np.int64).reshape(-1)
+    row[2 * keep:] = (n, totalhits, obvious)
+    buf = torch.from_numpy(row)
+    if device is not None:
+        buf = buf.to(device, non_blocking=True)
+    out = torch.empty(world * (2 * keep + 3), dtype=torch.int64, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    g = out.cpu().numpy().reshape(world, 2 * keep + 3)
+    merged = merge_hit_arrays(g[:, : 2 * keep].reshape(world, keep, 2), g[:, 2 * keep], keep)
+    return merged, int(g[:, 2 * keep + 1].sum()), int(g[:, 2 * keep + 2].sum())
+
+
 def align_sharded(db, query, hits: Sequence[Tuple[int, int]], first: int, last: int, dstrands=None, dframes=None,
                   group=None):
     """Alignment phase over shards: every rank holds the same merged hit list (gather_topk); the rank whose

@@ -220,7 +220,7 @@ def test_bound_build_under_a_translated_search(monkeypatch):
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SWA_BOUND", mode)
+        db.set_option("bound", mode)
         for minscore in (30, 45, 70):
             hits, tot, obv, c = db.search_frames_topk([q], keep=100, minscore=minscore)
             assert c["narrow_shifted"] == (8 if mode == "1" else 2)
@@ -331,7 +331,8 @@ def test_requeue_by_batches_and_by_wave(qlen, wave, monkeypatch):
 
 def test_bound_build_is_dropped_when_too_much_comes_back(monkeypatch):
     """auto mode: the bound build runs only for thresholds well above its slack, and a search that sends more than 2 % of
-    the sequences back switches it off until the scoring system changes; results are exact either way"""
+    the sequences back switches it off for that query length at thresholds up to that one, until the scoring system
+    changes; results are exact either way"""
     monkeypatch.delenv("SWA_BOUND", raising=False)
     q = cases.Q375
     rtab = synth.residue_table_protein()
@@ -362,6 +363,10 @@ def test_bound_build_is_dropped_when_too_much_comes_back(monkeypatch):
     assert tot > 40 and c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want3, 50, 80)     # fell back
     hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=80)
     assert c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want3, 50, 80)                  # and stays off
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=900)          # ... for that query and threshold only
+    assert c["narrow_shifted"] == 8 and (hits, tot, obv) == _expected_topk(want3, 50, 900)
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=70)           # a lower threshold sends back even more
+    assert c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want3, 50, 70)
     db3.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=900)
     assert c["narrow_shifted"] == 8 and (hits, tot, obv) == _expected_topk(want3, 50, 900)
@@ -387,7 +392,7 @@ def test_pipelined_profile_build_of_the_split_kernel(lanes, monkeypatch):
         q = full[: lanes * K - 1]
         want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
         for pipe in (("0", "1") if K < 40 else ("0", "2")):
-            monkeypatch.setenv("SWA_PIPE", pipe)
+            db.set_option("pipe", pipe)
             scores, c = db.search(q)
             assert c["narrow_rows"] == K and np.array_equal(scores, want), (K, pipe)
     db.close()
@@ -557,7 +562,7 @@ def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monk
         assert c["narrow_rows"] == K and c["narrow_shifted"] == 4
         assert np.array_equal(s1, oracle.search_all63(r2, o2, q1, Mo, goe, ge, threads=THREADS)), K
         assert np.array_equal(s2, oracle.search_all63(r2, o2, q2, Mo, goe, ge, threads=THREADS)), K
-    monkeypatch.setenv("SWA_DUAL_MP", "1")
+    db.set_option("dual_mp", 1)
     t1, t2, c = db.search2(q1, q2)
     assert c["narrow_shifted"] == 1 and np.array_equal(t1, s1) and np.array_equal(t2, s2)
     db.close()
@@ -980,7 +985,7 @@ def test_endpoints_wave_kernel_all_row_counts_and_passes(qlen, monkeypatch):
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     ids = list(range(len(seqs)))
     for mode in ("wave", "thread"):
-        monkeypatch.setenv("SWA_ENDPOINTS", mode)
+        db.set_option("endpoints_thread", mode)
         e = db.search_endpoints(q, ids)
         assert [(int(e[0][k]), int(e[1][k]), int(e[2][k])) for k in ids] == want, mode
     db.close()
@@ -1033,3 +1038,163 @@ def test_cli_errors_like_the_reference(tmp_path):
     assert r.returncode == 1 and "No database specified." in r.stderr
     r = subprocess.run([exe, "-d", str(tmp_path / "nosuch"), "-i", "/dev/null"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unable to open file" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ round 2
+def test_seeded_fuzz_slice():
+    """a bounded, seeded slice of tools/gpu_fuzz.py (random scoring systems, alphabets, query lengths, one / two queries,
+    top-K searches with the automatic first pass and the bound build forced, inclusion subsets) - every score, hit list
+    and count against the oracle"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gpu_fuzz
+    rng = np.random.default_rng(20260929)
+    bad = []
+    for it in range(30):
+        desc, ok, ok2, ok4, ok3 = gpu_fuzz.one_config(rng, THREADS, max_qlen=1600, max_nseq=1500)
+        if not (ok and ok2 and ok4 and ok3):
+            bad.append((it, desc, ok, ok2, ok4, ok3))
+    assert not bad, bad
+
+
+def test_options_are_explicit_and_checked():
+    """swa_set_option: unknown keys and unparsable values are errors; NULL restores the default; the search path does not
+    read the environment (a variable set after the handle exists changes nothing)"""
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(1, 3000, query=q)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    with pytest.raises(swipe_amd.SwaError):
+        db.set_option("no_such_knob", 1)
+    with pytest.raises(swipe_amd.SwaError):
+        db.set_option("lanes", "eight")
+    _, c = db.search(q)
+    assert c["narrow_shifted"] == 2 and c["narrow_rows"] == 47          # 375 rows: 8-lane chains by default
+    os.environ["SWA_LANES"] = "16"
+    try:
+        _, c = db.search(q)
+        assert c["narrow_shifted"] == 2                                  # the handle already exists: no effect
+        db2 = swipe_amd.Database.from_arrays(res, off)                   # read once, at creation
+        db2.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        assert db2.search(q)[1]["narrow_shifted"] == 1
+        db2.close()
+    finally:
+        del os.environ["SWA_LANES"]
+    db.set_option("lanes", 16)
+    assert db.search(q)[1]["narrow_shifted"] == 1
+    db.set_option("lanes", None)
+    assert db.search(q)[1]["narrow_shifted"] == 2
+    db.close()
+
+
+@pytest.mark.parametrize("host", [0, 1])
+def test_requeue_list_longer_than_the_device_driven_kernel_takes(host):
+    """the re-queue list normally never reaches the host: a persistent grid of waves works it off up to 65 536 entries
+    and the search synchronises once.  A list beyond that (here: the bound build forced with a threshold of 1 - every
+    sequence comes back) is taken over by the host after that synchronisation; requeue_host = 1 is the old
+    host-driven path.  Same hits either way"""
+    q = cases.Q375[:96]
+    res, off = swipe_amd.synth_db(21, 70_000, query=q)
+    lens = np.minimum(np.diff(off), 40)                      # sequences cut to at most 40 residues: a quick first pass
+    o2 = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=o2[1:])
+    src = np.repeat(off[:-1] - o2[:-1], lens) + np.arange(int(o2[-1]), dtype=np.int64)
+    r2 = res[src]
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=THREADS)
+    db.set_option("bound", 1)
+    db.set_option("requeue_host", host)
+    hits, tot, obv, c = db.search_topk(q, keep=100, minscore=1)
+    assert c["narrow_shifted"] == 8 and c["wide"] >= 70_000 - 5
+    assert (hits, tot, obv) == _expected_topk(want, 100, 1)
+    db.close()
+
+
+def test_second_query_takes_the_64_bit_hop():
+    """two queries whose scores both leave 32 bits: each keeps its own 64-bit score array (the first version answered
+    SWA_ERANGE for the second query)"""
+    rtab = synth.residue_table_protein()
+    q1 = synth._random_residues(77, 1, 40, rtab)
+    q2 = q1[::-1].copy()
+    res, off = swipe_amd.synth_db(5, 300)
+    seqs = [res[off[i]:off[i + 1]] for i in range(300)] + [q1, q2, np.concatenate([q2, q1])]
+    r2, o2 = oracle.pack(seqs)
+    M = np.full(1024, -1, dtype=np.int64)
+    for a in range(1, 28):
+        M[(a << 5) | a] = 0x3fffffff // 4
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(M, 11, 1)
+    s1, s2, c = db.search2(q1, q2)
+    assert np.array_equal(s1, oracle.search_all63(r2, o2, q1, M, 12, 1, threads=THREADS))
+    assert np.array_equal(s2, oracle.search_all63(r2, o2, q2, M, 12, 1, threads=THREADS))
+    assert c["full"] >= 4 and int(s2.max()) > (1 << 31)
+    hits, tot, obv, _ = db.search2_topk(q1, q2, keep=5, minscore=1 << 31)
+    want = sorted([(int(v), i, 0) for i, v in enumerate(s1) if v >= (1 << 31)] + [(int(v), i, 1) for i, v in enumerate(s2) if v >= (1 << 31)],
+                  key=lambda t: (-t[0], -t[1], t[2]))[:5]
+    assert hits == [(i, v, w) for v, i, w in want] and tot == len([1 for v in list(s1) + list(s2) if v >= (1 << 31)])
+    db.close()
+
+
+@pytest.mark.parametrize("lanes", [2, 4, 8])
+def test_overflow_to_infinity_does_not_poison_the_neighbour(lanes):
+    """short chains isolate neighbouring sequences with a multiplication by zero; a self-hit under a matrix
+    with scores of 400 drives its f16 state past 65504 = inf, and 0 x inf = NaN would zero the NEIGHBOUR's score without
+    re-queueing it.  Such searches take 16-lane chains (zero fill by DPP); every score must be exact"""
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(5, 1, 2 * 48 if lanes == 2 else 180, rtab)
+    res, off = swipe_amd.synth_db(8, 64)
+    base = [res[off[i]:off[i + 1]] for i in range(64)]
+    seqs = []
+    for k in range(32):                                      # self-hits interleaved with random neighbours of the same length
+        seqs += [q.copy(), synth._random_residues(1000 + k, 1, len(q), rtab)]
+    seqs += base
+    r2, o2 = oracle.pack(seqs)
+    M = swipe_amd.matrix_builtin("BLOSUM62").copy()
+    for a in range(1, 28):
+        M[(a << 5) | a] = 400
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_option("lanes", lanes)
+    db.set_scoring(M, 11, 1)
+    scores, c = db.search(q)
+    want = oracle.search_all63(r2, o2, q, M, 12, 1, threads=THREADS)
+    assert int(want.max()) > 65504 and np.array_equal(scores, want), c
+    db.close()
+
+
+def test_database_residue_codes_are_validated():
+    res, off = swipe_amd.synth_db(1, 50)
+    bad = res.copy()
+    bad[100] = 40
+    with pytest.raises(swipe_amd.SwaError) as e:
+        swipe_amd.Database.from_arrays(bad, off)
+    assert "residue code" in str(e.value)
+    nt, noff = swipe_amd.synth_db(3, 50, protein=False)
+    nt = nt.copy()
+    nt[7] = 17
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.Database.from_arrays(nt, noff, symtype=0)
+
+
+def _bench_line(env_extra, *args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_step_over_rccl_with_one_rank():
+    """the N > 1 code path of bench.py on the one GPU there is: SWA_BENCH_FORCE_DIST=1 initialises the nccl (RCCL) process
+    group with world size 1, every step goes through gather_topk_array (all_gather_into_tensor on device + merge), and the
+    gathered hit list equals the local one; both runs verify their scores against the oracle inside bench.py"""
+    args = ("--nseq", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--verify-sample", "2000")
+    local = _bench_line({}, *args)
+    dist = _bench_line({"SWA_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517", "RANK": "0",
+                        "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, *args)
+    assert local["search"] == dist["search"] and local["hits_sha1"] == dist["hits_sha1"]
+    assert dist["verified_vs_oracle"] >= 2000 and dist["scaling"] == "strong" and dist["n_gpus"] == 1
+    assert "roofline" in dist and "overhead_ms" in dist

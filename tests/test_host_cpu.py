@@ -355,3 +355,104 @@ def test_cli_database_dump_equals_reference(tmp_path):
     blastdb.write_db(base, nt.seqs[295:], protein=False)
     r = subprocess.run([exe, "-d", base, "-p", "0", "-N", "1"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == g["nt_N1"]
+
+
+# ------------------------------------------------------------------------------------------------ round 2
+def test_integration_binding_compiles_against_the_reference(tmp_path):
+    """INTEGRATION.md section 2 is code, not prose: the binding a SWIPE maintainer would add is cut out of the document,
+    spliced into a temporary copy of the reference's swipe.cc in place of search_chunk(), and type-checked by
+    g++ -fsyntax-only against the reference's own swipe.h and include/swipe_amd.h.  Build container only (the GPU box
+    has no /root/reference); nothing of the copy outlives the test."""
+    import shutil
+    import subprocess
+    ref = "/root/reference/swipe.cc"
+    if not os.path.exists(ref) or not shutil.which("g++"):
+        pytest.skip("needs /root/reference and g++")
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", doc, flags=re.S)
+    binding = next(b for b in blocks if b.startswith("#ifdef SWIPE_AMD"))
+    assert "swa_search(" in binding and "hits_enter(" in binding and "swa_set_scoring(" in binding
+    src = open(ref).read()
+    start = src.index("void search_chunk(struct search_data * sdp)\n{")
+    end = src.index("void * worker(void *)")
+    patched = src[:start] + "#ifndef SWIPE_AMD\n" + src[start:end] + "#endif\n" + binding + "\n" + src[end:]
+    work = tmp_path / "swipe_patched.cc"
+    work.write_text(patched)
+    cmd = ["g++", "-fsyntax-only", "-w", "-DSWIPE_AMD", "-I", "/root/reference", "-I", os.path.join(ROOT, "include"), str(work)]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[:3000]
+    # the alignment-phase and multi-query snippets are statement fragments: check that the entry points they name exist
+    for name in re.findall(r"\b(swa_[a-z0-9_]+)\s*\(", doc):
+        assert name in _lib.EXPORTS, name
+
+
+def test_cpp_volume_writer_equals_the_python_writer(tmp_path):
+    """swa_blastdb_write (streaming C++, used by bench.py for the reference's CPU baseline and the cold open) writes the
+    same bytes as the Python writer the golden fixtures were made with, for both alphabets; ambiguity codes are refused"""
+    import filecmp
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, 500, query=q)
+    swipe_amd.write_blastdb(str(tmp_path / "a"), res, off, first_id=7)
+    blastdb.write_protein_volume_arrays(str(tmp_path / "b"), res, off, first_id=7)
+    for e in ("pin", "psq", "phr"):
+        assert filecmp.cmp(tmp_path / f"a.{e}", tmp_path / f"b.{e}", shallow=False), e
+    res, off = swipe_amd.synth_db(3, 300, protein=False)
+    res = res.copy()
+    off = off.copy()
+    swipe_amd.write_blastdb(str(tmp_path / "c"), res, off, symtype=0)
+    blastdb.write_volume(str(tmp_path / "d"), [res[off[i]:off[i + 1]] for i in range(300)], protein=False,
+                         ids=[f"s{i}" for i in range(300)], titles=[f"seq{i}" for i in range(300)])
+    for e in ("nin", "nsq", "nhr"):
+        assert filecmp.cmp(tmp_path / f"c.{e}", tmp_path / f"d.{e}", shallow=False), e
+    r2, o2, _ = swipe_amd.read_blastdb(str(tmp_path / "c"), symtype=0)
+    assert np.array_equal(r2, res) and np.array_equal(o2, off)
+    res[5] = 15                                            # N
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.write_blastdb(str(tmp_path / "e"), res, off, symtype=0)
+    # a slice of a larger array, as bench.py cuts volumes
+    res, off = swipe_amd.synth_db(1, 500, query=q)
+    swipe_amd.write_blastdb(str(tmp_path / "f"), res, off[100:301], first_id=100)
+    r3, o3, _ = swipe_amd.read_blastdb(str(tmp_path / "f"))
+    assert np.array_equal(o3, off[100:301] - off[100]) and np.array_equal(r3, res[off[100]:off[300]])
+
+
+def test_set_option_rejects_bad_arguments_without_a_device():
+    L = _lib.load()
+    assert L.swa_set_option(None, b"bound", b"1") != 0
+    assert b"null" in L.swa_last_error()
+
+
+def test_merge_hit_arrays_equals_merge_hits():
+    rng = np.random.default_rng(4)
+    lists = []
+    for r in range(4):
+        n = int(rng.integers(0, 9))
+        sc = np.sort(rng.integers(40, 60, n))[::-1]
+        sq = rng.permutation(1000)[:n] + 1000 * r
+        order = np.lexsort((-sq, -sc))
+        lists.append([(int(sq[i]), int(sc[i])) for i in order])
+    stride = 8
+    arr = np.zeros((4, stride, 2), dtype=np.int64)
+    cnt = np.zeros(4, dtype=np.int64)
+    for r, l in enumerate(lists):
+        cnt[r] = len(l)
+        if l:
+            arr[r, : len(l)] = np.array(l, dtype=np.int64)
+    for keep in (1, 5, 40):
+        got = swipe_amd.merge_hit_arrays(arr, cnt, keep)
+        assert [tuple(x) for x in got.tolist()] == swipe_amd.merge_hits(lists, keep)
+
+
+def test_synth_offsets_place_a_shard_of_one_database():
+    """bench.py --gpus N: every rank derives the global length table, takes its shard_bounds slice and generates only
+    that slice; the slices concatenate to the database a single rank generates"""
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, 20_000, query=q)
+    goff = swipe_amd.synth_offsets(1, 20_000, query=q)
+    assert np.array_equal(goff, off)
+    parts = []
+    for lo, hi in parallel.shard_bounds(goff, 3):
+        r, o = swipe_amd.synth_db(1, hi - lo, first=lo, query=q)
+        assert np.array_equal(o, off[lo:hi + 1] - off[lo])
+        parts.append(r)
+    assert np.array_equal(np.concatenate(parts), res)

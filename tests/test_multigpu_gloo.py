@@ -41,6 +41,10 @@ def _worker(rank, world, port, keep, q_out):
         minscore = 40
         mine = sorted(((int(s), lo + i) for i, s in enumerate(local) if s >= minscore), key=lambda t: (-t[0], -t[1]))[:keep]
         hits, tot, obv = parallel.gather_topk([(i, s) for s, i in mine], keep, totalhits=int((local >= minscore).sum()))
+        # the array form bench.py uses (one all_gather_into_tensor, merged straight from the gathered buffer)
+        arr = np.array([(i, s) for s, i in mine], dtype=np.int64).reshape(-1, 2)
+        h2, t2, o2b = parallel.gather_topk_array(arr, keep, totalhits=int((local >= minscore).sum()))
+        assert [tuple(x) for x in h2.tolist()] == hits and (t2, o2b) == (tot, obv)
 
         class HostShard:
             """stands in for Database.align on a box without a GPU: end points from the oracle's search16s,

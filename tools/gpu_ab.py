@@ -11,8 +11,8 @@ M = swipe_amd.matrix_builtin("blosum62")
 VARIANTS = [int(x) for x in os.environ.get('AB_VARIANTS', '2,3').split(',')]
 dbs = {}
 for v in VARIANTS:
-    os.environ["SWA_NARROW_VARIANT"] = str(v)
     dbs[v] = swipe_amd.Database.from_arrays(res, off)
+    dbs[v].set_option("narrow_variant", str(v))
     dbs[v].set_scoring(M, 11, 1)
 s1, c1 = dbs[VARIANTS[0]].search(q)
 s2, c2 = dbs[VARIANTS[-1]].search(q)

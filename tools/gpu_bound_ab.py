@@ -14,7 +14,7 @@ for qlen in [int(x) for x in sys.argv[3:]] or [375]:
     qq = q[:qlen] if qlen <= len(q) else np.concatenate([q] * (qlen // len(q) + 1))[:qlen]
     ref = None
     for mode in ("0", "1", "0", "1"):
-        os.environ["SWA_BOUND"] = mode
+        db.set_option("bound", mode)
         hits, tot, obv, c = db.search_topk(qq, keep=250, minscore=minscore)
         best = min(db.search_topk(qq, keep=250, minscore=minscore)[3]["kernel_ms"] for _ in range(3))
         tbest = min(db.search_topk(qq, keep=250, minscore=minscore)[3]["total_ms"] for _ in range(3))

@@ -24,8 +24,8 @@ for q in queries:
     st = swipe_amd.stats_init(qlen=len(q), db_seqcount=nseq, db_symcount=int(off[-1]))
     out = {}
     for mode in ("0", None):
-        if mode: os.environ["SWA_BOUND"] = mode
-        else: os.environ.pop("SWA_BOUND", None)
+        if mode: db.set_option("bound", mode)
+        else: db.set_option("bound", None)
         t = time.time()
         hits, tot, obv, c = db.search_topk(q, keep=250, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
         out[mode] = (hits, tot, obv, c, time.time() - t)

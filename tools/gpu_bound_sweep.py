@@ -11,12 +11,12 @@ db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
 want = [int(x) for x in sys.argv[1:]]            # optional: G K0 K1
 for G in ((want[0],) if want else (2, 4, 8, 16)):
-    os.environ["SWA_LANES"] = str(G)
+    db.set_option("lanes", str(G))
     for K in range(want[1] if want else 25, (want[2] if want else (58 if G == 16 else 48)) + 1):
         q = full[:G * K]
         out, ref = [], None
         for mode in ("0", "1"):
-            os.environ["SWA_BOUND"] = mode
+            db.set_option("bound", mode)
             hits, tot, obv, c = db.search_topk(q, keep=250, minscore=80)
             if ref is None: ref = (hits, tot, obv)
             best = min(db.search_topk(q, keep=250, minscore=80)[3]["kernel_ms"] for _ in range(3))

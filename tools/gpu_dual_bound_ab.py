@@ -14,7 +14,7 @@ for qlen in map(int, sys.argv[1:]):
     q1 = full[:qlen]; q2 = full[::-1][:qlen].copy()
     ref = None
     for mode in ("0", "1"):
-        os.environ["SWA_BOUND"] = mode
+        db.set_option("bound", mode)
         hits, tot, obv, c = db.search2_topk(q1, q2, keep=250, minscore=80)
         if ref is None: ref = (hits, tot, obv)
         best = min(db.search2_topk(q1, q2, keep=250, minscore=80)[3]["kernel_ms"] for _ in range(3))

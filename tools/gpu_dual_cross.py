@@ -13,7 +13,7 @@ for qlen in map(int, sys.argv[1:]):
     q = full[:qlen]; qm = blastdb.revcomp_nt16(q)
     out = []
     for kmax in ("63", "61", "56"):
-        os.environ["SWA_DUAL_KMAX"] = kmax
+        db.set_option("dual_kmax", kmax)
         db.search2(q, qm, want_scores=False)
         best, c = 1e9, None
         for _ in range(3):

@@ -13,11 +13,11 @@ for qlen in map(int, sys.argv[1:]):
     q = full[:qlen]; qm = blastdb.revcomp_nt16(q)
     out = []
     for mp in ("0", "16", "1"):
-        os.environ["SWA_DUAL_MP"] = "1" if mp == "1" else "0"
+        db.set_option("dual_mp", "1" if mp == "1" else "0")
         if mp == "16":
-            os.environ["SWA_LANES"] = "16"
+            db.set_option("lanes", "16")
         else:
-            os.environ.pop("SWA_LANES", None)
+            db.set_option("lanes", None)
         db.search2(q, qm, want_scores=False)
         best, c = 1e9, None
         for _ in range(3):

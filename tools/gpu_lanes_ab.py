@@ -11,7 +11,7 @@ db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
 ref = None
 for lanes in ("16", "8", "16", "8"):
-    os.environ["SWA_LANES"] = lanes
+    db.set_option("lanes", lanes)
     s, c = db.search(q)
     if ref is None:
         ref = s
@@ -20,7 +20,7 @@ for lanes in ("16", "8", "16", "8"):
 for qlen in (30, 60, 100, 150, 192, 200, 300, 375):
     qq = q[:qlen]
     for lanes in ("16", "8", "4"):
-        os.environ["SWA_LANES"] = lanes
+        db.set_option("lanes", lanes)
         s, c = db.search(qq)
         best = min(db.search(qq, want_scores=False)[1]["kernel_ms"] for _ in range(3))
         print("qlen %3d lanes %2s: K=%2d  %.0f GCUPS" % (qlen, lanes, c["narrow_rows"], c["cells"] / best / 1e6))

@@ -12,7 +12,7 @@ for qlen in (1000, 3000):
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     base = None
     for k in (16, 24, 32, 16, 24, 32):
-        os.environ["SWA_MP_K"] = str(k)
+        db.set_option("mp_k", str(k))
         s1, c = db.search(q)
         if base is None: base = s1
         print("qlen %d pair K=%d: %.0f GCUPS (%.2f ms) rows %d same=%s requeued %d" % (qlen, k, c['cells'] / c['kernel_ms'] / 1e6, c['kernel_ms'], c['narrow_rows'], np.array_equal(s1, base), c['wide']))

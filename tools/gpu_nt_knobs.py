@@ -11,7 +11,7 @@ db = swipe_amd.Database.from_arrays(res, off, symtype=0)
 db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
 base = None
 for k, w in [(32, 3), (32, 2), (24, 3), (16, 4), (32, 3), (32, 2), (24, 3), (16, 4)]:
-    os.environ["SWA_MP_K"] = str(k); os.environ["SWA_MP_W"] = str(w)
+    db.set_option("mp_k", str(k)); db.set_option("mp_w", str(w))
     s1, s2, c = db.search2(q, qm)
     if base is None: base = (s1, s2)
     ok = np.array_equal(s1, base[0]) and np.array_equal(s2, base[1])

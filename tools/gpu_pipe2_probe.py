@@ -9,12 +9,12 @@ full = synth._random_residues(7, 1, 800, rtab)
 res, off = swipe_amd.synth_db(1, 2_000_000, query=full[:375])
 db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
-os.environ["SWA_LANES"] = "8"
+db.set_option("lanes", 8)
 for K in range(45, 49):
     q = full[: 8 * K - 1]
     out, ref = [], None
     for pipe in ("0", "2"):
-        os.environ["SWA_PIPE"] = pipe
+        db.set_option("pipe", pipe)
         sc, _ = db.search(q)
         ref = sc if ref is None else ref
         same = np.array_equal(sc, ref)

@@ -10,12 +10,12 @@ res, off = swipe_amd.synth_db(1, 2_000_000, query=full[:375])
 db = swipe_amd.Database.from_arrays(res, off)
 db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
 for G in (8, 4):
-    os.environ["SWA_LANES"] = str(G)
+    db.set_option("lanes", str(G))
     for K in range(30, 37):
         q = full[: G * K]
         out = []
         for pipe in ("0", "1"):
-            os.environ["SWA_PIPE"] = pipe
+            db.set_option("pipe", pipe)
             db.search(q, want_scores=False)
             best = min(db.search(q, want_scores=False)[1]["kernel_ms"] for _ in range(3))
             out.append(len(q) * float(off[-1]) / best / 1e6)

@@ -13,7 +13,7 @@ for qlen in (50, 64, 100, 128, 200, 256, 300, 375, 450, 512, 600, 700, 768):
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     out = []
     for force in ("0",):
-        os.environ["SWA_FORCE_MP"] = force
+        db.set_option("force_mp", force)
         best = 1e9
         for _ in range(2):
             _, c = db.search(q, want_scores=False)

@@ -14,7 +14,7 @@ for qlen in map(int, sys.argv[1:]):
     out = []
     ref = None
     for lanes in ("2", "4", "8"):
-        os.environ["SWA_LANES"] = lanes
+        db.set_option("lanes", lanes)
         s, c = db.search(q)
         if ref is None: ref = s
         best = min(db.search(q, want_scores=False)[1]["kernel_ms"] for _ in range(3))

@@ -14,7 +14,7 @@ for qlen in map(int, sys.argv[1:]):
     out = []
     ref = None
     for lanes in ("2", "4", "8"):
-        os.environ["SWA_LANES"] = lanes
+        db.set_option("lanes", lanes)
         s1, s2, c = db.search2(q, qm)
         if ref is None: ref = (s1, s2)
         best = min(db.search2(q, qm, want_scores=False)[2]["kernel_ms"] for _ in range(3))

@@ -14,8 +14,8 @@ for qlen in map(int, sys.argv[1:]):
     q = full[:qlen]
     out = []
     for mode in (None, "0"):
-        if mode: os.environ["SWA_BOUND"] = mode
-        else: os.environ.pop("SWA_BOUND", None)
+        if mode: db.set_option("bound", mode)
+        else: db.set_option("bound", None)
         hits, tot, obv, c = db.search_topk(q, keep=250, minscore=80)
         best = min(db.search_topk(q, keep=250, minscore=80)[3]["kernel_ms"] for _ in range(3))
         tot_ms = min(db.search_topk(q, keep=250, minscore=80)[3]["total_ms"] for _ in range(3))
