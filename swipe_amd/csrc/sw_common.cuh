@@ -31,6 +31,18 @@ __device__ __forceinline__ u32 row_shl1(u32 v)
 __device__ __forceinline__ u32 float_to_half_bits(float f)
 { _Float16 x = (_Float16)f; unsigned short s; __builtin_memcpy(&s, &x, 2); return s; }
 
+// End of a first-pass block when a re-queue follower runs beside the kernel: everything this block appended to the list is
+// released (agent scope) before its tick; the block that ticks last raises the flag the follower's waves poll.
+__device__ __forceinline__ void signal_block_done(int32_t* finished, int32_t* done)
+{
+  if (!done) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(finished, 1) == (int)gridDim.x - 1) __hip_atomic_store(done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u4v* lds_u4_ptr;
 

@@ -52,6 +52,10 @@ struct swa_narrow_params {
   long long boundary_base;     /* stream chunk (swa_batch.offset units) that boundary[0] belongs to */
   int32_t row0;                /* first query row of the pass */
   int32_t pass, last;          /* pass index; 1 when no pass follows */
+  /* re-queue follower running beside this kernel on a second stream (swa_requeue_follow_kernel): every block bumps
+     *finished when it is through; the last one raises *done.  Null: nobody follows */
+  int32_t* finished;
+  int32_t* done;
 };
 
 /* generic multi-pass kernel (sw_mp_kernel.inc) */

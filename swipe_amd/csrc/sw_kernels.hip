@@ -551,11 +551,13 @@ swa_narrow_split_kernel(swa_narrow_params p)
         if (lane == 0) base = atomicAdd(p.ovf_count, nA + nB);
         base = __builtin_amdgcn_readfirstlane(base);
         const u64 below = (1ull << lane) - 1;
+        if (p.done) __threadfence();            // a follower may pick the entry up at once: the placeholder score first
         if (oA) p.ovf_list[base + __popcll(mA & below)] = idA;
         if (oB) p.ovf_list[base + nA + __popcll(mB & below)] = idB;
       }
     }
   }
+  if constexpr (!MP) signal_block_done(p.finished, p.done);
 }
 
 // ------------------------------------------------------------------ hit filter
@@ -777,15 +779,19 @@ swa_requeue_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __r
 {
   __shared__ int M[1024];
   __shared__ uint8_t ring[128];
+  __shared__ int next;
   const int g = threadIdx.x;
   int n = *count;
   if (n > cap) n = cap;
   if (n <= 0) return;
   for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
   for (;;) {
-    int w = 0;
-    if (g == 0) w = atomicAdd(work, 1);
-    w = __builtin_amdgcn_readfirstlane(w);
+    // the queue head goes through LDS + barrier, not "if (lane 0) atomic; readfirstlane": with the barriers of the body
+    // inside this loop the compiler threaded the lanes' w = 0 past the readfirstlane and lanes 1..63 never left the loop
+    __syncthreads();
+    if (g == 0) next = atomicAdd(work, 1);
+    __syncthreads();
+    const int w = next;
     if (w >= n) break;
     const int id = list[w];
     const int64_t o = offsets[id];
@@ -793,6 +799,66 @@ swa_requeue_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __r
     int best, bcol, brow;
     endpoints_wave_one<K, false>(M, ring, residues, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
     if (g == 0) scores[id] = best;
+  }
+}
+
+// The same list worked off WHILE the first pass still runs: launched on a second stream right after the first-pass
+// kernel, a few waves per CU sit beside its blocks (they fit: the bound build leaves a quarter of the register file
+// free), claim list positions in order and wait for each to be filled.  The producer bumps the count BEFORE it writes
+// the entries, so the count proves nothing: the host presets the head of the list to -1 and an entry is there when it
+// is >= 0.  When the producer's last block raises *done (signal_block_done) every entry it ever wrote is visible and a
+// position still holding -1 lies beyond the end.  Re-queued sequences thus cost no time after the first pass except the
+// ones that surface in its last microseconds - the shortest sequences, since batches run longest first.  If the two
+// kernels are not co-resident (register file full: the exact build) the follower simply runs after the producer.
+template <int K>
+__global__ void __launch_bounds__(64)
+swa_requeue_follow_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
+                          const int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
+                          const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
+                          int* __restrict__ scores)
+{
+  __shared__ int M[1024];
+  __shared__ uint8_t ring[128];
+  __shared__ int next, leave;
+  const int g = threadIdx.x;
+  for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
+  for (;;) {
+    __syncthreads();
+    if (g == 0) {
+      int id = -1, fin = 0;
+      const int w = atomicAdd(work, 1);
+      if (w < cap) {
+        // relaxed polls a few microseconds apart: an acquire per poll would invalidate the CU's caches under the
+        // first-pass waves next door (measured: 1 024 polling waves cost the first pass 37 %)
+        for (;;) {
+          id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (id >= 0) break;
+          if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            fin = 1;
+            id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;                                // still -1: position w lies beyond the end of the list
+          }
+          __builtin_amdgcn_s_sleep(127);
+          __builtin_amdgcn_s_sleep(127);
+        }
+      }
+      __threadfence();
+      next = id;
+      leave = fin;
+    }
+    __syncthreads();
+    const int id = next;
+    const bool last = leave != 0;
+    if (id >= 0) {
+      const int64_t o = offsets[id];
+      const int len = (int)(offsets[id + 1] - o);
+      int best, bcol, brow;
+      endpoints_wave_one<K, false>(M, ring, residues, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
+      if (g == 0) scores[id] = best;
+    }
+    // the first pass is through: whatever is left belongs to the finishing kernel (swa_requeue_wave_kernel on the first
+    // stream, many more waves, same work-queue head)
+    if (id < 0 || last) break;
   }
 }
 
@@ -1043,6 +1109,25 @@ extern "C" hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int
     default: SWA_RQW(32); break;
   }
 #undef SWA_RQW
+  return hipGetLastError();
+}
+extern "C" hipError_t swa_launch_requeue_follow(const uint8_t* residues, const int64_t* offsets, const int32_t* list, int cap,
+                                                int32_t* work, const int32_t* done, const uint8_t* qseq, int qlen,
+                                                const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
+{
+#define SWA_RQF(KK) hipLaunchKernelGGL((swa_requeue_follow_kernel<KK>), dim3(blocks), dim3(64), 0, st, residues, offsets, list, cap, \
+                                       work, done, qseq, qlen, matrix, Q, R, scores)
+  switch (swa_endpoints_rows_for(qlen)) {
+    case 2: SWA_RQF(2); break;
+    case 4: SWA_RQF(4); break;
+    case 6: SWA_RQF(6); break;
+    case 8: SWA_RQF(8); break;
+    case 12: SWA_RQF(12); break;
+    case 16: SWA_RQF(16); break;
+    case 24: SWA_RQF(24); break;
+    default: SWA_RQF(32); break;
+  }
+#undef SWA_RQF
   return hipGetLastError();
 }
 extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,

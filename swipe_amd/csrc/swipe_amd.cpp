@@ -62,6 +62,9 @@ hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, co
 hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,
                              long long maxscore, int* cand_count, int cand_cap, swa_cand* cand,
                              unsigned long long* tallies, hipStream_t st);
+hipError_t swa_launch_requeue_follow(const uint8_t* residues, const int64_t* offsets, const int32_t* list, int cap, int32_t* work,
+                                     const int32_t* done, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
+                                     int* scores, int blocks, hipStream_t st);
 hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* list, const int32_t* count,
                                    int cap, int32_t* work, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                    int* scores, int blocks, hipStream_t st);
@@ -129,6 +132,7 @@ struct Options {
   int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
+  int64_t requeue_follow = 1;    // 1: the re-queue kernel runs BESIDE the first pass on a second stream (single-launch first passes)
 };
 struct OptionKey { const char* key; int64_t Options::*field; };
 const OptionKey kOptionKeys[] = {
@@ -137,6 +141,7 @@ const OptionKey kOptionKeys[] = {
   {"mp_w", &Options::mp_w}, {"boundary_mb", &Options::boundary_mb}, {"wave_requeue", &Options::wave_requeue},
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
+  {"requeue_follow", &Options::requeue_follow},
 };
 bool parse_option_value(const char* key, const char* value, int64_t* out)
 {
@@ -188,6 +193,8 @@ struct swa_db {
   std::vector<int32_t> h_order;            // sequence indices by descending length
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream2 = nullptr;           // the re-queue follower's stream
+  hipEvent_t ev2[2] = {nullptr, nullptr};  // [0] stream -> stream2: inputs uploaded; [1] stream2 -> stream: follower through
 
   DevBuf<uint8_t> residues;
   DevBuf<int64_t> offsets;
@@ -234,6 +241,8 @@ struct swa_db {
   ~swa_db()
   {
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev2) if (e) (void)hipEventDestroy(e);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
   }
@@ -382,6 +391,10 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
     HIP_TRY(hipStreamCreate(&db->stream));
     for (hipEvent_t& e : db->ev) HIP_TRY(hipEventCreate(&e));
   }
+  if (!db->stream2) {
+    HIP_TRY(hipStreamCreateWithFlags(&db->stream2, hipStreamNonBlocking));
+    for (hipEvent_t& e : db->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   HIP_TRY(db->offsets.reserve(size_t(nseq) + 1));
   if (residues) {
     HIP_TRY(db->residues.reserve(size_t(db->nsym) + 16));
@@ -391,7 +404,7 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   HIP_TRY(db->scores.reserve(size_t(nseq)));
   HIP_TRY(db->ovf_list.reserve(size_t(nseq)));
   db->cand_cap = int(std::max<int64_t>(1, std::min<int64_t>(nseq, 1 << 20)));
-  HIP_TRY(db->ctl.reserve(16 + size_t(db->cand_cap) * (sizeof(swa_cand) / sizeof(int32_t))));
+  HIP_TRY(db->ctl.reserve(48 + size_t(db->cand_cap) * (sizeof(swa_cand) / sizeof(int32_t))));
   HIP_TRY(db->matrix.reserve(1024));
   order_by_length(db->h_offsets, nullptr, nseq, db->h_order);
   return build_batches(db, db->h_order.data(), nseq, 2, db->main);
@@ -705,7 +718,8 @@ int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
 //   [0] work-queue head of the first-pass kernel     [1] re-queue count, query 1     [3] re-queue count, query 2
 //   [4] [5] work-queue heads of the device-driven re-queue kernels                   [8] candidate count
 //   [10..13] two 64-bit tallies (totalhits, obvious)                                 [16..] swa_cand records
-constexpr int CTL_INTS = 16;
+constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] blocks finished | [32] done flag (polled)
+constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
@@ -940,7 +954,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
 
   std::vector<int32_t> requeue;
-  bool used_bound = false;
+  bool used_bound = false, follow = false;
   const bool f16 = f16_applicable(db);
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = db->opt.force_mp == 1;
@@ -993,6 +1007,17 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // that slack for the recomputed share to be negligible (option "bound" = 0 never, 1 whenever a build exists); if more
     // than 2 % of the sequences come back it is switched off for this (query length, threshold) and the exact kernel runs
     used_bound = want_bound && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
+    // The re-queue list is worked off beside this kernel by a follower on the second stream (sw_kernels.hip
+    // swa_requeue_follow_kernel): the head of the list is preset to -1 ("not written yet"), the kernel's last block
+    // raises ctl[7].  The follower is launched AFTER the producer, so however the runtime maps the two streams onto
+    // hardware queues it can never wait for a kernel that has not been submitted.
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0;
+    if (follow) {
+      HIP_TRY(hipMemsetAsync(db->ovf_list.p, 0xFF, size_t(std::min<int64_t>(db->nseq, REQUEUE_CAP)) * sizeof(int32_t), st));
+      HIP_TRY(hipEventRecord(db->ev2[0], st));
+      p.finished = db->ctl.p + CTL_FINISHED;
+      p.done = db->ctl.p + CTL_DONE;
+    }
     if (used_bound) {
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
@@ -1001,6 +1026,16 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
                      : swa_launch_narrow_bound_g16(K, &p, blocks, st));
     } else {
       HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));
+    }
+    if (follow) {
+      HIP_TRY(hipStreamWaitEvent(db->stream2, db->ev2[0], 0));
+      // few waves: they only have to keep up with the trickle of entries while the first pass runs (measured: 128 blocks
+      // cost the first pass nothing, 1 024 cost it 37 %); what is left at its end goes to the finishing kernel below
+      const int fblocks = db->opt.requeue_follow > 1 ? int(db->opt.requeue_follow) : std::max(1, db->cus / 2);
+      HIP_TRY(swa_launch_requeue_follow(db->residues.p, db->offsets.p, db->ovf_list.p, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)), db->ctl.p + 4,
+                                        db->ctl.p + CTL_DONE, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge),
+                                        db->scores.p, fblocks, db->stream2));
+      HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
     }
     c.narrow = db->nseq;
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->opt.narrow_variant == 1 || f16_limit(db, K) < 1024)) {
@@ -1045,7 +1080,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   }
   HIP_TRY(hipEventRecord(db->ev[2], st));
   pd.used_bound = used_bound;
-  if (c.narrow && device_requeue_ok(db, qlen)) {
+  if (follow) {
+    // the finishing kernel takes what the follower's few waves did not get to (same work-queue head), then both are awaited
+    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)),
+                                    db->ctl.p + 4, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p,
+                                    db->cus * 8, st));
+    HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
+    pd.dev1 = true;
+  } else if (c.narrow && device_requeue_ok(db, qlen)) {
     // the list stays on the device: a persistent grid of waves takes entries off it until the count the first pass left
     HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
                                     db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
@@ -1548,7 +1590,7 @@ struct Cand { int64_t seqno, score; int32_t which, dtag; };
 // kernel(s); candidates of both arrays land in the same record list, tagged 0 / 1
 int enqueue_filter(swa_db* db, bool two, int64_t minscore, int64_t maxscore, hipStream_t st)
 {
-  HIP_TRY(hipMemsetAsync(db->ctl.p + CTL_CAND, 0, (CTL_INTS - CTL_CAND) * sizeof(int32_t), st));
+  HIP_TRY(hipMemsetAsync(db->ctl.p + CTL_CAND, 0, (16 - CTL_CAND) * sizeof(int32_t), st));
   unsigned long long* tallies = reinterpret_cast<unsigned long long*>(db->ctl.p + CTL_TALLY);
   HIP_TRY(swa_launch_filter(db->scores.p, db->scores64.p, int(db->nseq), 0, minscore, maxscore, db->ctl.p + CTL_CAND,
                             db->cand_cap, cand_dev(db), tallies, st));
