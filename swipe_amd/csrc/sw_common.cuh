@@ -31,6 +31,16 @@ __device__ __forceinline__ u32 row_shl1(u32 v)
 __device__ __forceinline__ u32 float_to_half_bits(float f)
 { _Float16 x = (_Float16)f; unsigned short s; __builtin_memcpy(&s, &x, 2); return s; }
 
+__device__ __forceinline__ void seq_span(const swa_seqs& s, int id, int64_t& o, int64_t& len)
+{
+  if (id < s.nseq) { o = s.offsets[id]; len = s.offsets[id + 1] - o; }
+  else { o = s.wstart[id - s.nseq]; len = s.wlen[id - s.nseq]; }
+}
+__device__ __forceinline__ u32 seq_residue(const swa_seqs& s, int64_t idx)
+{
+  return s.packed ? ((u32)s.residues[idx >> 1] >> ((int)(idx & 1) * 4)) & 15u : (u32)s.residues[idx];
+}
+
 // End of a first-pass block when a re-queue follower runs beside the kernel: everything this block appended to the list is
 // released (agent scope) before its tick; the block that ticks last raises the flag the follower's waves poll.
 __device__ __forceinline__ void signal_block_done(int32_t* finished, int32_t* done)

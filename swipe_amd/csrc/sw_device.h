@@ -15,6 +15,19 @@ struct swa_batch {
                                   the stream holds ceil(steps / 16) chunks of 16 columns */
 };
 
+/* How kernels address the sequences of a shard.  ids < nseq are database sequences, residues [offsets[id],
+   offsets[id + 1]); ids >= nseq are WINDOWS of long sequences (swipe_amd.cpp "windows"): residues
+   [wstart[id - nseq], + wlen[id - nseq]) of the same array.  packed: two 4-bit residues per byte, low nibble
+   first (nucleotide shards; residue index i lives in byte i >> 1). */
+struct swa_seqs {
+  const uint8_t* residues;
+  const int64_t* offsets;
+  int32_t packed;
+  int32_t nseq;
+  const int64_t* wstart;
+  const int32_t* wlen;
+};
+
 struct swa_cand {              /* one survivor of the hit filter (hits_enter's acceptance test on the device) */
   long long score;
   int32_t idx;                 /* shard-local sequence index */
@@ -65,6 +78,7 @@ struct swa_mp_params {
   const int32_t* matrix;
   int32_t qlen, npass, rows_per_lane;
   int32_t tune_w;              /* tuning override of the waves-per-SIMD build (0 = default) */
+  int32_t nibbles;             /* swa_dual_kernel, 16-lane chains: the stream holds 4-bit residues, 32 bytes per chunk */
   const uint16_t* stream;
   const swa_batch* batches;
   const int32_t* slots;

@@ -36,9 +36,8 @@
 // quarter-wave `grp` consumes at step 16*chunk + l.  Reads of a sequence are contiguous over
 // l, writes are fully coalesced.
 extern "C" __global__ void __launch_bounds__(256)
-swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                  const int32_t* __restrict__ slots, const swa_batch* __restrict__ batches,
-                  int nbatches, uint16_t* __restrict__ stream, int unpack2bit)
+swa_format_stream(swa_seqs sq, const int32_t* __restrict__ slots, const swa_batch* __restrict__ batches,
+                  int nbatches, uint16_t* __restrict__ stream)
 {
   const int b = blockIdx.x;
   if (b >= nbatches) return;
@@ -54,14 +53,42 @@ swa_format_stream(const uint8_t* __restrict__ residues, const int64_t* __restric
       const int32_t s = sl[grp * 2 + h];
       u32 r = SWA_PAD;
       if (s >= 0) {
-        const int64_t o = offsets[s], n = offsets[s + 1] - o;
-        if (t < n) r = residues[o + t];
+        int64_t o, n;
+        seq_span(sq, s, o, n);
+        if (t < n) r = seq_residue(sq, o + t);
       }
       v |= r << (8 * h);
     }
     out[e] = (uint16_t)v;
   }
-  (void)unpack2bit;
+}
+
+// The one-sequence-per-row stream of a NUCLEOTIDE shard at 4 bits per base: [batch][16-column chunk][row 0..3][column
+// 0..15] nibbles = 32 bytes per chunk instead of 128 (the slot-B half of the u16 form is padding there).  Code 0 pads:
+// the reference's nucleotide matrices score it -1 against everything (matrices.cc:531-538), like SWA_PAD.
+extern "C" __global__ void __launch_bounds__(256)
+swa_format_stream4(swa_seqs sq, const int32_t* __restrict__ slots, const swa_batch* __restrict__ batches,
+                   int nbatches, uint8_t* __restrict__ stream)
+{
+  const int b = blockIdx.x;
+  if (b >= nbatches) return;
+  const swa_batch bd = batches[b];
+  const int32_t* sl = slots + (int64_t)b * SWA_SLOTS;
+  uint8_t* out = stream + (int64_t)bd.offset * 32;
+  const int total = ((bd.steps + 15) >> 4) * 32;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int chunk = e >> 5, byte = e & 31, grp = byte >> 3, l = (byte & 7) * 2;
+    const int32_t s = sl[grp * 2];
+    u32 v = 0;
+    if (s >= 0) {
+      int64_t o, n;
+      seq_span(sq, s, o, n);
+      const int64_t t = (int64_t)chunk * 16 + l;
+      if (t < n) v = seq_residue(sq, o + t) & 15u;
+      if (t + 1 < n) v |= (seq_residue(sq, o + t + 1) & 15u) << 4;
+    }
+    out[e] = (uint8_t)v;
+  }
 }
 
 // Six-frame translation of a nucleotide shard into the protein residues the DP kernels consume - the
@@ -600,8 +627,7 @@ swa_filter_hits(const int* __restrict__ scores, const long long* __restrict__ sc
 // One thread per sequence, H/E columns in global scratch ([row][thread], coalesced); at most a few
 // hundred sequences per query, so throughput is irrelevant here.
 extern "C" __global__ void __launch_bounds__(64)
-swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                     const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
+swa_endpoints_kernel(swa_seqs sq, const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
                      const uint8_t* __restrict__ qseq, int qlen,
                      const int32_t* __restrict__ matrix, long long Q, long long R,
                      long long* __restrict__ Hs, long long* __restrict__ Es,
@@ -610,14 +636,15 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int stride = gridDim.x * blockDim.x;
-  const int64_t o = offsets[ids[t]], len = offsets[ids[t] + 1] - o;
+  int64_t o, len;
+  seq_span(sq, ids[t], o, len);
   // minus[t]: the reverse complement of a nucleotide sequence, as db_getsequence hands it out for
   // strand 1 (database.cc:1327-1339); complementing a one-hot/IUPAC nibble = reversing its 4 bits
   const bool rc = minus && minus[t];
   for (int i = 0; i < qlen; ++i) { Hs[(int64_t)i * stride + t] = 0; Es[(int64_t)i * stride + t] = 0; }
   long long S = 0, bp = 0, bq = -1;                       // d_best = d_begin, q_best = -1 (search16s.cc:483-486)
   for (int64_t j = 0; j < len; ++j) {
-    const int sym = rc ? (int)(__brev((unsigned)residues[o + len - 1 - j]) >> 28) : (int)residues[o + j];
+    const int sym = rc ? (int)(__brev(seq_residue(sq, o + len - 1 - j)) >> 28) : (int)seq_residue(sq, o + j);
     const int32_t* row = matrix + (sym << 5);
     long long hd = 0, f = 0, cm = 0, cq = -1;
     for (int i = 0; i < qlen; ++i) {
@@ -653,14 +680,14 @@ swa_endpoints_kernel(const uint8_t* __restrict__ residues, const int64_t* __rest
 // one sequence [o, o + len) against the query, by the 64 lanes of the calling wave (a block of its own: M and ring are
 // its LDS); returns the wave-wide best / first column / smallest row in every lane
 template <int K, bool POS>
-__device__ __forceinline__ void endpoints_wave_one(const int* M, uint8_t* ring, const uint8_t* __restrict__ residues, int64_t o,
+__device__ __forceinline__ void endpoints_wave_one(const int* M, uint8_t* ring, const swa_seqs& sq, int64_t o,
                                                    int len, bool rc, const uint8_t* __restrict__ qseq, int qlen, int Q, int R,
                                                    int* mybh, int* mybf, int& best, int& bcol, int& brow)
 {
   const int g = threadIdx.x;
   auto residue = [&](int c) -> u32 {
     if (c >= len) return 0;
-    return rc ? (__brev((u32)residues[o + len - 1 - c]) >> 28) : (u32)residues[o + c];
+    return rc ? (__brev(seq_residue(sq, o + len - 1 - c)) >> 28) : seq_residue(sq, o + c);
   };
   best = 0; bcol = 0; brow = -1;
   for (int row0 = 0; row0 < qlen; row0 += 64 * K) {
@@ -741,8 +768,7 @@ __device__ __forceinline__ void endpoints_wave_one(const int* M, uint8_t* ring, 
 
 template <int K, bool POS = true>
 __global__ void __launch_bounds__(64)
-swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                          const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
+swa_endpoints_wave_kernel(swa_seqs sq, const int32_t* __restrict__ ids, const uint8_t* __restrict__ minus, int n,
                           const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
                           int* __restrict__ bh, int* __restrict__ bf, const int64_t* __restrict__ boff,
                           long long* __restrict__ out_score, long long* __restrict__ out_pos, long long* __restrict__ out_q,
@@ -753,11 +779,12 @@ swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* _
   const int w = blockIdx.x, g = threadIdx.x;
   if (w >= n) return;
   for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
-  const int64_t o = offsets[ids[w]];
-  const int len = (int)(offsets[ids[w] + 1] - o);
+  int64_t o, len64;
+  seq_span(sq, ids[w], o, len64);
+  const int len = (int)len64;
   const bool rc = minus && minus[w];
   int best, bcol, brow;
-  endpoints_wave_one<K, POS>(M, ring, residues, o, len, rc, qseq, qlen, Q, R, bh ? bh + boff[w] : nullptr,
+  endpoints_wave_one<K, POS>(M, ring, sq, o, len, rc, qseq, qlen, Q, R, bh ? bh + boff[w] : nullptr,
                              bf ? bf + boff[w] : nullptr, best, bcol, brow);
   if (g == 0) {
     if (scores) scores[ids[w]] = best;           // re-queue use: the score of the sequence, in place
@@ -772,8 +799,7 @@ swa_endpoints_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* _
 // over by the host there.  Single pass of the wave kernel only: qlen <= 64 K.
 template <int K>
 __global__ void __launch_bounds__(64)
-swa_requeue_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                        const int32_t* __restrict__ list, const int32_t* __restrict__ count, int cap, int32_t* __restrict__ work,
+swa_requeue_wave_kernel(swa_seqs sq, const int32_t* __restrict__ list, const int32_t* __restrict__ count, int cap, int32_t* __restrict__ work,
                         const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
                         int* __restrict__ scores)
 {
@@ -794,10 +820,11 @@ swa_requeue_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __r
     const int w = next;
     if (w >= n) break;
     const int id = list[w];
-    const int64_t o = offsets[id];
-    const int len = (int)(offsets[id + 1] - o);
+    int64_t o, len64;
+    seq_span(sq, id, o, len64);
+    const int len = (int)len64;
     int best, bcol, brow;
-    endpoints_wave_one<K, false>(M, ring, residues, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
+    endpoints_wave_one<K, false>(M, ring, sq, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
     if (g == 0) scores[id] = best;
   }
 }
@@ -812,8 +839,7 @@ swa_requeue_wave_kernel(const uint8_t* __restrict__ residues, const int64_t* __r
 // kernels are not co-resident (register file full: the exact build) the follower simply runs after the producer.
 template <int K>
 __global__ void __launch_bounds__(64)
-swa_requeue_follow_kernel(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets,
-                          const int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
+swa_requeue_follow_kernel(swa_seqs sq, const int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
                           const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
                           int* __restrict__ scores)
 {
@@ -850,10 +876,11 @@ swa_requeue_follow_kernel(const uint8_t* __restrict__ residues, const int64_t* _
     const int id = next;
     const bool last = leave != 0;
     if (id >= 0) {
-      const int64_t o = offsets[id];
-      const int len = (int)(offsets[id + 1] - o);
+      int64_t o, len64;
+      seq_span(sq, id, o, len64);
+      const int len = (int)len64;
       int best, bcol, brow;
-      endpoints_wave_one<K, false>(M, ring, residues, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
+      endpoints_wave_one<K, false>(M, ring, sq, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
       if (g == 0) scores[id] = best;
     }
     // the first pass is through: whatever is left belongs to the finishing kernel (swa_requeue_wave_kernel on the first
@@ -1005,28 +1032,31 @@ extern "C" hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int b
   }
   return hipErrorInvalidValue;
 }
-extern "C" hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
-                                        const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st)
+extern "C" hipError_t swa_launch_format(const swa_seqs* sq, const int32_t* slots, const swa_batch* batches, int nbatches,
+                                        void* stream, int nibbles, hipStream_t st)
 {
   if (nbatches <= 0) return hipSuccess;
-  hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, residues, offsets, slots, batches, nbatches, stream, 0);
+  if (nibbles) hipLaunchKernelGGL(swa_format_stream4, dim3(nbatches), dim3(256), 0, st, *sq, slots, batches, nbatches, (uint8_t*)stream);
+  else hipLaunchKernelGGL(swa_format_stream, dim3(nbatches), dim3(256), 0, st, *sq, slots, batches, nbatches, (uint16_t*)stream);
   return hipGetLastError();
 }
 // the sequences the alignment phase wants back on the host, packed one after the other (one block per sequence)
 extern "C" __global__ void __launch_bounds__(256)
-swa_gather_sequences(const uint8_t* __restrict__ residues, const int64_t* __restrict__ offsets, const int* __restrict__ ids,
-                     const int64_t* __restrict__ out_off, int n, uint8_t* __restrict__ out)
+swa_gather_sequences(swa_seqs sq, const int* __restrict__ ids, const int64_t* __restrict__ out_off, int n,
+                     uint8_t* __restrict__ out)
 {
   const int i = blockIdx.x;
   if (i >= n) return;
-  const int64_t o = offsets[ids[i]], len = offsets[ids[i] + 1] - o, d = out_off[i];
-  for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[d + k] = residues[o + k];
+  int64_t o, len;
+  seq_span(sq, ids[i], o, len);
+  const int64_t d = out_off[i];
+  for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[d + k] = (uint8_t)seq_residue(sq, o + k);   // one byte per residue
 }
-extern "C" hipError_t swa_launch_gather(const uint8_t* residues, const int64_t* offsets, const int* ids, const int64_t* out_off,
-                                        int n, uint8_t* out, hipStream_t st)
+extern "C" hipError_t swa_launch_gather(const swa_seqs* sq, const int* ids, const int64_t* out_off, int n, uint8_t* out,
+                                        hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(swa_gather_sequences, dim3(n), dim3(256), 0, st, residues, offsets, ids, out_off, n, out);
+  hipLaunchKernelGGL(swa_gather_sequences, dim3(n), dim3(256), 0, st, *sq, ids, out_off, n, out);
   return hipGetLastError();
 }
 // excluded sequences (OID mask / taxid filter) report -1 so that no score threshold >= 0 ever accepts them
@@ -1050,14 +1080,13 @@ extern "C" hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* nto
   hipLaunchKernelGGL(swa_translate_frames, dim3(blocks), dim3(256), 0, st, nt, ntoff, voff, nv, table, prot, total);
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
-                                           const uint8_t* minus, int n,
+extern "C" hipError_t swa_launch_endpoints(const swa_seqs* sq, const int32_t* ids, const uint8_t* minus, int n,
                                            const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                            long long* Hs, long long* Es, long long* out, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
   const int blocks = (n + 63) / 64;
-  hipLaunchKernelGGL(swa_endpoints_kernel, dim3(blocks), dim3(64), 0, st, residues, offsets, ids, minus, n, qseq, qlen, matrix, Q, R,
+  hipLaunchKernelGGL(swa_endpoints_kernel, dim3(blocks), dim3(64), 0, st, *sq, ids, minus, n, qseq, qlen, matrix, Q, R,
                      Hs, Es, out, out + n, out + 2 * (size_t)n);
   return hipGetLastError();
 }
@@ -1069,15 +1098,14 @@ extern "C" int swa_endpoints_rows_for(int qlen)
   for (int r : rows) if (qlen <= 64 * r) return r;
   return 32;
 }
-extern "C" hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
-                                                const uint8_t* minus, int n, const uint8_t* qseq, int qlen,
+extern "C" hipError_t swa_launch_endpoints_wave(const swa_seqs* sq, const int32_t* ids, const uint8_t* minus, int n, const uint8_t* qseq, int qlen,
                                                 const int32_t* matrix, int Q, int R, int* bh, int* bf,
                                                 const int64_t* boff, long long* out, int* scores, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-#define SWA_EPW(KK) { if (scores) hipLaunchKernelGGL((swa_endpoints_wave_kernel<KK, false>), dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
+#define SWA_EPW(KK) { if (scores) hipLaunchKernelGGL((swa_endpoints_wave_kernel<KK, false>), dim3(n), dim3(64), 0, st, *sq, ids, minus, n, \
                                        qseq, qlen, matrix, Q, R, bh, bf, boff, out, out, out, scores); \
-                      else hipLaunchKernelGGL((swa_endpoints_wave_kernel<KK, true>), dim3(n), dim3(64), 0, st, residues, offsets, ids, minus, n, \
+                      else hipLaunchKernelGGL((swa_endpoints_wave_kernel<KK, true>), dim3(n), dim3(64), 0, st, *sq, ids, minus, n, \
                                        qseq, qlen, matrix, Q, R, bh, bf, boff, out, out + n, out + 2 * (size_t)n, scores); }
   switch (swa_endpoints_rows_for(qlen)) {
     case 2: SWA_EPW(2); break;
@@ -1092,11 +1120,10 @@ extern "C" hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const i
 #undef SWA_EPW
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* list,
-                                              const int32_t* count, int cap, int32_t* work, const uint8_t* qseq, int qlen,
+extern "C" hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t* list, const int32_t* count, int cap, int32_t* work, const uint8_t* qseq, int qlen,
                                               const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
 {
-#define SWA_RQW(KK) hipLaunchKernelGGL((swa_requeue_wave_kernel<KK>), dim3(blocks), dim3(64), 0, st, residues, offsets, list, count, \
+#define SWA_RQW(KK) hipLaunchKernelGGL((swa_requeue_wave_kernel<KK>), dim3(blocks), dim3(64), 0, st, *sq, list, count, \
                                        cap, work, qseq, qlen, matrix, Q, R, scores)
   switch (swa_endpoints_rows_for(qlen)) {
     case 2: SWA_RQW(2); break;
@@ -1111,11 +1138,11 @@ extern "C" hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int
 #undef SWA_RQW
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_requeue_follow(const uint8_t* residues, const int64_t* offsets, const int32_t* list, int cap,
+extern "C" hipError_t swa_launch_requeue_follow(const swa_seqs* sq, const int32_t* list, int cap,
                                                 int32_t* work, const int32_t* done, const uint8_t* qseq, int qlen,
                                                 const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
 {
-#define SWA_RQF(KK) hipLaunchKernelGGL((swa_requeue_follow_kernel<KK>), dim3(blocks), dim3(64), 0, st, residues, offsets, list, cap, \
+#define SWA_RQF(KK) hipLaunchKernelGGL((swa_requeue_follow_kernel<KK>), dim3(blocks), dim3(64), 0, st, *sq, list, cap, \
                                        work, done, qseq, qlen, matrix, Q, R, scores)
   switch (swa_endpoints_rows_for(qlen)) {
     case 2: SWA_RQF(2); break;

@@ -39,15 +39,14 @@ hipError_t swa_launch_narrow_bound_g8(int K, const swa_narrow_params* p, int blo
 hipError_t swa_launch_narrow_bound_g16(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_bound_period(void);
 int swa_bound_available(int G, int K);
-hipError_t swa_launch_gather(const uint8_t* residues, const int64_t* offsets, const int* ids, const int64_t* out_off, int n,
-                             uint8_t* out, hipStream_t st);
+hipError_t swa_launch_gather(const swa_seqs* sq, const int* ids, const int64_t* out_off, int n, uint8_t* out, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
-hipError_t swa_launch_endpoints(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
+hipError_t swa_launch_endpoints(const swa_seqs* sq, const int32_t* ids,
                                 const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix, long long Q, long long R,
                                 long long* Hs, long long* Es, long long* out, hipStream_t st);
 int swa_endpoints_rows_for(int qlen);
-hipError_t swa_launch_endpoints_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* ids,
+hipError_t swa_launch_endpoints_wave(const swa_seqs* sq, const int32_t* ids,
                                      const uint8_t* minus, int n, const uint8_t* qseq, int qlen, const int32_t* matrix,
                                      int Q, int R, int* bh, int* bf, const int64_t* boff, long long* out, int* scores,
                                      hipStream_t st);
@@ -57,15 +56,15 @@ hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const i
 int swa_dual_rows_for(int qlen, int nres, int G);
 hipError_t swa_launch_dual(int K, int nres, int G, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
-hipError_t swa_launch_format(const uint8_t* residues, const int64_t* offsets, const int32_t* slots,
-                             const swa_batch* batches, int nbatches, uint16_t* stream, hipStream_t st);
+hipError_t swa_launch_format(const swa_seqs* sq, const int32_t* slots, const swa_batch* batches, int nbatches, void* stream,
+                             int nibbles, hipStream_t st);
 hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,
                              long long maxscore, int* cand_count, int cand_cap, swa_cand* cand,
                              unsigned long long* tallies, hipStream_t st);
-hipError_t swa_launch_requeue_follow(const uint8_t* residues, const int64_t* offsets, const int32_t* list, int cap, int32_t* work,
+hipError_t swa_launch_requeue_follow(const swa_seqs* sq, const int32_t* list, int cap, int32_t* work,
                                      const int32_t* done, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                      int* scores, int blocks, hipStream_t st);
-hipError_t swa_launch_requeue_wave(const uint8_t* residues, const int64_t* offsets, const int32_t* list, const int32_t* count,
+hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t* list, const int32_t* count,
                                    int cap, int32_t* work, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                    int* scores, int blocks, hipStream_t st);
 }
@@ -113,6 +112,8 @@ struct BatchSet {
   int nbatches = 0;
   int64_t chunks = 0;
   std::vector<int32_t> h_steps;             // steps of every batch (non-increasing: batches are cut from a length-sorted list)
+  bool nibbles = false;                     // one-sequence-per-row stream of a nucleotide shard at 4 bits per base (32-byte chunks)
+  bool built = false;
 };
 
 // Tuning / test knobs of one handle (swa_set_option).  The defaults are what the measurements in DESIGN.md chose;
@@ -196,12 +197,20 @@ struct swa_db {
   hipStream_t stream2 = nullptr;           // the re-queue follower's stream
   hipEvent_t ev2[2] = {nullptr, nullptr};  // [0] stream -> stream2: inputs uploaded; [1] stream2 -> stream: follower through
 
-  DevBuf<uint8_t> residues;
+  DevBuf<uint8_t> residues;                // one byte per residue; nucleotide shards: two per byte (packed), low nibble first
+  bool packed = false;
   DevBuf<int64_t> offsets;
-  BatchSet main;                           // all sequences, two per DPP row
+  BatchSet main;                           // all sequences, two per DPP row (nucleotide shards: built on first use)
   BatchSet scratch;                        // re-queued sequences, one per DPP row
   BatchSet single;                         // all sequences, one per DPP row (built on first use)
-  bool single_built = false;
+  BatchSet single4;                        // the same at 4 bits per base: what the two-query kernel streams for nucleotide shards
+  // windows of long sequences (ids nseq + v), see "windows" below
+  DevBuf<int64_t> wstart;
+  DevBuf<int32_t> wlen;
+  std::vector<int64_t> h_wstart;
+  std::vector<int32_t> h_wlen;
+  int64_t len_of(int64_t id) const { return id < nseq ? h_offsets[size_t(id) + 1] - h_offsets[size_t(id)] : h_wlen[size_t(id - nseq)]; }
+  swa_seqs seqs() const { return swa_seqs{residues.p, offsets.p, packed ? 1 : 0, int32_t(nseq), wstart.p, wlen.p}; }
   DevBuf<int32_t> scores;
   DevBuf<long long> scores64;
   DevBuf<long long> scores64b;              // 64-bit scores of the second query of a dual search
@@ -250,7 +259,8 @@ struct swa_db {
   {
     return residues.bytes() + offsets.bytes() + main.slots.bytes() + main.batches.bytes() + main.stream.bytes() +
            scratch.slots.bytes() + scratch.batches.bytes() + scratch.stream.bytes() + single.slots.bytes() +
-           single.batches.bytes() + single.stream.bytes() + scores2.bytes() + boundary.bytes() + scores.bytes() +
+           single.batches.bytes() + single.stream.bytes() + single4.slots.bytes() + single4.batches.bytes() +
+           single4.stream.bytes() + scores2.bytes() + boundary.bytes() + scores.bytes() +
            scores64.bytes() + scores64b.bytes() + ovf_list.bytes() + ovf_list2.bytes() + ctl.bytes();
   }
 };
@@ -260,7 +270,7 @@ namespace {
 // Lay `ids` (already ordered by descending length) out as batches with `per_row` sequences per
 // DPP row (2 = packed pairs for the f16 kernel, 1 = slot A only for the wide kernels), upload,
 // and run the formatting kernel.
-int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchSet& bs)
+int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchSet& bs, bool nibbles = false)
 {
   const int per_batch = 4 * per_row;
   const int64_t nb = (n + per_batch - 1) / per_batch;
@@ -276,7 +286,7 @@ int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchS
       const int32_t id = ids[i];
       const int row = j / per_row, half = j % per_row;
       slots[size_t(b) * SWA_SLOTS + row * 2 + half] = id;
-      const int64_t len = db->h_offsets[id + 1] - db->h_offsets[id];
+      const int64_t len = db->len_of(id);
       if (len > longest) longest = len;
     }
     const int64_t steps = std::max<int64_t>(16, (longest + 1) & ~int64_t(1));   // even, and at least one full chunk
@@ -288,13 +298,16 @@ int build_batches(swa_db* db, const int32_t* ids, int64_t n, int per_row, BatchS
   }
   HIP_TRY(bs.slots.reserve(slots.size()));
   HIP_TRY(bs.batches.reserve(batches.size()));
-  HIP_TRY(bs.stream.reserve(size_t(chunk_total) * 64));
+  HIP_TRY(bs.stream.reserve(size_t(chunk_total) * (nibbles ? 16 : 64)));      // 32 / 128 bytes per 16-column chunk
   if (nb) {
+    const swa_seqs sq = db->seqs();
     HIP_TRY(hipMemcpyAsync(bs.slots.p, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, db->stream));
     HIP_TRY(hipMemcpyAsync(bs.batches.p, batches.data(), batches.size() * sizeof(swa_batch), hipMemcpyHostToDevice, db->stream));
-    HIP_TRY(swa_launch_format(db->residues.p, db->offsets.p, bs.slots.p, bs.batches.p, int(nb), bs.stream.p, db->stream));
+    HIP_TRY(swa_launch_format(&sq, bs.slots.p, bs.batches.p, int(nb), bs.stream.p, nibbles ? 1 : 0, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));     // host vectors go out of scope
   }
+  bs.nibbles = nibbles;
+  bs.built = true;
   bs.nbatches = int(nb);
   bs.chunks = int64_t(chunk_total);
   bs.h_steps.resize(size_t(nb));
@@ -396,7 +409,31 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
     for (hipEvent_t& e : db->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   HIP_TRY(db->offsets.reserve(size_t(nseq) + 1));
-  if (residues) {
+  std::vector<uint8_t> packed_host;
+  if (residues && db->symtype == SWA_SYMTYPE_NUCLEOTIDE) {
+    // nucleotide codes are 4-bit masks (validated above): the shard keeps two per byte - residue i in byte i >> 1, low
+    // nibble first, whatever sequence it belongs to - and every kernel reads them through seq_residue (sw_common.cuh)
+    db->packed = true;
+    const int64_t nbytes = (db->nsym + 1) / 2;
+    packed_host.assign(size_t(nbytes) + 16, 0);
+    const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, nbytes >> 22}));
+    auto pack = [&](int64_t t) {
+      const uint8_t* src = residues + base;
+      const int64_t lo = nbytes * t / nthreads, hi = nbytes * (t + 1) / nthreads;
+      for (int64_t b = lo; b < hi; ++b) {
+        const int64_t i = 2 * b;
+        packed_host[size_t(b)] = uint8_t((src[i] & 15) | (i + 1 < db->nsym ? (src[i + 1] & 15) << 4 : 0));
+      }
+    };
+    if (nthreads == 1) pack(0);
+    else {
+      std::vector<std::thread> pool;
+      for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(pack, t);
+      for (std::thread& t : pool) t.join();
+    }
+    HIP_TRY(db->residues.reserve(size_t(nbytes) + 16));
+    if (nbytes) HIP_TRY(hipMemcpyAsync(db->residues.p, packed_host.data(), size_t(nbytes), hipMemcpyHostToDevice, db->stream));
+  } else if (residues) {
     HIP_TRY(db->residues.reserve(size_t(db->nsym) + 16));
     if (db->nsym) HIP_TRY(hipMemcpyAsync(db->residues.p, residues + base, size_t(db->nsym), hipMemcpyHostToDevice, db->stream));
   }
@@ -407,6 +444,11 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   HIP_TRY(db->ctl.reserve(48 + size_t(db->cand_cap) * (sizeof(swa_cand) / sizeof(int32_t))));
   HIP_TRY(db->matrix.reserve(1024));
   order_by_length(db->h_offsets, nullptr, nseq, db->h_order);
+  HIP_TRY(hipStreamSynchronize(db->stream));           // packed_host goes out of scope
+  db->main.built = db->single.built = db->single4.built = false;
+  // a nucleotide shard is searched with both strands in one pass over the one-sequence-per-row stream (single4): its
+  // pair stream is only built if a single-strand search or a short query asks for it
+  if (db->packed) return SWA_OK;
   return build_batches(db, db->h_order.data(), nseq, 2, db->main);
 }
 
@@ -419,10 +461,28 @@ uint32_t f16_pair(float v)
 // all sequences, one per DPP row (dual-query kernel, and the 32-bit kernel when f16 does not apply)
 int ensure_single(swa_db* db)
 {
-  if (db->single_built) return SWA_OK;
-  const int rc = build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 1, db->single);
-  if (rc == SWA_OK) db->single_built = true;
-  return rc;
+  if (db->single.built) return SWA_OK;
+  return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 1, db->single);
+}
+// the same at 4 bits per base (nucleotide shards, two-query kernel with 16-lane chains)
+int ensure_single4(swa_db* db)
+{
+  if (db->single4.built) return SWA_OK;
+  return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 1, db->single4, true);
+}
+// all sequences, two per DPP row
+int ensure_main(swa_db* db)
+{
+  if (db->main.built) return SWA_OK;
+  return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 2, db->main);
+}
+// The 4-bit stream pads with code 0, which must not score: true of every matrix swa_matrix_nucleotide makes
+// (matrices.cc:531-538 leaves row 0 at -1); a caller's own matrix with a positive entry there takes the 16-bit stream
+bool nibble_stream_ok(const swa_db* db)
+{
+  if (!db->packed) return false;
+  for (int q = 0; q < 32; ++q) if (db->h_matrix[q] > 0) return false;
+  return true;
 }
 
 struct MpRun {
@@ -669,8 +729,9 @@ int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
 {
   int npass = 0, K = 0;
   dual_pass_shape(qlen, nres, &npass, &K);
-  const BatchSet& bs = db->single;
+  const BatchSet& bs = nibble_stream_ok(db) ? db->single4 : db->single;
   swa_mp_params p{};
+  p.nibbles = bs.nibbles ? 1 : 0;
   p.qseq = db->qseq_p;
   p.qseq2 = db->qseq2_p;
   p.matrix = db->matrix.p;
@@ -805,6 +866,7 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
   // time): a wave per sequence - the end-point kernel of the alignment phase, 64 lanes on one sequence - finishes the
   // 1 500 sequences the bound build sends back for the bench query in 1.3 ms instead of 1.5, the 390 of a 5 000-row
   // query in a fraction of the batch kernel's 20 passes.
+  const swa_seqs sq = db->seqs();
   bool by_wave = !requeue.empty() && requeue.size() <= size_t(REQUEUE_CAP) && int64_t(requeue.size()) < db->nseq &&
                  wave_requeue_ok(db, qlen);
   const bool passes = by_wave && qlen > 64 * swa_endpoints_rows_for(int(qlen));   // over 2 048 rows: hand-over per column
@@ -827,7 +889,7 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
       HIP_TRY(db->rq_boff.reserve(requeue.size()));
       HIP_TRY(hipMemcpyAsync(db->rq_boff.p, boff.data(), boff.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(swa_launch_endpoints_wave(db->residues.p, db->offsets.p, db->rq_ids.p, nullptr, int(requeue.size()), qdev, int(qlen),
+    HIP_TRY(swa_launch_endpoints_wave(&sq, db->rq_ids.p, nullptr, int(requeue.size()), qdev, int(qlen),
                                       db->matrix.p, int(db->goe), int(db->ge), passes ? db->rq_bh.p : nullptr,
                                       passes ? db->rq_bf.p : nullptr, passes ? db->rq_boff.p : nullptr, nullptr, scores, st));
     HIP_TRY(hipStreamSynchronize(st));                 // the id list lives in the caller's vector
@@ -952,6 +1014,9 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   if (rc != SWA_OK) return rc;
   const swa_query* dquery = reinterpret_cast<const swa_query*>(db->qblock.p);
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
+  rc = ensure_main(db);                                  // nucleotide shards build their pair stream on first use
+  if (rc != SWA_OK) return rc;
+  const swa_seqs sq = db->seqs();
 
   std::vector<int32_t> requeue;
   bool used_bound = false, follow = false;
@@ -1032,7 +1097,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       // few waves: they only have to keep up with the trickle of entries while the first pass runs (measured: 128 blocks
       // cost the first pass nothing, 1 024 cost it 37 %); what is left at its end goes to the finishing kernel below
       const int fblocks = db->opt.requeue_follow > 1 ? int(db->opt.requeue_follow) : std::max(1, db->cus / 2);
-      HIP_TRY(swa_launch_requeue_follow(db->residues.p, db->offsets.p, db->ovf_list.p, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)), db->ctl.p + 4,
+      HIP_TRY(swa_launch_requeue_follow(&sq, db->ovf_list.p, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)), db->ctl.p + 4,
                                         db->ctl.p + CTL_DONE, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge),
                                         db->scores.p, fblocks, db->stream2));
       HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
@@ -1082,14 +1147,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   pd.used_bound = used_bound;
   if (follow) {
     // the finishing kernel takes what the follower's few waves did not get to (same work-queue head), then both are awaited
-    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)),
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)),
                                     db->ctl.p + 4, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p,
                                     db->cus * 8, st));
     HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
     pd.dev1 = true;
   } else if (c.narrow && device_requeue_ok(db, qlen)) {
     // the list stays on the device: a persistent grid of waves takes entries off it until the count the first pass left
-    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
                                     db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
     pd.dev1 = true;
   } else {
@@ -1133,9 +1198,9 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   rc = upload_queries(db, q1, q2, qlen, st);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
-  rc = ensure_single(db);
-  if (rc != SWA_OK) return rc;
   std::vector<int32_t> rq1, rq2;
+  const swa_seqs sq = db->seqs();
+  const bool nib = nibble_stream_ok(db);                 // nucleotide shard: 16-lane chains stream 4 bits per base
   bool listed = false;                                   // the first pass left re-queue lists on the device
   bool used_bound = false;
   HIP_TRY(hipEventRecord(db->ev[1], st));
@@ -1153,8 +1218,11 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
   if (db->opt.dual_kmax > 0 && Kd > db->opt.dual_kmax) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
-    const BatchSet& set = Gd == 16 ? db->single : db->main;
+    rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
+    if (rc != SWA_OK) return rc;
+    const BatchSet& set = Gd < 16 ? db->main : nib ? db->single4 : db->single;
     swa_mp_params p{};
+    p.nibbles = set.nibbles ? 1 : 0;
     p.qseq = db->qseq_p;
     p.qseq2 = db->qseq2_p;
     p.matrix = db->matrix.p;
@@ -1193,13 +1261,16 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     c.narrow = db->nseq;
     listed = true;
   } else if (f16_applicable(db) && !dual_mp && Gd == 16 && f16_limit(db, dual_pass_rows(qlen, nres)) >= 1024) {
-    rc = launch_dual_passes(db, qlen, nres, st);         // long queries: one launch per pass of the same kernel
+    rc = nib ? ensure_single4(db) : ensure_single(db);
+    if (rc == SWA_OK) rc = launch_dual_passes(db, qlen, nres, st);   // long queries: one launch per pass of the same kernel
     if (rc != SWA_OK) return rc;
     c.narrow_rows = dual_pass_rows(qlen, nres);
     c.narrow_shifted = 6;
     c.narrow = db->nseq;
     listed = true;
   } else if (f16_applicable(db) && f16_limit(db, mp_rows_for(1, qlen)) >= 1024) {
+    rc = ensure_single(db);
+    if (rc != SWA_OK) return rc;
     MpRun r;
     r.mode = 1;
     r.set = &db->single;
@@ -1221,9 +1292,9 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   HIP_TRY(hipEventRecord(db->ev[2], st));
   pd.used_bound = used_bound;
   if (listed && device_requeue_ok(db, qlen)) {
-    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
                                     db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
-    HIP_TRY(swa_launch_requeue_wave(db->residues.p, db->offsets.p, db->ovf_list2.p, db->ctl.p + 3, REQUEUE_CAP, db->ctl.p + 5,
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list2.p, db->ctl.p + 3, REQUEUE_CAP, db->ctl.p + 5,
                                     db->qseq2_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores2.p, db->cus * 8, st));
     pd.dev1 = pd.dev2 = true;
   } else {
@@ -1546,8 +1617,8 @@ extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t 
   db->n_excluded = int64_t(ex.size());
   HIP_TRY(db->excluded.reserve(ex.size()));
   if (!ex.empty()) HIP_TRY(hipMemcpy(db->excluded.p, ex.data(), ex.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  db->single_built = false;
-  return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 2, db->main);
+  db->main.built = db->single.built = db->single4.built = false;
+  return db->packed ? SWA_OK : ensure_main(db);
 }
 
 extern "C" void swa_db_close(swa_db* db)
@@ -1898,6 +1969,7 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
   }
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
+  const swa_seqs sq = db->seqs();
   const size_t threads = size_t((n + 63) / 64) * 64;
   DevBuf<int32_t> d_ids;
   DevBuf<uint8_t> d_minus;
@@ -1930,7 +2002,7 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
       HIP_TRY(hipMemcpyAsync(d_boff.p, boff.data(), size_t(n) * sizeof(int64_t), hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));          // boff lives on this stack frame
     }
-    HIP_TRY(swa_launch_endpoints_wave(db->residues.p, db->offsets.p, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
+    HIP_TRY(swa_launch_endpoints_wave(&sq, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
                                       db->matrix.p, int(db->goe), int(db->ge), passes ? d_bh.p : nullptr,
                                       passes ? d_bf.p : nullptr, passes ? d_boff.p : nullptr, d_out.p, nullptr, st));
     out.resize(3 * size_t(n));
@@ -1940,7 +2012,7 @@ int endpoints_on_device(swa_db* db, const uint8_t* query, int64_t qlen, const in
   }
   HIP_TRY(d_h.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
   HIP_TRY(d_e.reserve(threads * size_t(qlen > 0 ? qlen : 1)));
-  HIP_TRY(swa_launch_endpoints(db->residues.p, db->offsets.p, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
+  HIP_TRY(swa_launch_endpoints(&sq, d_ids.p, d_minus.p, int(n), db->qseq.p, int(qlen),
                                db->matrix.p, db->goe, db->ge, d_h.p, d_e.p, d_out.p, st));
   out.resize(3 * size_t(n));
   HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -1959,7 +2031,14 @@ int fetch_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, std::vect
   seq.resize(size_t(len));
   if (len) {
     HIP_TRY(hipSetDevice(db->device));
-    HIP_TRY(hipMemcpy(seq.data(), db->residues.p + o, size_t(len), hipMemcpyDeviceToHost));
+    if (db->packed) {                                    // two residues per byte: the covering bytes, unpacked here
+      const int64_t b0 = o >> 1, b1 = (o + len + 1) >> 1;
+      std::vector<uint8_t> raw(size_t(b1 - b0));
+      HIP_TRY(hipMemcpy(raw.data(), db->residues.p + b0, raw.size(), hipMemcpyDeviceToHost));
+      for (int64_t k = 0; k < len; ++k) seq[size_t(k)] = (raw[size_t(((o + k) >> 1) - b0)] >> (((o + k) & 1) * 4)) & 15;
+    } else {
+      HIP_TRY(hipMemcpy(seq.data(), db->residues.p + o, size_t(len), hipMemcpyDeviceToHost));
+    }
   }
   if (minus) {
     static const uint8_t compl4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // database.cc ntcompl
@@ -1989,6 +2068,7 @@ int fetch_sequences(swa_db* db, const int64_t* seqnos, const int32_t* dstrands, 
   const int64_t total = out_off[size_t(n)];
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
+  const swa_seqs sq = db->seqs();
   DevBuf<int32_t> d_ids;
   DevBuf<int64_t> d_off;
   DevBuf<uint8_t> d_out;
@@ -1997,7 +2077,7 @@ int fetch_sequences(swa_db* db, const int64_t* seqnos, const int32_t* dstrands, 
   HIP_TRY(d_out.reserve(size_t(total) + 1));
   HIP_TRY(hipMemcpyAsync(d_ids.p, ids.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_off.p, out_off.data(), size_t(n) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-  HIP_TRY(swa_launch_gather(db->residues.p, db->offsets.p, d_ids.p, d_off.p, int(n), d_out.p, st));
+  HIP_TRY(swa_launch_gather(&sq, d_ids.p, d_off.p, int(n), d_out.p, st));
   std::vector<uint8_t> all(size_t(total) + 1);
   HIP_TRY(hipMemcpyAsync(all.data(), d_out.p, size_t(total), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
