@@ -182,6 +182,10 @@ SWA_API void swa_db_close(swa_db* db);
      wave_requeue     0: re-queued sequences always by the batch kernels; -1 auto
      requeue_host     1: the host reads the re-queue list between the passes (two more stream synchronisations)
      requeue_follow   0: the re-queue kernel runs after the first pass instead of beside it on a second stream
+     window           long database sequences are searched as overlapping windows and folded back (scores stay exact:
+                      the overlap is the longest span a positive-scoring alignment can have): -1 auto, 0 never,
+                      n > 0 every sequence longer than n
+     window_step      distance between window starts; 0 = from the query length and scoring system
      endpoints_thread 1 ("thread"): one-thread 64-bit end-point kernel; 0 ("wave")
    A new handle takes its initial values from the environment variables SWA_<KEY> ONCE, at creation; the search path
    never reads the environment.  Unknown keys and unparsable values return SWA_EINVAL. */

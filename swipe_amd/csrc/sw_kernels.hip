@@ -1059,6 +1059,44 @@ extern "C" hipError_t swa_launch_gather(const swa_seqs* sq, const int* ids, cons
   hipLaunchKernelGGL(swa_gather_sequences, dim3(n), dim3(256), 0, st, *sq, ids, out_off, n, out);
   return hipGetLastError();
 }
+// a view's copy of a set's batch table: same steps, chunk offsets counted from the view's base pointer
+extern "C" __global__ void swa_rebase_batches(const swa_batch* __restrict__ src, swa_batch* __restrict__ dst, int n, u32 delta)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { swa_batch b = src[i]; b.offset += delta; dst[i] = b; }
+}
+extern "C" hipError_t swa_launch_rebase(const swa_batch* src, swa_batch* dst, int n, uint32_t delta, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swa_rebase_batches, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, n, delta);
+  return hipGetLastError();
+}
+// long sequences searched as overlapping windows (ids nseq + v): the score of parent i is the maximum over its windows
+// [wfirst[i], wfirst[i + 1]) - exactly, see swipe_amd.cpp "windows".  Scores beyond 32 bits sit in scores64 behind the
+// sentinel, for windows as for sequences.
+extern "C" __global__ void swa_fold_windows(int* __restrict__ scores, long long* __restrict__ scores64,
+                                            const int32_t* __restrict__ parents, const int32_t* __restrict__ wfirst,
+                                            int nparents, int nseq)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nparents) return;
+  long long best = -1;
+  for (int v = wfirst[i]; v < wfirst[i + 1]; ++v) {
+    long long sc = scores[nseq + v];
+    if (sc == SWA_SCORE_IN_64) sc = scores64[nseq + v];
+    best = sc > best ? sc : best;
+  }
+  const int p = parents[i];
+  if (best >= SWA_SCORE_IN_64) { scores[p] = SWA_SCORE_IN_64; scores64[p] = best; }
+  else scores[p] = (int)best;
+}
+extern "C" hipError_t swa_launch_fold(int* scores, long long* scores64, const int32_t* parents, const int32_t* wfirst,
+                                      int nparents, int nseq, hipStream_t st)
+{
+  if (nparents <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swa_fold_windows, dim3((nparents + 255) / 256), dim3(256), 0, st, scores, scores64, parents, wfirst, nparents, nseq);
+  return hipGetLastError();
+}
 // excluded sequences (OID mask / taxid filter) report -1 so that no score threshold >= 0 ever accepts them
 extern "C" __global__ void swa_mark_excluded(int* __restrict__ scores, const int* __restrict__ ids, int n)
 {

@@ -61,6 +61,9 @@ hipError_t swa_launch_format(const swa_seqs* sq, const int32_t* slots, const swa
 hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,
                              long long maxscore, int* cand_count, int cand_cap, swa_cand* cand,
                              unsigned long long* tallies, hipStream_t st);
+hipError_t swa_launch_rebase(const swa_batch* src, swa_batch* dst, int n, uint32_t delta, hipStream_t st);
+hipError_t swa_launch_fold(int* scores, long long* scores64, const int32_t* parents, const int32_t* wfirst, int nparents, int nseq,
+                           hipStream_t st);
 hipError_t swa_launch_requeue_follow(const swa_seqs* sq, const int32_t* list, int cap, int32_t* work,
                                      const int32_t* done, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                      int* scores, int blocks, hipStream_t st);
@@ -114,6 +117,11 @@ struct BatchSet {
   std::vector<int32_t> h_steps;             // steps of every batch (non-increasing: batches are cut from a length-sorted list)
   bool nibbles = false;                     // one-sequence-per-row stream of a nucleotide shard at 4 bits per base (32-byte chunks)
   bool built = false;
+  // a VIEW (see "windows"): tables of its own over two stream regions addressed from one base pointer
+  const uint16_t* stream_base = nullptr;
+  int nlong = 0;                            // batches [0, nlong) live in the view's own stream region
+  int64_t off_long = 0, off_main = 0;       // chunk offset (from the base) of batch 0 / batch nlong
+  const uint16_t* sp() const { return stream_base ? stream_base : stream.p; }
 };
 
 // Tuning / test knobs of one handle (swa_set_option).  The defaults are what the measurements in DESIGN.md chose;
@@ -134,6 +142,8 @@ struct Options {
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
   int64_t requeue_follow = 1;    // 1: the re-queue kernel runs BESIDE the first pass on a second stream (single-launch first passes)
+  int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
+  int64_t window_step = 0;       // distance between window starts; 0 = from the query (the overlap is never a knob: it is what makes it exact)
 };
 struct OptionKey { const char* key; int64_t Options::*field; };
 const OptionKey kOptionKeys[] = {
@@ -142,7 +152,7 @@ const OptionKey kOptionKeys[] = {
   {"mp_w", &Options::mp_w}, {"boundary_mb", &Options::boundary_mb}, {"wave_requeue", &Options::wave_requeue},
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
-  {"requeue_follow", &Options::requeue_follow},
+  {"requeue_follow", &Options::requeue_follow}, {"window", &Options::window}, {"window_step", &Options::window_step},
 };
 bool parse_option_value(const char* key, const char* value, int64_t* out)
 {
@@ -209,6 +219,12 @@ struct swa_db {
   DevBuf<int32_t> wlen;
   std::vector<int64_t> h_wstart;
   std::vector<int32_t> h_wlen;
+  BatchSet view;                           // the set a search runs over when long sequences are cut into windows
+  const BatchSet* view_of = nullptr;       // ... built over this set
+  int64_t view_O = -1, view_W = 0, view_Lmax = 0;
+  DevBuf<int32_t> wparents, wfirst;        // fold: parent p of windows [wfirst[i], wfirst[i + 1])
+  int nparents = 0;
+  int64_t nwin = 0;
   int64_t len_of(int64_t id) const { return id < nseq ? h_offsets[size_t(id) + 1] - h_offsets[size_t(id)] : h_wlen[size_t(id - nseq)]; }
   swa_seqs seqs() const { return swa_seqs{residues.p, offsets.p, packed ? 1 : 0, int32_t(nseq), wstart.p, wlen.p}; }
   DevBuf<int32_t> scores;
@@ -324,30 +340,29 @@ int persistent_blocks(const swa_db* db, int nbatches)
 }
 
 // sort sequence indices by (length desc, index asc): counting sort when lengths are modest
-void order_by_length(const std::vector<int64_t>& off, const int32_t* ids, int64_t n, std::vector<int32_t>& out)
+template <typename LenOf>
+void order_by_length(const LenOf& len_of, const int32_t* ids, int64_t n, std::vector<int32_t>& out)
 {
   out.resize(size_t(n));
   int64_t longest = 0;
   for (int64_t i = 0; i < n; ++i) {
     const int32_t id = ids ? ids[i] : int32_t(i);
-    longest = std::max(longest, off[id + 1] - off[id]);
+    longest = std::max<int64_t>(longest, len_of(id));
   }
   if (longest <= (int64_t(1) << 24) && n > 1024) {
     std::vector<int64_t> count(size_t(longest) + 2, 0);
     for (int64_t i = 0; i < n; ++i) {
       const int32_t id = ids ? ids[i] : int32_t(i);
-      ++count[size_t(longest - (off[id + 1] - off[id])) + 1];
+      ++count[size_t(longest - len_of(id)) + 1];
     }
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
     for (int64_t i = 0; i < n; ++i) {
       const int32_t id = ids ? ids[i] : int32_t(i);
-      out[size_t(count[size_t(longest - (off[id + 1] - off[id]))]++)] = id;
+      out[size_t(count[size_t(longest - len_of(id))]++)] = id;
     }
   } else {
     for (int64_t i = 0; i < n; ++i) out[size_t(i)] = ids ? ids[i] : int32_t(i);
-    std::stable_sort(out.begin(), out.end(), [&](int32_t a, int32_t b) {
-      return off[a + 1] - off[a] > off[b + 1] - off[b];
-    });
+    std::stable_sort(out.begin(), out.end(), [&](int32_t a, int32_t b) { return len_of(a) > len_of(b); });
   }
 }
 
@@ -443,9 +458,11 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   db->cand_cap = int(std::max<int64_t>(1, std::min<int64_t>(nseq, 1 << 20)));
   HIP_TRY(db->ctl.reserve(48 + size_t(db->cand_cap) * (sizeof(swa_cand) / sizeof(int32_t))));
   HIP_TRY(db->matrix.reserve(1024));
-  order_by_length(db->h_offsets, nullptr, nseq, db->h_order);
+  order_by_length([&](int32_t id) { return db->len_of(id); }, nullptr, nseq, db->h_order);
   HIP_TRY(hipStreamSynchronize(db->stream));           // packed_host goes out of scope
-  db->main.built = db->single.built = db->single4.built = false;
+  db->main.built = db->single.built = db->single4.built = db->view.built = false;
+  db->view_of = nullptr;
+  db->nwin = 0;
   // a nucleotide shard is searched with both strands in one pass over the one-sequence-per-row stream (single4): its
   // pair stream is only built if a single-strand search or a short query asks for it
   if (db->packed) return SWA_OK;
@@ -476,6 +493,168 @@ int ensure_main(swa_db* db)
   if (db->main.built) return SWA_OK;
   return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 2, db->main);
 }
+// ---- windows: long database sequences, score-exact ------------------------------------------------------------------
+// A sequence is worked on by ONE chain of at most 16 lanes, a column per ~1.5 us whatever else the shard holds: a
+// 35 000-residue protein takes 50 ms, a chromosome minutes (the reference streams any length 4 columns at a time,
+// search7.cc:836-847).  Cut it into windows that overlap by the longest stretch of the sequence a positive-scoring
+// alignment can cover,
+//     O = qlen + qlen x hi / R + 1     (at most qlen aligned columns; every further column sits in a gap and costs at
+//                                        least R of a total that cannot exceed qlen x hi),
+// window k = residues [k W, k W + W + O): an alignment starting in [k W, (k + 1) W) lies inside window k whole, a
+// window's best local score never exceeds the sequence's, so the MAXIMUM OVER THE WINDOWS IS THE SCORE - exactly.
+// Windows are searched as sequences of their own (ids nseq + v, swa_seqs.wstart / wlen) by the same kernels, re-queued
+// one by one, and folded into their parents (swa_fold_windows) before anything reads the scores.
+// Which sequences: longer than Lmax = max(1.5 (W + O), half the columns one chain gets if the shard is spread evenly
+// over 64 chains per CU) - below that a sequence cannot outlast the rest of the shard.  W + O = max(1.25 O, 4096).
+// The set a search launches over becomes a VIEW: tables of its own = [windows + the few sequences sharing the first
+// batches | the set's remaining batches, offsets rebased], two stream regions under one base pointer; nothing is copied
+// but 12 bytes per batch.  Rebuilt when the query changes O; shards without long sequences never build one.
+struct WindowPlan { bool on = false; int64_t O = 0, W = 0, Lmax = 0; };
+WindowPlan plan_windows(const swa_db* db, int64_t qlen)
+{
+  WindowPlan w;
+  if (db->opt.window == 0 || db->ge <= 0 || db->h_order.empty()) return w;
+  w.O = db->hi > 0 ? qlen + qlen * db->hi / db->ge + 1 : qlen + 1;
+  const int64_t wlen = std::max<int64_t>(w.O + w.O / 4, 4096);
+  w.W = db->opt.window_step > 0 ? db->opt.window_step : wlen - w.O;
+  const int64_t share = db->active_sym / std::max<int64_t>(1, int64_t(db->cus) * 64) / 2;
+  w.Lmax = db->opt.window > 0 ? db->opt.window : std::max<int64_t>(3 * (w.W + w.O) / 2, share);
+  if (w.W + w.O >= (int64_t(1) << 30)) return w;         // window lengths are 32 bit
+  w.on = db->len_of(db->h_order[0]) > w.Lmax;            // h_order: longest first
+  return w;
+}
+
+// the set to launch over: `set` itself, or the view that replaces its long sequences by windows
+int prepare_view(swa_db* db, const BatchSet& set, int per_row, int64_t qlen, const BatchSet** out)
+{
+  *out = &set;
+  const WindowPlan wp = plan_windows(db, qlen);
+  if (!wp.on) { db->nwin = 0; db->view_of = nullptr; return SWA_OK; }
+  if (db->view_of == &set && db->view.built && db->view_O == wp.O && db->view_W == wp.W && db->view_Lmax == wp.Lmax) {
+    *out = &db->view;
+    return SWA_OK;
+  }
+  hipStream_t st = db->stream;
+  BatchSet& v = db->view;
+  v.built = false;
+  db->view_of = nullptr;
+  const int64_t n = int64_t(db->h_order.size());
+  int64_t nlong = 0;
+  while (nlong < n && db->h_offsets[size_t(db->h_order[size_t(nlong)]) + 1] - db->h_offsets[size_t(db->h_order[size_t(nlong)])] > wp.Lmax) ++nlong;
+  const int per_batch = 4 * per_row;
+  const int64_t nskip = (nlong + per_batch - 1) / per_batch;
+  // windows of the long sequences, then the sequences that shared their batches
+  db->h_wstart.clear();
+  db->h_wlen.clear();
+  std::vector<int32_t> parents, wfirst, entries;
+  for (int64_t i = 0; i < nlong; ++i) {
+    const int32_t p = db->h_order[size_t(i)];
+    const int64_t o = db->h_offsets[size_t(p)], plen = db->h_offsets[size_t(p) + 1] - o;
+    parents.push_back(p);
+    wfirst.push_back(int32_t(db->h_wstart.size()));
+    for (int64_t start = 0; start == 0 || start + wp.O < plen; start += wp.W) {
+      db->h_wstart.push_back(o + start);
+      db->h_wlen.push_back(int32_t(std::min<int64_t>(wp.W + wp.O, plen - start)));
+    }
+    if (db->h_wstart.size() > size_t(0x3fffffff)) return fail(SWA_EINVAL, "too many windows; raise window_step");
+  }
+  wfirst.push_back(int32_t(db->h_wstart.size()));
+  db->nwin = int64_t(db->h_wstart.size());
+  if (db->nseq + db->nwin > 0x7ffffff0) return fail(SWA_EINVAL, "too many windows for one shard");
+  for (int64_t v2 = 0; v2 < db->nwin; ++v2) entries.push_back(int32_t(db->nseq + v2));
+  for (int64_t i = nlong; i < std::min<int64_t>(n, nskip * per_batch); ++i) entries.push_back(db->h_order[size_t(i)]);
+  std::vector<int32_t> ordered;
+  order_by_length([&](int32_t id) { return db->len_of(id); }, entries.data(), int64_t(entries.size()), ordered);
+  // everything indexed by id grows by the windows (contents between searches do not matter)
+  const size_t total_ids = size_t(db->nseq + db->nwin);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(db->scores.reserve(total_ids));
+  HIP_TRY(db->ovf_list.reserve(total_ids));
+  if (db->scores2.cap) HIP_TRY(db->scores2.reserve(total_ids));
+  if (db->ovf_list2.cap) HIP_TRY(db->ovf_list2.reserve(total_ids));
+  if (db->scores64.cap) HIP_TRY(db->scores64.reserve(total_ids));
+  if (db->scores64b.cap) HIP_TRY(db->scores64b.reserve(total_ids));
+  HIP_TRY(db->wstart.reserve(size_t(db->nwin)));
+  HIP_TRY(db->wlen.reserve(size_t(db->nwin)));
+  HIP_TRY(db->wparents.reserve(parents.size()));
+  HIP_TRY(db->wfirst.reserve(wfirst.size()));
+  HIP_TRY(hipMemcpyAsync(db->wstart.p, db->h_wstart.data(), db->h_wstart.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(db->wlen.p, db->h_wlen.data(), db->h_wlen.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(db->wparents.p, parents.data(), parents.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(db->wfirst.p, wfirst.data(), wfirst.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  db->nparents = int(parents.size());
+  // the long part: batches with chunk offsets counted from 0
+  const int64_t ne = int64_t(ordered.size());
+  const int64_t nl = (ne + per_batch - 1) / per_batch;
+  const int64_t nm = int64_t(set.nbatches) - nskip;
+  std::vector<int32_t> slots(size_t(nl) * SWA_SLOTS, -1);
+  std::vector<swa_batch> batches(static_cast<size_t>(nl));
+  uint64_t lchunks = 0;
+  v.h_steps.clear();
+  for (int64_t b = 0; b < nl; ++b) {
+    int64_t longest = 0;
+    for (int j = 0; j < per_batch; ++j) {
+      const int64_t i = b * per_batch + j;
+      if (i >= ne) break;
+      const int32_t id = ordered[size_t(i)];
+      slots[size_t(b) * SWA_SLOTS + (j / per_row) * 2 + j % per_row] = id;
+      longest = std::max(longest, db->len_of(id));
+    }
+    const int64_t steps = std::max<int64_t>(16, (longest + 1) & ~int64_t(1));
+    if (lchunks > 0xffffffffull || steps > 0x7ffffff0) return fail(SWA_EINVAL, "window stream exceeds 2^32 chunks");
+    batches[size_t(b)].offset = uint32_t(lchunks);
+    batches[size_t(b)].steps = int32_t(steps);
+    v.h_steps.push_back(int32_t(steps));
+    lchunks += uint64_t((steps + 15) / 16);
+  }
+  const size_t unit = set.nibbles ? 32 : 128;            // bytes per 16-column chunk
+  HIP_TRY(v.stream.reserve(size_t(lchunks) * unit / 2 + 64));
+  const uintptr_t pa = reinterpret_cast<uintptr_t>(set.stream.p), pb = reinterpret_cast<uintptr_t>(v.stream.p);
+  const uintptr_t base = std::min(pa, pb) & ~uintptr_t(127);
+  const uint64_t da = (pa - base) / unit, dl = (pb - base) / unit;
+  if ((pa - base) % unit || (pb - base) % unit || da + uint64_t(set.chunks) > 0xffffffffull || dl + lchunks > 0xffffffffull)
+    return fail(SWA_ENOMEM, "window stream cannot be addressed from the set's base");
+  for (swa_batch& b : batches) b.offset += uint32_t(dl);
+  HIP_TRY(v.slots.reserve(size_t(nl + nm) * SWA_SLOTS));
+  HIP_TRY(v.batches.reserve(size_t(nl + nm)));
+  HIP_TRY(hipMemcpyAsync(v.slots.p, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(v.batches.p, batches.data(), batches.size() * sizeof(swa_batch), hipMemcpyHostToDevice, st));
+  if (nm > 0) {
+    HIP_TRY(hipMemcpyAsync(v.slots.p + size_t(nl) * SWA_SLOTS, set.slots.p + size_t(nskip) * SWA_SLOTS,
+                           size_t(nm) * SWA_SLOTS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(swa_launch_rebase(set.batches.p + nskip, v.batches.p + nl, int(nm), uint32_t(da), st));
+  }
+  v.stream_base = reinterpret_cast<const uint16_t*>(base);
+  v.nibbles = set.nibbles;
+  {
+    const swa_seqs sq = db->seqs();
+    HIP_TRY(swa_launch_format(&sq, v.slots.p, v.batches.p, int(nl), reinterpret_cast<void*>(base), set.nibbles ? 1 : 0, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));                     // host vectors go out of scope
+  int64_t skipped_chunks = 0;
+  for (int64_t b = 0; b < nskip; ++b) skipped_chunks += (set.h_steps[size_t(b)] + 15) / 16;
+  v.h_steps.insert(v.h_steps.end(), set.h_steps.begin() + nskip, set.h_steps.end());
+  v.nbatches = int(nl + nm);
+  v.nlong = int(nl);
+  v.off_long = int64_t(dl);
+  v.off_main = int64_t(da) + skipped_chunks;
+  v.chunks = int64_t(lchunks) + set.chunks - skipped_chunks;
+  v.built = true;
+  db->view_of = &set;
+  db->view_O = wp.O; db->view_W = wp.W; db->view_Lmax = wp.Lmax;
+  *out = &v;
+  return SWA_OK;
+}
+
+// windows -> parents, on whatever score arrays the search filled (after every re-queue, before anything reads them)
+int fold_windows(swa_db* db, bool two, hipStream_t st)
+{
+  if (!db->nwin || !db->nparents) return SWA_OK;
+  HIP_TRY(swa_launch_fold(db->scores.p, db->scores64.p, db->wparents.p, db->wfirst.p, db->nparents, int(db->nseq), st));
+  if (two) HIP_TRY(swa_launch_fold(db->scores2.p, db->scores64b.p, db->wparents.p, db->wfirst.p, db->nparents, int(db->nseq), st));
+  return SWA_OK;
+}
+
 // The 4-bit stream pads with code 0, which must not score: true of every matrix swa_matrix_nucleotide makes
 // (matrices.cc:531-538 leaves row 0 at -1); a caller's own matrix with a positive entry there takes the 16-bit stream
 bool nibble_stream_ok(const swa_db* db)
@@ -529,7 +708,7 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   p.qlen = int32_t(qlen);
   p.rows_per_lane = K;
   p.npass = int32_t((qlen + 16 * K - 1) / (16 * K));
-  p.stream = r.set->stream.p;
+  p.stream = r.set->sp();
   p.batches = r.set->batches.p;
   p.slots = r.set->slots.p;
   p.nbatches = r.set->nbatches;
@@ -624,9 +803,17 @@ int plan_pass_runs(swa_db* db, const BatchSet& bs, PassRuns& runs)
   const size_t per_chunk = 64 * 8;
   const int nb = bs.nbatches;
   size_t largest = 0, bytes = 0;
-  int64_t chunk = 0;
+  // chunk offsets count from the set's base pointer; a view has two regions (windows | the set's own batches)
+  int64_t chunk = bs.stream_base ? (bs.nlong ? bs.off_long : bs.off_main) : 0;
+  runs.first_chunk[0] = chunk;
   for (int b = 0; b < nb; ++b) {
     const size_t need = size_t((bs.h_steps[size_t(b)] + 15) / 16) * per_chunk;
+    if (bs.stream_base && b == bs.nlong && b > 0) {        // a run never straddles the two regions
+      runs.cut.push_back(b);
+      runs.first_chunk.push_back(bs.off_main);
+      chunk = bs.off_main;
+      bytes = 0;
+    }
     if (bytes && bytes + need > budget) {
       runs.cut.push_back(b);
       runs.first_chunk.push_back(chunk);
@@ -664,15 +851,14 @@ int split_pass_rows(int64_t qlen)
 }
 
 // bound: the passes are bound builds (top-K searches, see run_search)
-int launch_split_passes(swa_db* db, int64_t qlen, hipStream_t st, bool bound, int64_t bound_min)
+int launch_split_passes(swa_db* db, const BatchSet& bs, int64_t qlen, hipStream_t st, bool bound, int64_t bound_min)
 {
   int npass = 0, K = 0;
   split_pass_shape(qlen, &npass, &K);
   const int Nb = bound ? swa_bound_period() : 0;
-  const BatchSet& bs = db->main;
   swa_narrow_params p{};
   p.query = reinterpret_cast<const swa_query*>(db->qblock.p);
-  p.stream = bs.stream.p;
+  p.stream = bs.sp();
   p.counter = db->ctl.p + 0;
   p.scores = db->scores.p;
   p.ovf_count = db->ctl.p + 1;
@@ -725,11 +911,10 @@ int dual_pass_rows(int64_t qlen, int nres)
   return K;
 }
 
-int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
+int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, hipStream_t st)
 {
   int npass = 0, K = 0;
   dual_pass_shape(qlen, nres, &npass, &K);
-  const BatchSet& bs = nibble_stream_ok(db) ? db->single4 : db->single;
   swa_mp_params p{};
   p.nibbles = bs.nibbles ? 1 : 0;
   p.qseq = db->qseq_p;
@@ -738,7 +923,7 @@ int launch_dual_passes(swa_db* db, int64_t qlen, int nres, hipStream_t st)
   p.qlen = int32_t(qlen);
   p.rows_per_lane = K;
   p.npass = npass;
-  p.stream = bs.stream.p;
+  p.stream = bs.sp();
   p.counter = db->ctl.p + 0;
   p.scores = db->scores.p;
   p.scores2 = db->scores2.p;
@@ -876,7 +1061,7 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
     boff.resize(requeue.size());
     for (size_t i = 0; i < requeue.size(); ++i) {
       boff[i] = columns;
-      columns += db->h_offsets[size_t(requeue[i]) + 1] - db->h_offsets[size_t(requeue[i])];
+      columns += db->len_of(requeue[i]);
     }
     by_wave = columns <= (int64_t(1) << 28);           // 2 x 4 bytes of hand-over per column: at most 2 GB
   }
@@ -905,11 +1090,11 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
       set = &db->single;
     } else {
       std::vector<int32_t> ordered;
-      order_by_length(db->h_offsets, requeue.data(), int64_t(requeue.size()), ordered);
+      order_by_length([&](int32_t id) { return db->len_of(id); }, requeue.data(), int64_t(requeue.size()), ordered);
       const int rc = build_batches(db, ordered.data(), int64_t(ordered.size()), 1, db->scratch);
       if (rc != SWA_OK) return rc;
     }
-    if (bits == 64) HIP_TRY(s64.reserve(size_t(db->nseq)));
+    if (bits == 64) HIP_TRY(s64.reserve(size_t(db->nseq + db->nwin)));
     HIP_TRY(hipMemsetAsync(db->ctl.p + 1, 0, sizeof(int32_t), st));
     MpRun r;
     r.mode = bits == 32 ? 2 : 3;
@@ -965,6 +1150,7 @@ struct Pending {
   bool dev1 = false, dev2 = false;   // the re-queue list of query 1 / 2 was worked off by the device-driven kernel
   bool two = false;
   bool empty = false;
+  bool windows = false;              // the first pass ran over a view: window scores are folded into their parents
 };
 
 int finish_empty(swa_db* db, Pending& pd, bool two, hipStream_t st)
@@ -1016,7 +1202,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
   rc = ensure_main(db);                                  // nucleotide shards build their pair stream on first use
   if (rc != SWA_OK) return rc;
+  const BatchSet* bsp = &db->main;                       // ... or the view that cuts long sequences into windows
+  rc = prepare_view(db, db->main, 2, qlen, &bsp);
+  if (rc != SWA_OK) return rc;
+  const BatchSet& bs = *bsp;
   const swa_seqs sq = db->seqs();
+  const int64_t nids = db->nseq + (bsp != &db->main ? db->nwin : 0);
 
   std::vector<int32_t> requeue;
   bool used_bound = false, follow = false;
@@ -1044,10 +1235,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     const int K = Kg;
     swa_narrow_params p{};
     p.query = dquery;
-    p.stream = db->main.stream.p;
-    p.batches = db->main.batches.p;
-    p.slots = db->main.slots.p;
-    p.nbatches = db->main.nbatches;
+    p.stream = bs.sp();
+    p.batches = bs.batches.p;
+    p.slots = bs.slots.p;
+    p.nbatches = bs.nbatches;
     p.counter = db->ctl.p + 0;
     p.scores = db->scores.p;
     p.ovf_count = db->ctl.p + 1;
@@ -1078,7 +1269,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // hardware queues it can never wait for a kernel that has not been submitted.
     follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0;
     if (follow) {
-      HIP_TRY(hipMemsetAsync(db->ovf_list.p, 0xFF, size_t(std::min<int64_t>(db->nseq, REQUEUE_CAP)) * sizeof(int32_t), st));
+      HIP_TRY(hipMemsetAsync(db->ovf_list.p, 0xFF, size_t(std::min<int64_t>(nids, REQUEUE_CAP)) * sizeof(int32_t), st));
       HIP_TRY(hipEventRecord(db->ev2[0], st));
       p.finished = db->ctl.p + CTL_FINISHED;
       p.done = db->ctl.p + CTL_DONE;
@@ -1097,7 +1288,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       // few waves: they only have to keep up with the trickle of entries while the first pass runs (measured: 128 blocks
       // cost the first pass nothing, 1 024 cost it 37 %); what is left at its end goes to the finishing kernel below
       const int fblocks = db->opt.requeue_follow > 1 ? int(db->opt.requeue_follow) : std::max(1, db->cus / 2);
-      HIP_TRY(swa_launch_requeue_follow(&sq, db->ovf_list.p, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)), db->ctl.p + 4,
+      HIP_TRY(swa_launch_requeue_follow(&sq, db->ovf_list.p, int(std::min<int64_t>(nids, REQUEUE_CAP)), db->ctl.p + 4,
                                         db->ctl.p + CTL_DONE, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge),
                                         db->scores.p, fblocks, db->stream2));
       HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
@@ -1106,10 +1297,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   } else if (f16 && !force_mp && qlen <= 1024 && K > 0 && db->hi < 1024 && (db->opt.narrow_variant == 1 || f16_limit(db, K) < 1024)) {
     swa_narrow_params p{};                             // plain form (8.5 ops): K*R would eat the f16 range
     p.query = dquery;
-    p.stream = db->main.stream.p;
-    p.batches = db->main.batches.p;
-    p.slots = db->main.slots.p;
-    p.nbatches = db->main.nbatches;
+    p.stream = bs.sp();
+    p.batches = bs.batches.p;
+    p.slots = bs.slots.p;
+    p.nbatches = bs.nbatches;
     p.counter = db->ctl.p + 0;
     p.scores = db->scores.p;
     p.limit = int32_t(2048 - db->hi);
@@ -1124,7 +1315,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     int np = 0, Kp = 0;                                // long query: passes of the tuned kernel, or of its bound build
     split_pass_shape(qlen, &np, &Kp);
     used_bound = want_bound && f16_limit(db, Kp + Nb) >= 1024;
-    rc = launch_split_passes(db, qlen, st, used_bound, bound_min);
+    rc = launch_split_passes(db, bs, qlen, st, used_bound, bound_min);
     if (rc != SWA_OK) return rc;
     c.narrow_rows = Kp;
     c.narrow_shifted = used_bound ? 9 : 5;
@@ -1132,7 +1323,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   } else if (f16 && f16_limit(db, mp_rows_for(0, qlen)) >= 1024) {
     MpRun r;                                           // multi-pass pair kernel (short passes: large gap-extension penalties)
     r.mode = 0;
-    r.set = &db->main;
+    r.set = &bs;
     r.q1 = db->qseq_p;
     r.scores = db->scores.p;
     r.ovf_count = db->ctl.p + 1;
@@ -1147,7 +1338,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   pd.used_bound = used_bound;
   if (follow) {
     // the finishing kernel takes what the follower's few waves did not get to (same work-queue head), then both are awaited
-    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, int(std::min<int64_t>(db->nseq, REQUEUE_CAP)),
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, int(std::min<int64_t>(nids, REQUEUE_CAP)),
                                     db->ctl.p + 4, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p,
                                     db->cus * 8, st));
     HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
@@ -1171,6 +1362,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     rc = run_wide(db, requeue, db->qseq_p, qlen, db->scores.p, db->scores64, &c.wide, &c.full, st);
     if (rc != SWA_OK) return rc;
   }
+  pd.windows = c.narrow && bsp != &db->main;
+  if (pd.windows) { rc = fold_windows(db, false, st); if (rc != SWA_OK) return rc; }
   HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(hipEventRecord(db->ev[3], st));
   return SWA_OK;
@@ -1193,14 +1386,20 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (rc != SWA_OK) return rc;
   if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, true, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
-  HIP_TRY(db->scores2.reserve(size_t(db->nseq)));
-  HIP_TRY(db->ovf_list2.reserve(size_t(db->nseq)));
   rc = upload_queries(db, q1, q2, qlen, st);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
   std::vector<int32_t> rq1, rq2;
-  const swa_seqs sq = db->seqs();
-  const bool nib = nibble_stream_ok(db);                 // nucleotide shard: 16-lane chains stream 4 bits per base
+  const bool nib = nibble_stream_ok(db);
+  const BatchSet* bsp = nullptr;
+  bool windows = false;
+  // everything indexed by sequence id also holds the windows of a view (ids nseq + v)
+  auto reserve2 = [&](bool view) -> int {
+    const size_t ids = size_t(db->nseq + (view ? db->nwin : 0));
+    HIP_TRY(db->scores2.reserve(ids));
+    HIP_TRY(db->ovf_list2.reserve(ids));
+    return SWA_OK;
+  };                 // nucleotide shard: 16-lane chains stream 4 bits per base
   bool listed = false;                                   // the first pass left re-queue lists on the device
   bool used_bound = false;
   HIP_TRY(hipEventRecord(db->ev[1], st));
@@ -1220,7 +1419,12 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
     if (rc != SWA_OK) return rc;
-    const BatchSet& set = Gd < 16 ? db->main : nib ? db->single4 : db->single;
+    const BatchSet& whole = Gd < 16 ? db->main : nib ? db->single4 : db->single;
+    rc = prepare_view(db, whole, Gd < 16 ? 2 : 1, qlen, &bsp);
+    if (rc == SWA_OK) rc = reserve2(bsp != &whole);
+    if (rc != SWA_OK) return rc;
+    const BatchSet& set = *bsp;
+    windows = bsp != &whole;
     swa_mp_params p{};
     p.nibbles = set.nibbles ? 1 : 0;
     p.qseq = db->qseq_p;
@@ -1229,7 +1433,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     p.qlen = int32_t(qlen);
     p.rows_per_lane = Kd;
     p.npass = 1;
-    p.stream = set.stream.p;
+    p.stream = set.sp();
     p.batches = set.batches.p;
     p.slots = set.slots.p;
     p.nbatches = set.nbatches;
@@ -1262,7 +1466,12 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     listed = true;
   } else if (f16_applicable(db) && !dual_mp && Gd == 16 && f16_limit(db, dual_pass_rows(qlen, nres)) >= 1024) {
     rc = nib ? ensure_single4(db) : ensure_single(db);
-    if (rc == SWA_OK) rc = launch_dual_passes(db, qlen, nres, st);   // long queries: one launch per pass of the same kernel
+    if (rc != SWA_OK) return rc;
+    const BatchSet& whole = nib ? db->single4 : db->single;
+    rc = prepare_view(db, whole, 1, qlen, &bsp);
+    if (rc == SWA_OK) rc = reserve2(bsp != &whole);
+    windows = bsp != &whole;
+    if (rc == SWA_OK) rc = launch_dual_passes(db, *bsp, qlen, nres, st);   // long queries: one launch per pass of the same kernel
     if (rc != SWA_OK) return rc;
     c.narrow_rows = dual_pass_rows(qlen, nres);
     c.narrow_shifted = 6;
@@ -1270,10 +1479,13 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     listed = true;
   } else if (f16_applicable(db) && f16_limit(db, mp_rows_for(1, qlen)) >= 1024) {
     rc = ensure_single(db);
+    if (rc == SWA_OK) rc = prepare_view(db, db->single, 1, qlen, &bsp);
+    if (rc == SWA_OK) rc = reserve2(bsp != &db->single);
     if (rc != SWA_OK) return rc;
+    windows = bsp != &db->single;
     MpRun r;
     r.mode = 1;
-    r.set = &db->single;
+    r.set = bsp;
     r.q1 = db->qseq_p;
     r.q2 = db->qseq2_p;
     r.scores = db->scores.p;
@@ -1291,6 +1503,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   }
   HIP_TRY(hipEventRecord(db->ev[2], st));
   pd.used_bound = used_bound;
+  if (!listed) { rc = reserve2(false); if (rc != SWA_OK) return rc; }
+  const swa_seqs sq = db->seqs();
   if (listed && device_requeue_ok(db, qlen)) {
     HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
                                     db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
@@ -1316,6 +1530,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     if (rc != SWA_OK) return rc;
     c.full += full2;
   }
+  pd.windows = listed && windows;
+  if (pd.windows) { rc = fold_windows(db, true, st); if (rc != SWA_OK) return rc; }
   HIP_TRY(swa_launch_mark_excluded(db->scores.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(swa_launch_mark_excluded(db->scores2.p, db->excluded.p, int(db->n_excluded), st));
   HIP_TRY(hipEventRecord(db->ev[3], st));
@@ -1355,6 +1571,7 @@ int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2,
       *changed = true;
     }
     if (*changed) {
+      if (pd.windows) { const int rc = fold_windows(db, pd.two, st); if (rc != SWA_OK) return rc; }
       HIP_TRY(hipEventRecord(db->ev[3], st));
       HIP_TRY(hipStreamSynchronize(st));
     }
@@ -1613,11 +1830,13 @@ extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t 
       ex.push_back(int32_t(v));
     }
   }
-  order_by_length(db->h_offsets, in.data(), int64_t(in.size()), db->h_order);
+  order_by_length([&](int32_t id) { return db->len_of(id); }, in.data(), int64_t(in.size()), db->h_order);
   db->n_excluded = int64_t(ex.size());
   HIP_TRY(db->excluded.reserve(ex.size()));
   if (!ex.empty()) HIP_TRY(hipMemcpy(db->excluded.p, ex.data(), ex.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  db->main.built = db->single.built = db->single4.built = false;
+  db->main.built = db->single.built = db->single4.built = db->view.built = false;
+  db->view_of = nullptr;
+  db->nwin = 0;
   return db->packed ? SWA_OK : ensure_main(db);
 }
 

@@ -1199,3 +1199,121 @@ def test_bench_step_over_rccl_with_one_rank():
     assert local["search"] == dist["search"] and local["hits_sha1"] == dist["hits_sha1"]
     assert dist["verified_vs_oracle"] >= 2000 and dist["scaling"] == "strong" and dist["n_gpus"] == 1
     assert "roofline" in dist and "overhead_ms" in dist
+
+
+def _long_subject_db(q, rng, rtab, nbase, long_len, protein=True, seed=31):
+    """random sequences + one very long one that carries copies of the query: one whole, one with a long insertion in
+    the middle (an alignment that spans a long gap), pieces at both ends"""
+    res, off = swipe_amd.synth_db(seed, nbase, protein=protein)
+    seqs = [res[off[i]:off[i + 1]] for i in range(nbase)]
+    body = rtab[rng.integers(0, len(rtab), long_len)].astype(np.uint8)
+    half = len(q) // 2
+    ins = rtab[rng.integers(0, len(rtab), 150)].astype(np.uint8)
+    pos = [long_len // 7, long_len // 2, long_len - 3 * len(q)]
+    body[pos[0]:pos[0] + len(q)] = q
+    gapped = np.concatenate([q[:half], ins, q[half:]])
+    body[pos[1]:pos[1] + len(gapped)] = gapped
+    body[:half] = q[half:2 * half]
+    body[long_len - half:] = q[:half]
+    seqs.append(body)
+    seqs.append(np.zeros(0, np.uint8))
+    return seqs
+
+
+def test_long_subject_is_searched_as_overlapping_windows():
+    """a 35 000-residue protein among 2 000 ordinary ones: cut into windows that overlap by the longest span a
+    positive-scoring alignment can have, each window searched as a sequence of its own, maximum per parent - every score
+    equals the oracle's, for all-scores searches, top-K searches with the bound build, both queries of a pair, and the
+    long sequence no longer sets the time of the pass"""
+    rng = np.random.default_rng(77)
+    rtab = synth.residue_table_protein()
+    q = cases.Q375
+    seqs = _long_subject_db(q, rng, rtab, 2000, 35_000)
+    r2, o2 = oracle.pack(seqs)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    db.set_option("window", 0)
+    s0, c0 = db.search(q)
+    db.set_option("window", None)
+    s1, c1 = db.search(q)
+    assert np.array_equal(s0, want) and np.array_equal(s1, want)
+    assert int(want[2000]) >= 1957                                  # the whole copy of the query sits in it
+    assert c1["kernel_ms"] < 0.5 * c0["kernel_ms"], (c0["kernel_ms"], c1["kernel_ms"])   # 35 000 columns on one chain vs windows
+    for bound in (0, 1):
+        db.set_option("bound", bound)
+        for minscore in (40, 80, 300):
+            hits, tot, obv, c = db.search_topk(q, keep=50, minscore=minscore)
+            assert (hits, tot, obv) == _expected_topk(want, 50, minscore), (bound, minscore)
+    db.set_option("bound", None)
+    q2 = q[::-1].copy()
+    want2 = oracle.search_all63(r2, o2, q2, Mo, 12, 1, threads=THREADS)
+    t1, t2, _ = db.search2(q, q2)
+    assert np.array_equal(t1, want) and np.array_equal(t2, want2)
+    # a longer query: passes of the kernel over the view (hand-over buffer addressed per region)
+    ql = np.concatenate([q, synth._random_residues(3, 1, 700, rtab)])
+    wantl = oracle.search_all63(r2, o2, ql, Mo, 12, 1, threads=THREADS)
+    sl, cl = db.search(ql)
+    assert cl["narrow_shifted"] == 5 and np.array_equal(sl, wantl)
+    db.close()
+
+
+@pytest.mark.parametrize("step", [64, 333, 1000])
+def test_windows_are_exact_for_alignments_that_span_long_gaps(step):
+    """the overlap is the longest span a positive-scoring alignment can have, qlen (1 + hi / R): planted alignments with
+    insertions of up to 400 columns, windows forced on every sequence longer than 300 with starts every `step` columns
+    so that the alignments straddle window starts everywhere - scores equal to the oracle's under three gap systems"""
+    rng = np.random.default_rng(step)
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(11, 1, 120, rtab)
+    res, off = swipe_amd.synth_db(17, 400)
+    seqs = [res[off[i]:off[i + 1]] for i in range(400)]
+    for k in range(60):
+        g = int(rng.integers(1, 400))
+        ins = rtab[rng.integers(0, len(rtab), g)].astype(np.uint8)
+        a = int(rng.integers(30, 90))
+        left = rtab[rng.integers(0, len(rtab), int(rng.integers(0, 2500)))].astype(np.uint8)
+        right = rtab[rng.integers(0, len(rtab), int(rng.integers(0, 900)))].astype(np.uint8)
+        seqs.append(np.concatenate([left, q[:a], ins, q[a:], right]))
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_option("window", 300)
+    db.set_option("window_step", step)
+    for go, ge in ((11, 1), (5, 2), (0, 1)):
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
+        want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62"), go + ge, ge, threads=THREADS)
+        got, c = db.search(q)
+        assert np.array_equal(got, want), (go, ge)
+        hits, tot, obv, c = db.search_topk(q, keep=30, minscore=60)
+        assert (hits, tot, obv) == _expected_topk(want, 30, 60)
+    db.close()
+
+
+def test_chromosome_sized_nucleotide_subject_both_strands():
+    """a 3 Mbp nucleotide sequence among short reads, 1 kb query on both strands: windows over the 4-bit stream of the
+    two-query kernel; plus-strand and reverse-complement hits planted far apart; time no longer proportional to the
+    longest sequence"""
+    rng = np.random.default_rng(5)
+    tab = synth.residue_table_nucleotide()
+    q = synth._random_residues(99, 1, 1000, tab)
+    qm = blastdb.revcomp_nt16(q)
+    res, off = swipe_amd.synth_db(3, 3000, protein=False)
+    seqs = [res[off[i]:off[i + 1]] for i in range(3000)]
+    big = tab[rng.integers(0, len(tab), 3_000_000)].astype(np.uint8)
+    big[500_000:501_000] = q
+    big[2_200_000:2_201_000] = qm
+    big[2_999_400:] = q[:600]
+    seqs.append(big)
+    r2, o2 = oracle.pack(seqs)
+    Mo = oracle.matrix_nucleotide(1, -3)
+    w1 = oracle.search_all63(r2, o2, q, Mo, 7, 2, threads=THREADS)
+    w2 = oracle.search_all63(r2, o2, qm, Mo, 7, 2, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2, symtype=0)
+    db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+    s1, s2, c = db.search2(q, qm)
+    assert np.array_equal(s1, w1) and np.array_equal(s2, w2) and int(w1[3000]) == 1000 and int(w2[3000]) == 1000
+    assert c["kernel_ms"] < 1000, c                       # one chain over 3 M columns would take about 4 s
+    hits, tot, obv, _ = db.search2_topk(q, qm, keep=10, minscore=100)
+    assert hits == [(3000, 1000, 0), (3000, 1000, 1)] and tot == 2      # one score per (sequence, strand): the maximum over its windows
+    db.close()
