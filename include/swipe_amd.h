@@ -228,6 +228,17 @@ SWA_API int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* q
                      int64_t keep, int64_t minscore, int64_t maxscore, swa_hit_t* hits,
                      int32_t* which, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                      swa_counters_t* counters);
+/* Two DIFFERENT queries in one pass over the shard - the unit of work of the reference is a query FILE
+   (swipe.cc:2561-2575), and two queries in the two halves of every packed lane cost 5 (bound build) / 6.5 instructions
+   per cell pair where one query and two sequences cost 6 / 7.5.  qlen1 and qlen2 may differ: the shorter query is
+   padded with rows that score -1 against everything, so pairing pays when the lengths are within about a quarter of
+   each other.  Each query has its own list length, score window, hit list and counts; every result equals what two
+   swa_search_topk calls return.  counters describe the shared first pass (cells = symcount x (qlen1 + qlen2)). */
+SWA_API int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t qlen1, const uint8_t* query2, int64_t qlen2,
+                         int64_t keep1, int64_t minscore1, int64_t maxscore1, int64_t keep2, int64_t minscore2,
+                         int64_t maxscore2, swa_hit_t* hits1, int64_t* nhits1, int64_t* totalhits1, int64_t* obvious1,
+                         swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2, int64_t* obvious2,
+                         swa_counters_t* counters);
 /* The general form behind every -p mode: nq query frames (1 for -p 1/3, 3 or 6 for -p 2/4; also the two
    strands of -p 0) against every frame the shard holds, merged into ONE hit list exactly as the
    reference's search_chunk + hits_enter leave it (swipe.cc:1403-1592, hits.cc:163-222): score descending,

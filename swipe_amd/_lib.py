@@ -53,7 +53,7 @@ EXPORTS = [
     "swa_gencode_name", "swa_translate_table", "swa_translate",
     "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_time", "swa_headers_get", "swa_headers_inclusion",
     "swa_db_set_inclusion", "swa_set_option",
-    "swa_db_close", "swa_blastdb_read", "swa_blastdb_write", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
+    "swa_db_close", "swa_blastdb_read", "swa_blastdb_write", "swa_free", "swa_blastdb_defline", "swa_blastdb_deflines", "swa_set_scoring", "swa_search", "swa_search_topk", "swa_search2", "swa_search2_topk", "swa_search_pair_topk", "swa_search_endpoints", "swa_search_endpoints_strand",
     "swa_db_sequence", "swa_align_hits", "swa_traceback", "swa_hits_merge", "swa_fhits_merge",
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
@@ -92,6 +92,8 @@ def load():
     L.swa_search2.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(Counters)]
     L.swa_search2_topk.argtypes = [vp, vp, vp, i64, i64, i64, i64, C.POINTER(Hit), C.POINTER(C.c_int32), i64p, i64p, i64p,
                                    C.POINTER(Counters)]
+    L.swa_search_pair_topk.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, C.POINTER(Hit), i64p, i64p, i64p,
+                                       C.POINTER(Hit), i64p, i64p, i64p, C.POINTER(Counters)]
     L.swa_search_endpoints.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp]
     L.swa_search_endpoints_strand.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, vp]
     L.swa_db_sequence.argtypes = [vp, i64, C.c_int, C.c_int, vp, i64, i64p, i64p]

@@ -251,6 +251,23 @@ class Database:
         return ([(hits[i].seqno, hits[i].score, which[i]) for i in range(n.value)], tot.value, obv.value,
                 {f: getattr(c, f) for f, _ in c._fields_})
 
+    def search_pair_topk(self, query1, query2, keep=250, minscore=(1, 1), maxscore=((1 << 62), (1 << 62))):
+        """Two different queries (lengths may differ) in one pass: ((hits1, total1, obvious1), (hits2, total2, obvious2),
+        counters) - each part equal to search_topk of that query.  keep / minscore / maxscore: one value or a pair."""
+        q1 = np.ascontiguousarray(query1, dtype=np.uint8)
+        q2 = np.ascontiguousarray(query2, dtype=np.uint8)
+        two = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        k, lo, hi = two(keep), two(minscore), two(maxscore)
+        c = _lib.Counters()
+        h1, h2 = (_lib.Hit * max(1, k[0]))(), (_lib.Hit * max(1, k[1]))()
+        n1, t1, o1, n2, t2, o2 = (C.c_int64() for _ in range(6))
+        _check(_lib.load().swa_search_pair_topk(self._h, q1.ctypes.data, len(q1), q2.ctypes.data, len(q2), k[0], lo[0], hi[0],
+                                                k[1], lo[1], hi[1], h1, C.byref(n1), C.byref(t1), C.byref(o1), h2, C.byref(n2),
+                                                C.byref(t2), C.byref(o2), C.byref(c)))
+        return (([(h1[i].seqno, h1[i].score) for i in range(n1.value)], t1.value, o1.value),
+                ([(h2[i].seqno, h2[i].score) for i in range(n2.value)], t2.value, o2.value),
+                {f: getattr(c, f) for f, _ in c._fields_})
+
     def search_frames_topk(self, queries, qtags=None, *, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
         """Up to six query frames against every frame the shard holds, one merged hit list in the reference's
         order: ([(seqno, score, qstrand, qframe, dstrand, dframe)], totalhits, obvious, counters)."""

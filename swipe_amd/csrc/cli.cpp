@@ -462,8 +462,25 @@ int main(int argc, char** argv)
     std::fprintf(out, "<?xml version=\"1.0\"?>\n");
 
   std::string pending;
-  Query q;
-  while (read_query(qf, pending, !query_nt, q)) {
+  Query q, qahead;
+  // Protein queries of a file are searched two at a time where their lengths are within a quarter of each other
+  // (swa_search_pair_topk: the two halves of every packed lane, 5 instead of 6 instructions per cell pair): the second
+  // query of a pair is read ahead, its hit list kept until its turn - the output is what one search per query prints
+  bool have_ahead = false, ahead_searched = false;
+  std::vector<swa_fhit_t> ahead_hits;
+  int64_t ahead_nhits = 0, ahead_total = 0, ahead_obvious = 0;
+  swa_counters_t ahead_cnt{};
+  const bool pairing = symtype == 1;
+  for (;;) {
+    bool searched = false;
+    if (have_ahead) {
+      q = qahead;
+      have_ahead = false;
+      searched = ahead_searched;
+      ahead_searched = false;
+    } else if (!read_query(qf, pending, !query_nt, q)) {
+      break;
+    }
     const int64_t qlen = int64_t(q.seq.size());
     const Mode mode{symtype, long(qlen)};
     // the query frames search_chunk loops over (swipe.cc:277-337, 1403-1404), tag = 3 * qstrand + qframe
@@ -503,7 +520,40 @@ int main(int argc, char** argv)
     std::vector<swa_fhit_t> hits(size_t(keep > 0 ? keep : 1));
     int64_t nhits = 0, total = 0, obvious = 0;
     swa_counters_t cnt;
-    {
+    bool paired = false;
+    if (searched) {                                                   // searched together with the previous query
+      hits = ahead_hits;
+      hits.resize(size_t(keep > 0 ? keep : 1));
+      nhits = ahead_nhits; total = ahead_total; obvious = ahead_obvious; cnt = ahead_cnt;
+      paired = true;
+    } else if (pairing && qlen > 0 && keep > 0 && read_query(qf, pending, !query_nt, qahead)) {
+      have_ahead = true;
+      const int64_t qlen2 = int64_t(qahead.seq.size());
+      if (qlen2 > 0 && 4 * std::min(qlen, qlen2) >= 3 * std::max(qlen, qlen2)) {
+        swa_stats_t st2;
+        check(swa_stats_init(int(symtype), matrixname.c_str(), match, mismatch, gapopen, gapextend, qlen2, info.total_seqcount,
+                             info.total_symcount, effdbsize, minscore, maxscore, minexpect, expect, &st2));
+        std::vector<swa_hit_t> h1{size_t(keep)}, h2{size_t(keep)};
+        int64_t n1 = 0, n2 = 0;
+        check(swa_search_pair_topk(db, q.seq.data(), qlen, qahead.seq.data(), qlen2, keep, st.scorethreshold,
+                                   st.upperscorethreshold, keep, st2.scorethreshold, st2.upperscorethreshold, h1.data(), &n1,
+                                   &total, &obvious, h2.data(), &n2, &ahead_total, &ahead_obvious, &cnt));
+        for (int64_t i = 0; i < n1; ++i) hits[size_t(i)] = swa_fhit_t{h1[size_t(i)].seqno, h1[size_t(i)].score, 0, 0, 0, 0};
+        nhits = n1;
+        ahead_hits.assign(size_t(keep), swa_fhit_t{});
+        for (int64_t i = 0; i < n2; ++i) ahead_hits[size_t(i)] = swa_fhit_t{h2[size_t(i)].seqno, h2[size_t(i)].score, 0, 0, 0, 0};
+        ahead_nhits = n2;
+        // the pass served both queries: each is credited with its share of the time
+        cnt.total_ms *= double(qlen) / double(qlen + qlen2);
+        cnt.kernel_ms *= double(qlen) / double(qlen + qlen2);
+        ahead_cnt = cnt;
+        ahead_cnt.total_ms *= double(qlen2) / double(qlen);
+        ahead_cnt.kernel_ms *= double(qlen2) / double(qlen);
+        ahead_searched = true;
+        paired = true;
+      }
+    }
+    if (!paired) {
       std::vector<const uint8_t*> ptr;
       std::vector<int64_t> len;
       for (const auto& f : frames) { ptr.push_back(f.data()); len.push_back(int64_t(f.size())); }

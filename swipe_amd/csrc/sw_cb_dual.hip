@@ -27,8 +27,8 @@ swa_dual_bound_kernel(swa_mp_params p)
       const int k = e & 3, ll = (e >> 2) & (G - 1), c = (e >> 6) % C, d = (e >> 6) / C;
       const int local = c * 4 + k, row = ll * K + local;
       const bool live = local < K && row < p.qlen && d < NRES;
-      const float v1 = live ? (float)p.matrix[(d << 5) + p.qseq[row]] : -1.0f;
-      const float v2 = live ? (float)p.matrix[(d << 5) + p.qseq2[row]] : -1.0f;
+      const float v1 = live && row < (p.qlen_a ? p.qlen_a : p.qlen) ? (float)p.matrix[(d << 5) + p.qseq[row]] : -1.0f;
+      const float v2 = live && row < (p.qlen_b ? p.qlen_b : p.qlen) ? (float)p.matrix[(d << 5) + p.qseq2[row]] : -1.0f;
       t[e] = float_to_half_bits(v1 + add) | (float_to_half_bits(v2 + add) << 16);
     }
   }

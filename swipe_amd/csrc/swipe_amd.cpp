@@ -676,6 +676,7 @@ struct MpRun {
   int32_t* ovf_count2 = nullptr;
   int32_t* ovf_list2 = nullptr;
   long long* scores64 = nullptr;  // 64-bit results (mode 3); null = db->scores64
+  int64_t qlen_a = 0, qlen_b = 0; // mode 1 with two different queries: their own row counts (0 = qlen)
 };
 
 int mp_rows_for(int mode, int64_t qlen)
@@ -706,6 +707,8 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   p.qseq2 = r.q2;
   p.matrix = db->matrix.p;
   p.qlen = int32_t(qlen);
+  p.qlen_a = int32_t(r.qlen_a);
+  p.qlen_b = int32_t(r.qlen_b);
   p.rows_per_lane = K;
   p.npass = int32_t((qlen + 16 * K - 1) / (16 * K));
   p.stream = r.set->sp();
@@ -911,12 +914,14 @@ int dual_pass_rows(int64_t qlen, int nres)
   return K;
 }
 
-int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, hipStream_t st)
+int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, hipStream_t st, int64_t qlen_a = 0, int64_t qlen_b = 0)
 {
   int npass = 0, K = 0;
   dual_pass_shape(qlen, nres, &npass, &K);
   swa_mp_params p{};
   p.nibbles = bs.nibbles ? 1 : 0;
+  p.qlen_a = int32_t(qlen_a);
+  p.qlen_b = int32_t(qlen_b);
   p.qseq = db->qseq_p;
   p.qseq2 = db->qseq2_p;
   p.matrix = db->matrix.p;
@@ -995,7 +1000,19 @@ int sync_ctl(swa_db* db, int ncand, hipStream_t st)
 
 // query (+ its descriptor for the first-pass kernel) in ONE copy out of page-locked memory:
 // device layout of db->qblock = [swa_query | residues of query 1 | residues of query 2]
-int upload_queries(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, hipStream_t st)
+// The second query of a two-query search when it is a DIFFERENT query (swa_search_pair_topk) rather than another strand
+// or frame of the first: its own length (the shorter query is padded to `qlen` rows that score -1 against everything)
+// and its own score window.  Zero lengths = both queries have qlen rows and share the window.
+struct Pair {
+  int64_t qlen_a = 0, qlen_b = 0;
+  bool own_window = false;
+  int64_t minscore_b = 0, maxscore_b = 0, keep_b = 0;
+  int64_t total_b = 0, obvious_b = 0;          // out
+};
+constexpr int CTL_TALLY_B = 36;                // tallies of the second score array of a pair (third counter line)
+
+int upload_queries(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, hipStream_t st, int64_t qlen_a = 0,
+                   int64_t qlen_b = 0)
 {
   const size_t qpad = (size_t(qlen) + 15) & ~size_t(15);
   const size_t bytes = 32 + qpad * (q2 ? 2 : 1);
@@ -1008,8 +1025,10 @@ int upload_queries(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qle
   swa_query hq{db->qseq_p, db->matrix.p, int32_t(qlen)};
   std::memset(h, 0, 32);
   std::memcpy(h, &hq, sizeof hq);
-  std::memcpy(h + 32, q1, size_t(qlen));
-  if (q2) std::memcpy(h + 32 + qpad, q2, size_t(qlen));
+  const size_t na = size_t(qlen_a ? qlen_a : qlen), nb = size_t(qlen_b ? qlen_b : qlen);
+  std::memset(h + 32, SWA_PAD, qpad * (q2 ? 2 : 1));     // rows past a query's end: never scored (profile builders check the row)
+  std::memcpy(h + 32, q1, na);
+  if (q2) std::memcpy(h + 32 + qpad, q2, nb);
   HIP_TRY(hipMemcpyAsync(db->qblock.p, h, bytes, hipMemcpyHostToDevice, st));
   return SWA_OK;
 }
@@ -1371,22 +1390,24 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
 
 // Two queries of equal length against every sequence in one pass (nucleotide plus/minus strand).
 // Scores of query 1 end up in db->scores (64-bit values in scores64), of query 2 in db->scores2 (scores64b).
-int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t bound_min, Pending& pd)
+int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t bound_min, Pending& pd,
+                int64_t qlen_a = 0, int64_t qlen_b = 0)
 {
-  int rc = check_query(db, q1, qlen);
-  if (rc == SWA_OK) rc = check_query(db, q2, qlen);
+  const int64_t qa = qlen_a ? qlen_a : qlen, qb = qlen_b ? qlen_b : qlen;      // rows of query 1 / 2; qlen = the longer
+  int rc = check_query(db, q1, qa);
+  if (rc == SWA_OK) rc = check_query(db, q2, qb);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
   pd = Pending{};
   pd.two = true;
   swa_counters_t& c = pd.c;
-  c.cells = 2 * db->active_sym * qlen;
+  c.cells = db->active_sym * (qa + qb);
   rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 8192);
   if (rc != SWA_OK) return rc;
   if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, true, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
-  rc = upload_queries(db, q1, q2, qlen, st);
+  rc = upload_queries(db, q1, q2, qlen, st, qlen_a, qlen_b);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
   std::vector<int32_t> rq1, rq2;
@@ -1427,6 +1448,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     windows = bsp != &whole;
     swa_mp_params p{};
     p.nibbles = set.nibbles ? 1 : 0;
+    p.qlen_a = int32_t(qlen_a);
+    p.qlen_b = int32_t(qlen_b);
     p.qseq = db->qseq_p;
     p.qseq2 = db->qseq2_p;
     p.matrix = db->matrix.p;
@@ -1471,7 +1494,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     rc = prepare_view(db, whole, 1, qlen, &bsp);
     if (rc == SWA_OK) rc = reserve2(bsp != &whole);
     windows = bsp != &whole;
-    if (rc == SWA_OK) rc = launch_dual_passes(db, *bsp, qlen, nres, st);   // long queries: one launch per pass of the same kernel
+    if (rc == SWA_OK) rc = launch_dual_passes(db, *bsp, qlen, nres, st, qlen_a, qlen_b);   // long queries: one launch per pass of the same kernel
     if (rc != SWA_OK) return rc;
     c.narrow_rows = dual_pass_rows(qlen, nres);
     c.narrow_shifted = 6;
@@ -1485,6 +1508,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     windows = bsp != &db->single;
     MpRun r;
     r.mode = 1;
+    r.qlen_a = qlen_a;
+    r.qlen_b = qlen_b;
     r.set = bsp;
     r.q1 = db->qseq_p;
     r.q2 = db->qseq2_p;
@@ -1507,9 +1532,9 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   const swa_seqs sq = db->seqs();
   if (listed && device_requeue_ok(db, qlen)) {
     HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
-                                    db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
+                                    db->qseq_p, int(qa), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
     HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list2.p, db->ctl.p + 3, REQUEUE_CAP, db->ctl.p + 5,
-                                    db->qseq2_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores2.p, db->cus * 8, st));
+                                    db->qseq2_p, int(qb), db->matrix.p, int(db->goe), int(db->ge), db->scores2.p, db->cus * 8, st));
     pd.dev1 = pd.dev2 = true;
   } else {
     if (listed) {
@@ -1518,15 +1543,15 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
       if (rc != SWA_OK) return rc;
       if (used_bound && int64_t(rq1.size() + rq2.size()) * 50 > 2 * db->nseq && db->opt.bound != 1) {
         db->bound_off.emplace_back(qlen, bound_min);
-        return run_search2(db, q1, q2, qlen, 0, pd);
+        return run_search2(db, q1, q2, qlen, 0, pd, qlen_a, qlen_b);
       }
     } else {
       rq1.assign(db->h_order.begin(), db->h_order.end());
       rq2 = rq1;
     }
     int64_t full2 = 0;
-    rc = run_wide(db, rq1, db->qseq_p, qlen, db->scores.p, db->scores64, &c.wide, &c.full, st);
-    if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2_p, qlen, db->scores2.p, db->scores64b, &c.wide, &full2, st);
+    rc = run_wide(db, rq1, db->qseq_p, qa, db->scores.p, db->scores64, &c.wide, &c.full, st);
+    if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2_p, qb, db->scores2.p, db->scores64b, &c.wide, &full2, st);
     if (rc != SWA_OK) return rc;
     c.full += full2;
   }
@@ -1542,7 +1567,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
 // build sent back too much - it is now off for this query length and threshold); *changed: scores were rewritten
 // after the caller's filter ran, so the filter must run again.
 int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t bound_min,
-                  bool* again, bool* changed)
+                  bool* again, bool* changed, int64_t qlen_a = 0, int64_t qlen_b = 0)
 {
   *again = *changed = false;
   hipStream_t st = db->stream;
@@ -1563,7 +1588,8 @@ int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2,
       HIP_TRY(hipMemcpy(list.data(), which ? db->ovf_list2.p : db->ovf_list.p, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
       std::sort(list.begin(), list.end());
       int64_t full = 0;
-      const int rc = run_wide(db, list, which ? db->qseq2_p : db->qseq_p, qlen, which ? db->scores2.p : db->scores.p,
+      const int64_t ql = which ? (qlen_b ? qlen_b : qlen) : (qlen_a ? qlen_a : qlen);
+      const int rc = run_wide(db, list, which ? db->qseq2_p : db->qseq_p, ql, which ? db->scores2.p : db->scores.p,
                               which ? db->scores64b : db->scores64, &pd.c.wide, &full, st);
       if (rc != SWA_OK) return rc;
       pd.c.full += full;
@@ -1878,15 +1904,21 @@ struct Cand { int64_t seqno, score; int32_t which, dtag; };
 
 // hits_enter acceptance test (hits.cc:174-184) over one / two score arrays: ENQUEUES the counter reset and the filter
 // kernel(s); candidates of both arrays land in the same record list, tagged 0 / 1
-int enqueue_filter(swa_db* db, bool two, int64_t minscore, int64_t maxscore, hipStream_t st)
+int enqueue_filter(swa_db* db, bool two, int64_t minscore, int64_t maxscore, hipStream_t st, const Pair* pair = nullptr)
 {
   HIP_TRY(hipMemsetAsync(db->ctl.p + CTL_CAND, 0, (16 - CTL_CAND) * sizeof(int32_t), st));
   unsigned long long* tallies = reinterpret_cast<unsigned long long*>(db->ctl.p + CTL_TALLY);
   HIP_TRY(swa_launch_filter(db->scores.p, db->scores64.p, int(db->nseq), 0, minscore, maxscore, db->ctl.p + CTL_CAND,
                             db->cand_cap, cand_dev(db), tallies, st));
-  if (two)
+  if (two && pair && pair->own_window) {                 // a different query: its own thresholds and its own counts
+    unsigned long long* tallies_b = reinterpret_cast<unsigned long long*>(db->ctl.p + CTL_TALLY_B);
+    HIP_TRY(hipMemsetAsync(tallies_b, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(swa_launch_filter(db->scores2.p, db->scores64b.p, int(db->nseq), 1, pair->minscore_b, pair->maxscore_b,
+                              db->ctl.p + CTL_CAND, db->cand_cap, cand_dev(db), tallies_b, st));
+  } else if (two) {
     HIP_TRY(swa_launch_filter(db->scores2.p, db->scores64b.p, int(db->nseq), 1, minscore, maxscore, db->ctl.p + CTL_CAND,
                               db->cand_cap, cand_dev(db), tallies, st));
+  }
   return SWA_OK;
 }
 
@@ -1929,7 +1961,7 @@ int candidates_by_histogram(swa_db* db, const int32_t* scores, const long long* 
 // after sync_ctl(db, CAND_EAGER): the filter's results out of the page-locked block (tag0 / tag1 = the `which` value
 // the caller wants on candidates of the first / second score array)
 int gather_candidates(swa_db* db, bool two, int32_t tag0, int32_t tag1, int64_t keep, int64_t minscore, int64_t maxscore,
-                      std::vector<Cand>& cand, int64_t* totalhits, int64_t* obvious)
+                      std::vector<Cand>& cand, int64_t* totalhits, int64_t* obvious, Pair* pair = nullptr)
 {
   const int32_t* h = ctl_host(db);
   const int64_t ncand = h[CTL_CAND];
@@ -1937,6 +1969,11 @@ int gather_candidates(swa_db* db, bool two, int32_t tag0, int32_t tag1, int64_t 
   std::memcpy(tl, h + CTL_TALLY, sizeof tl);
   *totalhits += int64_t(tl[0]);
   *obvious += int64_t(tl[1]);
+  if (pair && pair->own_window) {
+    std::memcpy(tl, h + CTL_TALLY_B, sizeof tl);
+    pair->total_b = int64_t(tl[0]);
+    pair->obvious_b = int64_t(tl[1]);
+  }
   if (ncand <= db->cand_cap) {
     const swa_cand* rec = reinterpret_cast<const swa_cand*>(db->pin + CTL_INTS * sizeof(int32_t));
     std::vector<swa_cand> rest;
@@ -1952,7 +1989,10 @@ int gather_candidates(swa_db* db, bool two, int32_t tag0, int32_t tag1, int64_t 
     return SWA_OK;
   }
   int rc = candidates_by_histogram(db, db->scores.p, db->scores64.p, 0, tag0, keep, minscore, maxscore, cand);
-  if (rc == SWA_OK && two) rc = candidates_by_histogram(db, db->scores2.p, db->scores64b.p, 1, tag1, keep, minscore, maxscore, cand);
+  if (rc == SWA_OK && two && pair && pair->own_window)
+    rc = candidates_by_histogram(db, db->scores2.p, db->scores64b.p, 1, tag1, pair->keep_b, pair->minscore_b, pair->maxscore_b, cand);
+  else if (rc == SWA_OK && two)
+    rc = candidates_by_histogram(db, db->scores2.p, db->scores64b.p, 1, tag1, keep, minscore, maxscore, cand);
   return rc;
 }
 
@@ -1971,30 +2011,33 @@ bool cand_before(const Cand& a, const Cand& b)
 // `cand` with `which` = tag0 / tag1.
 int search_candidates(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, int64_t keep, int64_t minscore,
                       int64_t maxscore, int32_t tag0, int32_t tag1, std::vector<Cand>& cand, int64_t* totalhits,
-                      int64_t* obvious, swa_counters_t* counters)
+                      int64_t* obvious, swa_counters_t* counters, Pair* pair = nullptr)
 {
   hipStream_t st = db ? db->stream : nullptr;
+  const int64_t qa = pair ? pair->qlen_a : 0, qb = pair ? pair->qlen_b : 0;
+  // one first pass serves both queries: it must keep whatever EITHER threshold wants
+  const int64_t bound_min = pair && pair->own_window ? std::min(minscore, pair->minscore_b) : minscore;
   for (;;) {
     Pending pd;
-    int rc = q2 ? run_search2(db, q1, q2, qlen, minscore, pd) : run_search(db, q1, qlen, minscore, pd);
+    int rc = q2 ? run_search2(db, q1, q2, qlen, bound_min, pd, qa, qb) : run_search(db, q1, qlen, minscore, pd);
     if (rc != SWA_OK) return rc;
     if (db->nseq) {
-      rc = enqueue_filter(db, q2 != nullptr, minscore, maxscore, st);
+      rc = enqueue_filter(db, q2 != nullptr, minscore, maxscore, st, pair);
       if (rc != SWA_OK) return rc;
     }
     rc = sync_ctl(db, db->nseq ? std::min(CAND_EAGER, db->cand_cap) : 0, st);
     if (rc != SWA_OK) return rc;
     bool again = false, changed = false;
-    rc = settle_search(db, pd, q1, q2, qlen, minscore, &again, &changed);
+    rc = settle_search(db, pd, q1, q2, qlen, bound_min, &again, &changed, qa, qb);
     if (rc != SWA_OK) return rc;
     if (again) continue;
     if (changed && db->nseq) {
-      rc = enqueue_filter(db, q2 != nullptr, minscore, maxscore, st);
+      rc = enqueue_filter(db, q2 != nullptr, minscore, maxscore, st, pair);
       if (rc == SWA_OK) rc = sync_ctl(db, std::min(CAND_EAGER, db->cand_cap), st);
       if (rc != SWA_OK) return rc;
     }
     if (db->nseq) {
-      rc = gather_candidates(db, q2 != nullptr, tag0, tag1, keep, minscore, maxscore, cand, totalhits, obvious);
+      rc = gather_candidates(db, q2 != nullptr, tag0, tag1, keep, minscore, maxscore, cand, totalhits, obvious, pair);
       if (rc != SWA_OK) return rc;
     }
     if (counters) *counters = pd.c;
@@ -2098,6 +2141,47 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
   std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), cand_before);
   for (size_t i = 0; i < k; ++i) { hits[i] = {cand[i].seqno, cand[i].score}; which[i] = cand[i].which; }
   *nhits = int64_t(k);
+  return SWA_OK;
+}
+
+// Two different queries of a multi-query file in one pass (swipe.cc:2561-2575: the reference's unit of work is a query
+// FILE): each query keeps its own hit list, thresholds and counts; results equal two swa_search_topk calls.
+extern "C" int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t qlen1, const uint8_t* query2, int64_t qlen2,
+                                    int64_t keep1, int64_t minscore1, int64_t maxscore1, int64_t keep2, int64_t minscore2,
+                                    int64_t maxscore2, swa_hit_t* hits1, int64_t* nhits1, int64_t* totalhits1, int64_t* obvious1,
+                                    swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2, int64_t* obvious2,
+                                    swa_counters_t* counters)
+{
+  if (keep1 < 0 || keep2 < 0 || (keep1 > 0 && !hits1) || (keep2 > 0 && !hits2) || !nhits1 || !nhits2)
+    return fail(SWA_EINVAL, "bad hit buffer");
+  if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
+  if (qlen1 <= 0 || qlen2 <= 0) return fail(SWA_EINVAL, "swa_search_pair_topk needs two non-empty queries");
+  *nhits1 = *nhits2 = 0;
+  Pair pair;
+  pair.qlen_a = qlen1;
+  pair.qlen_b = qlen2;
+  pair.own_window = true;
+  pair.minscore_b = minscore2;
+  pair.maxscore_b = maxscore2;
+  pair.keep_b = keep2;
+  int64_t tot = 0, obv = 0;
+  std::vector<Cand> cand;
+  const int rc = search_candidates(db, query1, query2, std::max(qlen1, qlen2), keep1, minscore1, maxscore1, 0, 1, cand, &tot, &obv,
+                                   counters, &pair);
+  if (rc != SWA_OK) return rc;
+  if (totalhits1) *totalhits1 = tot;
+  if (obvious1) *obvious1 = obv;
+  if (totalhits2) *totalhits2 = pair.total_b;
+  if (obvious2) *obvious2 = pair.obvious_b;
+  std::vector<Cand> c1, c2;
+  for (const Cand& c : cand) (c.which ? c2 : c1).push_back(c);
+  const size_t k1 = std::min<size_t>(size_t(keep1), c1.size()), k2 = std::min<size_t>(size_t(keep2), c2.size());
+  std::partial_sort(c1.begin(), c1.begin() + k1, c1.end(), cand_before);
+  std::partial_sort(c2.begin(), c2.begin() + k2, c2.end(), cand_before);
+  for (size_t i = 0; i < k1; ++i) hits1[i] = {c1[i].seqno, c1[i].score};
+  for (size_t i = 0; i < k2; ++i) hits2[i] = {c2[i].seqno, c2[i].score};
+  *nhits1 = int64_t(k1);
+  *nhits2 = int64_t(k2);
   return SWA_OK;
 }
 

@@ -1317,3 +1317,38 @@ def test_chromosome_sized_nucleotide_subject_both_strands():
     hits, tot, obv, _ = db.search2_topk(q, qm, keep=10, minscore=100)
     assert hits == [(3000, 1000, 0), (3000, 1000, 1)] and tot == 2      # one score per (sequence, strand): the maximum over its windows
     db.close()
+
+
+@pytest.mark.parametrize("lens", [(375, 375), (375, 300), (300, 375), (100, 90), (40, 33), (600, 520), (1300, 1100), (2300, 2000)])
+def test_two_different_queries_in_one_pass(lens):
+    """swa_search_pair_topk: two queries of a multi-query file in the two halves of the packed lanes, the shorter padded
+    with rows that never score; each keeps its own thresholds, hit list and counts - equal to two separate searches and
+    to the oracle, with the exact first pass and with the bound build"""
+    rtab = synth.residue_table_protein()
+    qa = synth._random_residues(1001, 1, lens[0], rtab)
+    qb = synth._random_residues(2002, 1, lens[1], rtab)
+    res, off = swipe_amd.synth_db(41, 1500)
+    seqs = [res[off[i]:off[i + 1]] for i in range(1500)]
+    rng = np.random.default_rng(lens[0] * 7 + lens[1])
+    for k in range(60):                                      # relatives of either query, of both in one sequence
+        src = (qa, qb)[k % 2]
+        a = int(rng.integers(0, max(1, len(src) - 20)))
+        piece = src[a:a + int(rng.integers(10, 120))].copy()
+        mut = rng.random(len(piece)) < rng.random() * 0.3
+        piece[mut] = rtab[rng.integers(0, len(rtab), int(mut.sum()))]
+        seqs.append(np.concatenate([seqs[k][:30], piece, seqs[k + 1][:30]]))
+    seqs += [qa, qb, np.concatenate([qb, qa]), np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    wa = oracle.search_all63(r2, o2, qa, Mo, 12, 1, threads=THREADS)
+    wb = oracle.search_all63(r2, o2, qb, Mo, 12, 1, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    for bound in (0, 1, None):
+        db.set_option("bound", bound)
+        for (lo_a, hi_a), (lo_b, hi_b) in (((1, 1 << 62), (1, 1 << 62)), ((70, 1 << 62), (45, 200)), ((45, 150), (90, 1 << 62))):
+            (h1, t1, o1), (h2, t2, o2b), c = db.search_pair_topk(qa, qb, keep=(40, 25), minscore=(lo_a, lo_b), maxscore=(hi_a, hi_b))
+            assert (h1, t1, o1) == _expected_topk(wa, 40, lo_a, hi_a), (bound, lo_a)
+            assert (h2, t2, o2b) == _expected_topk(wb, 25, lo_b, hi_b), (bound, lo_b)
+            assert c["cells"] == int(o2[-1]) * (len(qa) + len(qb))
+    db.close()
