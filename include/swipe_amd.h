@@ -121,6 +121,18 @@ SWA_API int swa_db_open_translated(const char* basename, int db_gencode, int dev
 SWA_API int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
                                   int db_gencode, int device, int64_t first_seqno, int64_t total_seqcount,
                                   int64_t total_symcount, swa_db** out);
+/* Databases larger than the device memory they may use (the reference maps any range of a database a chunk at a time,
+   db_mapsequences, database.cc:1082-1131).  With hbm_budget_bytes below what the resident form needs, the shard stays
+   in page-locked HOST memory, cut into parts of at most half the budget; every search walks the parts through two
+   device slots - one is searched while the next part travels over PCIe and is formatted on the other (double
+   buffering) - and merges the per-part candidates, so hit lists, counts and scores are those of the resident shard.
+   The handle answers swa_search, swa_search_topk, swa_set_scoring, swa_set_option, swa_db_info and swa_db_close (other
+   entry points return SWA_ESTATE).  hbm_budget_bytes <= 0 or large enough: an ordinary resident shard. */
+SWA_API int swa_db_from_memory_streamed(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int device,
+                                int64_t first_seqno, int64_t total_seqcount, int64_t total_symcount,
+                                int64_t hbm_budget_bytes, swa_db** out);
+SWA_API int swa_db_open_streamed(const char* basename, int symtype, int device, int64_t first_seqno, int64_t last_seqno,
+                         int64_t hbm_budget_bytes, swa_db** out);
 SWA_API int swa_db_info(const swa_db* db, swa_db_info_t* info);
 /* Host-only: read sequences [first_seqno, last_seqno] of a BLAST v4 database into malloc'ed
    arrays in reference symbol codes (what db_getsequence returns, database.cc:1237-1401:

@@ -48,7 +48,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = [
-    "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_info",
+    "swa_last_error", "swa_device_count", "swa_db_open", "swa_db_from_memory", "swa_db_from_memory_streamed", "swa_db_open_streamed", "swa_db_info",
     "swa_db_open_translated", "swa_db_from_memory_translated", "swa_search_frames_topk",
     "swa_gencode_name", "swa_translate_table", "swa_translate",
     "swa_headers_open", "swa_headers_close", "swa_headers_info", "swa_headers_time", "swa_headers_get", "swa_headers_inclusion",
@@ -76,6 +76,8 @@ def load():
     L.swa_device_count.restype = C.c_int
     L.swa_db_open.argtypes = [C.c_char_p, C.c_int, C.c_int, i64, i64, C.POINTER(vp)]
     L.swa_db_from_memory.argtypes = [vp, vp, i64, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp)]
+    L.swa_db_from_memory_streamed.argtypes = [vp, vp, i64, C.c_int, C.c_int, i64, i64, i64, i64, C.POINTER(vp)]
+    L.swa_db_open_streamed.argtypes = [C.c_char_p, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp)]
     L.swa_db_info.argtypes = [vp, C.POINTER(DbInfo)]
     L.swa_blastdb_read.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(vp), C.POINTER(vp), i64p, i64p, i64p, i64p]
     L.swa_blastdb_defline.argtypes = [C.c_char_p, C.c_int, i64, C.c_char_p, i64, i64p]

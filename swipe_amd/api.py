@@ -146,12 +146,18 @@ class Database:
     @classmethod
     def from_arrays(cls, residues: np.ndarray, offsets: np.ndarray, *, symtype: int = 1, device: int = 0,
                     first_seqno: int = 0, total_seqcount: int = 0, total_symcount: int = 0,
-                    translate_gencode: Optional[int] = None):
-        """translate_gencode: residues are nucleotides to be held as their six translations under that code"""
+                    translate_gencode: Optional[int] = None, hbm_budget: int = 0):
+        """translate_gencode: residues are nucleotides to be held as their six translations under that code.
+        hbm_budget > 0 (bytes): a database that may not be resident is streamed through two device slots
+        (swa_db_from_memory_streamed); search and search_topk work on it as on a resident shard."""
         residues = np.ascontiguousarray(residues, dtype=np.uint8)
         offsets = _i64(offsets)
         h = C.c_void_p()
-        if translate_gencode is not None:
+        if hbm_budget > 0:
+            _check(_lib.load().swa_db_from_memory_streamed(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1, symtype,
+                                                           device, first_seqno, total_seqcount, total_symcount, hbm_budget,
+                                                           C.byref(h)))
+        elif translate_gencode is not None:
             _check(_lib.load().swa_db_from_memory_translated(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
                                                              translate_gencode, device, first_seqno, total_seqcount,
                                                              total_symcount, C.byref(h)))

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -185,7 +186,9 @@ uint16_t f16_bits(float f)
 }
 }  // namespace
 
+struct Streamed;                          // sw_streamed.inc: a database walked through two device slots, part by part
 struct swa_db {
+  std::shared_ptr<Streamed> streamed;     // set on the FRONT handle of a streamed database (it owns no device memory itself)
   int device = 0;
   int symtype = SWA_SYMTYPE_PROTEIN;
   int cus = 256;
@@ -282,6 +285,16 @@ struct swa_db {
 };
 
 namespace {
+int streamed_set_scoring(swa_db* front, const int64_t* matrix, int64_t goe, int64_t ge);
+size_t streamed_hbm(const swa_db* front);
+int streamed_candidates(swa_db* front, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore, int64_t maxscore,
+                        std::vector<struct Cand>& cand, int64_t* tot, int64_t* obv, swa_counters_t* counters);
+int streamed_all_scores(swa_db* front, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters);
+int not_streamed(const swa_db* db)
+{
+  return db && db->streamed ? fail(SWA_ESTATE, "streamed database: only swa_search, swa_search_topk, swa_set_scoring, "
+                                               "swa_set_option, swa_db_info and swa_db_close apply") : SWA_OK;
+}
 
 // Lay `ids` (already ordered by descending length) out as batches with `per_row` sequences per
 // DPP row (2 = packed pairs for the f16 kernel, 1 = slot A only for the wide kernels), upload,
@@ -1836,13 +1849,14 @@ extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
   info->first_seqno = db->first_seqno;
   info->total_seqcount = db->total_seq;
   info->total_symcount = db->total_sym;
-  info->hbm_bytes = int64_t(db->hbm_bytes());
+  info->hbm_bytes = int64_t(db->streamed ? streamed_hbm(db) : db->hbm_bytes());
   return SWA_OK;
 }
 
 extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t n)
 {
   if (!db) return fail(SWA_EINVAL, "null database handle");
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   const int64_t real = db->nseq / db->frames;
   if (include && n != real) return fail(SWA_EINVAL, "inclusion array must have one entry per sequence of the shard");
   HIP_TRY(hipSetDevice(db->device));
@@ -1889,6 +1903,10 @@ extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapope
   db->hi = hi;
   db->goe = gapopenextend;
   db->ge = gapextend;
+  if (db->streamed) {
+    db->scoring_set = true;
+    return streamed_set_scoring(db, matrix, gapopenextend, gapextend);
+  }
   HIP_TRY(hipSetDevice(db->device));
   HIP_TRY(hipMemcpyAsync(db->matrix.p, db->h_matrix, sizeof db->h_matrix, hipMemcpyHostToDevice, db->stream));
   HIP_TRY(hipStreamSynchronize(db->stream));
@@ -2084,8 +2102,14 @@ int download_scores(swa_db* db, const int32_t* dev, const DevBuf<long long>& dev
 }
 }  // namespace
 
+#include "sw_streamed.inc"
+
 extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters)
 {
+  if (db && db->streamed) {
+    const int rc0 = check_query(db, query, qlen);
+    return rc0 != SWA_OK ? rc0 : streamed_all_scores(db, query, qlen, scores, counters);
+  }
   const int rc = search_all(db, query, nullptr, qlen, counters);
   if (rc != SWA_OK || !scores || db->nseq == 0) return rc;
   return download_scores(db, db->scores.p, db->scores64, scores);
@@ -2100,7 +2124,13 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
   *nhits = 0;
   int64_t tot = 0, obv = 0;
   std::vector<Cand> cand;
-  const int rc = search_candidates(db, query, nullptr, qlen, keep, minscore, maxscore, 0, 0, cand, &tot, &obv, counters);
+  int rc = SWA_OK;
+  if (db && db->streamed) {
+    rc = check_query(db, query, qlen);
+    if (rc == SWA_OK) rc = streamed_candidates(db, query, qlen, keep, minscore, maxscore, cand, &tot, &obv, counters);
+  } else {
+    rc = search_candidates(db, query, nullptr, qlen, keep, minscore, maxscore, 0, 0, cand, &tot, &obv, counters);
+  }
   if (rc != SWA_OK) return rc;
   if (totalhits) *totalhits = tot;
   if (obvious) *obvious = obv;
@@ -2114,6 +2144,7 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
 extern "C" int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
                            int64_t* scores1, int64_t* scores2, swa_counters_t* counters)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
   int rc = search_all(db, query1, query2 ? query2 : query1, qlen, counters);
   if (rc != SWA_OK || db->nseq == 0) return rc;
@@ -2126,6 +2157,7 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
                                 int64_t minscore, int64_t maxscore, swa_hit_t* hits, int32_t* which, int64_t* nhits,
                                 int64_t* totalhits, int64_t* obvious, swa_counters_t* counters)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
   if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
@@ -2152,6 +2184,7 @@ extern "C" int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t q
                                     swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2, int64_t* obvious2,
                                     swa_counters_t* counters)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (keep1 < 0 || keep2 < 0 || (keep1 > 0 && !hits1) || (keep2 > 0 && !hits2) || !nhits1 || !nhits2)
     return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
@@ -2190,6 +2223,7 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
                                       swa_fhit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                                       swa_counters_t* counters)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (!db) return fail(SWA_EINVAL, "null database handle");
   if (nq < 1 || nq > 6 || !queries || !qlens) return fail(SWA_EINVAL, "between 1 and 6 query frames expected");
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
@@ -2229,9 +2263,10 @@ extern "C" int swa_set_option(swa_db* db, const char* key, const char* value)
   for (const OptionKey& k : kOptionKeys)
     if (!std::strcmp(k.key, key)) {
       int64_t v = 0;
-      if (!value) { db->opt.*(k.field) = Options{}.*(k.field); return SWA_OK; }     // NULL: back to the default
-      if (!parse_option_value(key, value, &v)) return fail(SWA_EINVAL, std::string("bad value for option ") + key);
+      if (value && !parse_option_value(key, value, &v)) return fail(SWA_EINVAL, std::string("bad value for option ") + key);
+      if (!value) v = Options{}.*(k.field);                                          // NULL: back to the default
       db->opt.*(k.field) = v;
+      if (db->streamed) for (swa_db* slot : db->streamed->slot) slot->opt.*(k.field) = v;
       return SWA_OK;
     }
   return fail(SWA_EINVAL, std::string("unknown option ") + key);
@@ -2401,6 +2436,7 @@ extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int
                                            const int32_t* dstrands, const int32_t* dframes, int64_t n, int64_t* scores,
                                            int64_t* bestpos, int64_t* bestq)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
   if (n < 0 || (n > 0 && (!seqnos || !scores || !bestpos || !bestq))) return fail(SWA_EINVAL, "bad argument");
@@ -2425,6 +2461,7 @@ extern "C" int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t ql
 extern "C" int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, uint8_t* buf, int64_t cap,
                                int64_t* len, int64_t* ntlen)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (!db || !len || cap < 0 || (cap > 0 && !buf)) return fail(SWA_EINVAL, "bad argument");
   std::vector<uint8_t> seq;
   const int rc = fetch_sequence(db, seqno, dstrand, dframe, seq);
@@ -2495,6 +2532,7 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
                               const int32_t* dstrands, const int32_t* dframes, int64_t n, swa_alignment_t* out,
                               char* text, int64_t text_cap, int64_t* text_used)
 {
+  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
   if (n < 0 || text_cap < 0 || !text_used || (n > 0 && (!seqnos || !out)) || (text_cap > 0 && !text))

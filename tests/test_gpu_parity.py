@@ -1352,3 +1352,36 @@ def test_two_different_queries_in_one_pass(lens):
             assert (h2, t2, o2b) == _expected_topk(wb, 25, lo_b, hi_b), (bound, lo_b)
             assert c["cells"] == int(o2[-1]) * (len(qa) + len(qb))
     db.close()
+
+
+def test_database_larger_than_its_hbm_budget_is_streamed():
+    """a shard that may use less device memory than its resident form needs stays in page-locked host memory and is
+    walked through two device slots, part by part, double-buffered: same scores, hit lists and counts as the resident
+    shard for every budget, in both walking directions, with the bound build and with score windows"""
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(1, 40_000, query=q)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    want = oracle.search_all63(res, off, q, Mo, 12, 1, threads=THREADS)
+    resident = swipe_amd.Database.from_arrays(res, off, first_seqno=1000)
+    resident.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    full = resident.info()["hbm_bytes"]
+    for budget_mb in (34, 26, 18.5):                         # 2 slots x (budget / 2 - 8 MB of fixed allowance): 4, 6 and ~24 parts
+        db = swipe_amd.Database.from_arrays(res, off, first_seqno=1000, hbm_budget=int(budget_mb * (1 << 20)))
+        info = db.info()
+        assert info["seqcount"] == 40_000 and info["symcount"] == int(off[-1]) and info["hbm_bytes"] < 0.8 * full
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        for rnd in range(3):                                 # the walk alternates direction
+            scores, c = db.search(q)
+            assert np.array_equal(scores, want) and c["cells"] == int(off[-1]) * len(q)
+        for bound in (None, 1, 0):
+            db.set_option("bound", bound)
+            for minscore, maxscore in ((40, 1 << 62), (80, 1 << 62), (45, 120)):
+                got = db.search_topk(q, keep=60, minscore=minscore, maxscore=maxscore)
+                ref = resident.search_topk(q, keep=60, minscore=minscore, maxscore=maxscore)
+                assert got[:3] == ref[:3]
+                exp = _expected_topk(want, 60, minscore, maxscore)
+                assert ([(s - 1000, v) for s, v in got[0]], got[1], got[2]) == exp
+        with pytest.raises(swipe_amd.SwaError):
+            db.search2(q, q)
+        db.close()
+    resident.close()
