@@ -118,9 +118,9 @@ def cpu_baseline(res, off, query_text, cores, *, protein=True, sample_seqs=3_000
             swipe_amd.write_blastdb(base, res, off[: n + 1], symtype=1 if protein else 0)
             extra = [] if protein else ["-p", "0", "-r", "1", "-q", "-3", "-G", "5", "-E", "2"]
             sweep = {}
-            cand = sorted({t for t in (16, 32, 64, 128, 256) if t <= max(cores, 16)} | {min(cores, 256)})
+            cand = sorted({t for t in (8, 16, 24, 32, 64, 128, 256) if t <= max(cores, 8)} | {min(cores, 256)})
             for t in cand:
-                g, k, tot = reference_cli_rate(d, base, query_text, t, extra, cells1, budget_s=4.0)
+                g, k, tot = reference_cli_rate(d, base, query_text, t, extra, cells1, budget_s=3.0)
                 sweep[t] = (round(g, 2), k, round(tot, 2))
             best = max(sweep, key=lambda t: sweep[t][0])
             return {"value": sweep[best][0], "unit": "GCUPS", "cores": best, "kind": "reference",
@@ -289,7 +289,10 @@ def main():
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SWA_BENCH_DEVICE / SWA_BENCH_BACKEND=gloo: tests run the N-rank code path on the ONE GPU a test box has (all ranks on
+    # that device, collectives over gloo on host tensors - RCCL refuses two ranks on one GPU); the driver never sets them
+    local = int(os.environ.get("SWA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("SWA_BENCH_BACKEND", "nccl")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import swipe_amd
@@ -301,7 +304,11 @@ def main():
     use_dist = world > 1 or os.environ.get("SWA_BENCH_FORCE_DIST") == "1"     # the latter: exercise RCCL with one rank
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"          # where the collectives' tensors live
     cores = os.cpu_count() or 1
 
     if a.workload == "nucleotide":
@@ -332,7 +339,7 @@ def main():
     nsym = int(off[-1])
     tot_sym = nsym
     if use_dist:
-        t = torch.tensor([nsym], dtype=torch.int64, device="cuda")
+        t = torch.tensor([nsym], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         tot_sym = int(t.item())
     if not a.weak and tot_sym != tot_sym_known:
@@ -342,7 +349,7 @@ def main():
     t_load = time.time() - t0
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     st = swipe_amd.stats_init(qlen=len(q), db_seqcount=db_seqs, db_symcount=tot_sym)
-    dev = torch.device("cuda", local) if use_dist else None
+    dev = torch.device("cuda", local) if use_dist and backend == "nccl" else None
     minscore, maxscore = st.scorethreshold, st.upperscorethreshold
 
     def step():
@@ -359,7 +366,7 @@ def main():
     def all_max(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -387,7 +394,7 @@ def main():
     exact = None
     want_exact = int(c["narrow_shifted"] in (8, 9) and not a.no_secondary)
     if use_dist:                                         # every rank takes the same branch (the steps hold collectives)
-        t = torch.tensor([want_exact], dtype=torch.int64, device="cuda")
+        t = torch.tensor([want_exact], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         want_exact = int(t.item())
     if want_exact:
@@ -410,7 +417,7 @@ def main():
     if not a.no_verify:
         nver, bad, tot_local = verify_against_oracle(db, res, off, lo, q, "BLOSUM62", 12, 1, [tuple(h) for h in hits.tolist()],
                                                      tot, minscore, maxscore, max(1, a.verify_sample // world), gen_threads)
-        v = torch.tensor([nver, bad, tot_local], dtype=torch.int64, device="cuda")
+        v = torch.tensor([nver, bad, tot_local], dtype=torch.int64, device=cdev)
         if use_dist:
             dist.all_reduce(v)
         nver, bad, tot_all = (int(x) for x in v.tolist())
@@ -435,6 +442,7 @@ def main():
             "vs_baseline": None, "dtype": "f16x2 (exact integers; re-queue to i32/i64)", "data": "synthetic",
             "value_is": what + ": hit list, totalhits and every listed score bit-exact (verified_vs_oracle); the all-scores-"
                                "exact rate of swa_search is exact_first_pass.value",
+            "collectives": (backend if use_dist else None),
             "config": {"workload": f"375-aa query (P07327) vs ONE database of {db_seqs} synthetic protein sequences "
                                    f"({tot_sym} residues), BLOSUM62, gap 11+1, top-{KEEP} hits by E<=10 (score >= {minscore})",
                        "sequences_total": db_seqs, "residues_total": tot_sym, "query_len": len(q),

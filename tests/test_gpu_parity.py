@@ -1385,3 +1385,27 @@ def test_database_larger_than_its_hbm_budget_is_streamed():
             db.search2(q, q)
         db.close()
     resident.close()
+
+
+def test_bench_shards_one_database_over_two_ranks():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on the one GPU of this box:
+    both ranks use device 0 and the collectives run over gloo (RCCL refuses two ranks on one GPU).  The ONE database is cut by
+    parallel.shard_bounds, each rank generates and searches only its residue-balanced slice, the gathered hit list, totalhits
+    and every verified score equal the single-rank run's"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--nseq", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--verify-sample", "2000"]
+    one = _bench_line({}, *args)
+    env = dict(os.environ, SWA_BENCH_DEVICE="0", SWA_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", *args],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["collectives"] == "gloo"
+    assert two["hits_sha1"] == one["hits_sha1"] and two["search"]["totalhits"] == one["search"]["totalhits"]
+    assert two["config"]["residues_total"] == one["config"]["residues_total"]
+    assert abs(two["config"]["residues_rank0"] * 2 - two["config"]["residues_total"]) < 40_000      # balanced by residues
+    assert two["verified_vs_oracle"] >= 2000
