@@ -283,6 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-first-pass, nucleotide and cold-open sections")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-open (disk -> HBM) section")
     ap.add_argument("--verify-sample", type=int, default=10_000)
     ap.add_argument("--workload", choices=["protein", "protein100M", "nucleotide"], default="protein",
                     help="protein = BASELINE.json configs[1] (the headline); protein100M = configs[4]; nucleotide = configs[3]")
@@ -464,7 +465,7 @@ def main():
         if exact:
             out["exact_first_pass"] = exact
         line = out
-    if world == 1 and rank == 0 and not a.no_secondary and a.workload == "protein":
+    if world == 1 and rank == 0 and not a.no_secondary and not a.no_cold and a.workload == "protein":
         try:
             line["cold_open"] = cold_open(res, off, local)
         except Exception as e:
