@@ -46,14 +46,24 @@ KERNEL = {0: "swa_narrow_kernel<%d>", 1: "swa_narrow_split_kernel<%d, W, 16>", 2
           9: "swa_narrow_bound_kernel<%d, 2, 16, 16, MP> (one launch per pass)", 10: "swa_dual_bound_kernel<%d>"}
 
 
-def roofline_blocks(nsym, nseq, cells, k_ms, form, rows, bytes_per_residue=1.0, traffic=None, traffic_source=None):
+def kernel_name(form, rows, qlen):
+    """the first-pass kernel as rocprofv3 names it, where the template arguments follow from (form, rows, qlen) alone"""
+    if form == 8:                                        # swipe_amd.cpp run_search + sw_cb_kernel.inc cb_waves_for
+        G = 2 if qlen <= 96 else 4 if qlen <= 192 else 8 if qlen <= 384 else 16
+        W = 8 if rows <= 5 else 6 if rows <= 10 else 4 if rows <= 20 else 3 if rows <= 29 else 2
+        return ("swa_narrow_bound_kernel<%d, %d, %d, 16, false> (bound build of the first pass; sequences at or above the score "
+                "threshold recomputed exactly by the 32-bit wave kernel beside it)" % (rows, W, G))
+    return KERNEL.get(form, "first-pass kernel, %d rows per lane") % rows
+
+
+def roofline_blocks(nsym, nseq, cells, k_ms, form, rows, bytes_per_residue=1.0, traffic=None, traffic_source=None, qlen=375):
     """roofline (HBM, SURVEY.md 8(d): 1 B per residue + 12 B per sequence per launch) and the VALU-issue model"""
     alg_bytes = int(nsym * bytes_per_residue) + 12 * nseq
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     ops = OPS.get(form, 7.5)
     r = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-         "kernel": KERNEL.get(form, "first-pass kernel, %d rows per lane") % rows, "kernel_ms": round(k_ms, 3),
+         "kernel": kernel_name(form, rows, qlen), "kernel_ms": round(k_ms, 3),
          "algorithmic_bytes_per_launch": alg_bytes,
          "note": "integer DP at hundreds of cells per residue byte is VALU-issue-bound, not HBM-bound; see valu_roofline"}
     if traffic_source:
@@ -252,7 +262,8 @@ def nucleotide_section(a, rank, local, world, nseq, steps, want_cpu):
     k_ms = float(np.mean(kms))
     info = db.info()
     traffic, tsrc = committed_traffic("nucleotide", nseq)
-    roof, valu = roofline_blocks(nsym, nseq, cells, k_ms, c["narrow_shifted"], c["narrow_rows"], traffic=traffic, traffic_source=tsrc)
+    roof, valu = roofline_blocks(nsym, nseq, cells, k_ms, c["narrow_shifted"], c["narrow_rows"], traffic=traffic, traffic_source=tsrc,
+                                 qlen=len(q))
     roof["algorithmic_bytes_note"] = ("1 B per base + 12 B per sequence, read ONCE for both strands (the reference makes one pass per "
                                       "strand, swipe.cc:1403); at the .nsq format's 2 bits per base it would be %d" % (nsym // 4 + 12 * nseq))
     out = {"metric": "GCUPS, 1 kb DNA query vs synthetic nt db, both strands (BASELINE.json configs[3])",

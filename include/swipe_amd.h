@@ -91,7 +91,8 @@ typedef struct {
                             7: row-shifted form with 2 lanes per sequence pair (queries of at most 40 rows);
                             8: bound build of the row-shifted form (swa_search_topk only, see there);
                             9: bound build, one launch per pass (queries > 928 rows);
-                            10: bound build of the two-query kernel (non-nucleotide pairs of 129..512 rows) */
+                            10: bound build of the two-query kernel (non-nucleotide pairs of 129..512 rows);
+                            11: row-shifted form, ONE lane per sequence pair (exact searches of queries of at most 48 rows) */
 } swa_counters_t;
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;
@@ -126,8 +127,9 @@ SWA_API int swa_db_from_memory_translated(const uint8_t* nt_residues, const int6
    in page-locked HOST memory, cut into parts of at most half the budget; every search walks the parts through two
    device slots - one is searched while the next part travels over PCIe and is formatted on the other (double
    buffering) - and merges the per-part candidates, so hit lists, counts and scores are those of the resident shard.
-   The handle answers swa_search, swa_search_topk, swa_set_scoring, swa_set_option, swa_db_info and swa_db_close (other
-   entry points return SWA_ESTATE).  hbm_budget_bytes <= 0 or large enough: an ordinary resident shard. */
+   The handle answers swa_search, swa_search_topk, swa_search2_topk (nucleotide parts carry the 4-bit one-sequence-per-
+   row tables their both-strand searches run over), swa_search_pair_topk, swa_set_scoring, swa_set_option, swa_db_info
+   and swa_db_close (other entry points return SWA_ESTATE).  hbm_budget_bytes <= 0 or large enough: an ordinary resident shard. */
 SWA_API int swa_db_from_memory_streamed(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int device,
                                 int64_t first_seqno, int64_t total_seqcount, int64_t total_symcount,
                                 int64_t hbm_budget_bytes, swa_db** out);
@@ -185,7 +187,7 @@ SWA_API void swa_db_close(swa_db* db);
    DESIGN.md 4.9, so a SWIPE integration never needs this call - it exists for the A/B tools and so that the parity
    tests reach every kernel build.  key / value are text ("bound", "0"); value NULL restores the default.  Keys:
      bound            top-K searches: -1 auto, 0 exact first pass always, 1 bound build whenever one exists
-     lanes            lanes per sequence pair of the first-pass kernel (2, 4, 8, 16) if the query fits; 0 auto
+     lanes            lanes per sequence pair of the first-pass kernel (1, 2, 4, 8, 16) if the query fits; 0 auto
      pipe             profile-load build of the first-pass kernel: -1 measured best, 0 / 1 / 2
      blocks_per_cu    persistent blocks per CU of the first-pass kernel; 0 = 8
      narrow_variant   1 plain (8.5-instruction) form, 2 row-shifted form, 0 auto

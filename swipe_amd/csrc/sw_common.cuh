@@ -41,6 +41,14 @@ __device__ __forceinline__ u32 seq_residue(const swa_seqs& s, int64_t idx)
   return s.packed ? ((u32)s.residues[idx >> 1] >> ((int)(idx & 1) * 4)) & 15u : (u32)s.residues[idx];
 }
 
+// Start of a first-pass block when a re-queue follower may run beside the kernel: "the producer is on the device".  A
+// follower that never sees this gives up (swa_requeue_follow_kernel) - under a tool that runs one kernel at a time it
+// may have been dispatched first, and must not wait for a kernel that cannot start.
+__device__ __forceinline__ void signal_block_started(int32_t* done)
+{
+  if (done && threadIdx.x == 0) __hip_atomic_store(done + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // End of a first-pass block when a re-queue follower runs beside the kernel: everything this block appended to the list is
 // released (agent scope) before its tick; the block that ticks last raises the flag the follower's waves poll.
 __device__ __forceinline__ void signal_block_done(int32_t* finished, int32_t* done)

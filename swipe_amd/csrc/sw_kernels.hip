@@ -297,21 +297,7 @@ swa_narrow_kernel(swa_narrow_params p)
 //   * a 16-byte LDS unit is stored once per pair position of a DPP row: unit (d*C + c)*16 + l serves lane
 //     l & (G-1) of each pair, so the pairs of a row read disjoint bank groups - conflict-free as before;
 //   * the residue register of a lane is refilled every G steps from the 16-column chunks of ITS batch.
-template <int K, int G>
-__device__ __forceinline__ void build_profile_f16_split(unsigned char* lds, const swa_query* q, float add, int row0 = 0)
-{
-  constexpr int C = (K + 7) / 8;
-  unsigned short* t = (unsigned short*)lds;
-  const int total = 32 * C * 16 * 8;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int k = e & 7, l = (e >> 3) & (G - 1), c = (e >> 7) % C, d = (e >> 7) / C;
-    const int local = c * 8 + k;
-    const int row = row0 + l * K + local;
-    float v = -1.0f;
-    if (local < K && row < q->qlen && d != SWA_PAD) v = (float)q->matrix[(d << 5) + q->qseq[row]];
-    t[e] = (unsigned short)float_to_half_bits(v + add);
-  }
-}
+#include "sw_profile.cuh"
 
 //
 // MP (16-lane chains only): one PASS of a query longer than 928 rows.  The launch covers rows
@@ -328,6 +314,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
   constexpr u32 CS = C * 256;
   constexpr int NB = 16 / G;                              // batches per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  if constexpr (!MP) signal_block_started(p.done);
   build_profile_f16_split<K, G>(lds, p.query, p.gapextend_f, MP ? p.row0 : 0);
   __syncthreads();
 
@@ -820,6 +807,7 @@ swa_requeue_wave_kernel(swa_seqs sq, const int32_t* __restrict__ list, const int
     const int w = next;
     if (w >= n) break;
     const int id = list[w];
+    if (id < 0) continue;                                  // taken by a follower (marked -2 - id), which finishes it itself
     int64_t o, len64;
     seq_span(sq, id, o, len64);
     const int len = (int)len64;
@@ -839,7 +827,7 @@ swa_requeue_wave_kernel(swa_seqs sq, const int32_t* __restrict__ list, const int
 // kernels are not co-resident (register file full: the exact build) the follower simply runs after the producer.
 template <int K>
 __global__ void __launch_bounds__(64)
-swa_requeue_follow_kernel(swa_seqs sq, const int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
+swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
                           const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
                           int* __restrict__ scores)
 {
@@ -848,6 +836,7 @@ swa_requeue_follow_kernel(swa_seqs sq, const int32_t* list, int cap, int32_t* __
   __shared__ int next, leave;
   const int g = threadIdx.x;
   for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
+  bool started = false;                                    // lane 0: the producer has been seen on the device
   for (;;) {
     __syncthreads();
     if (g == 0) {
@@ -856,7 +845,7 @@ swa_requeue_follow_kernel(swa_seqs sq, const int32_t* list, int cap, int32_t* __
       if (w < cap) {
         // relaxed polls a few microseconds apart: an acquire per poll would invalidate the CU's caches under the
         // first-pass waves next door (measured: 1 024 polling waves cost the first pass 37 %)
-        for (;;) {
+        for (int polls = 0;; ++polls) {
           id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (id >= 0) break;
           if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -864,10 +853,19 @@ swa_requeue_follow_kernel(swa_seqs sq, const int32_t* list, int cap, int32_t* __
             id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;                                // still -1: position w lies beyond the end of the list
           }
+          // The producer was submitted before this kernel, but a profiler that runs one kernel at a time may have
+          // dispatched this one first: never wait for a kernel that is not on the device.  About a millisecond without
+          // a sign of it and the follower leaves; the finishing kernel does all the work then.
+          if (!started) {
+            started = __hip_atomic_load(done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (!started && polls > 128) { fin = 1; id = -1; break; }
+          }
           __builtin_amdgcn_s_sleep(127);
           __builtin_amdgcn_s_sleep(127);
         }
       }
+      // taken: the finishing kernel (same list, its own queue head) skips entries marked < -1
+      if (id >= 0) __hip_atomic_store(list + w, -2 - id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence();
       next = id;
       leave = fin;
@@ -884,7 +882,7 @@ swa_requeue_follow_kernel(swa_seqs sq, const int32_t* list, int cap, int32_t* __
       if (g == 0) scores[id] = best;
     }
     // the first pass is through: whatever is left belongs to the finishing kernel (swa_requeue_wave_kernel on the first
-    // stream, many more waves, same work-queue head)
+    // stream, many more waves)
     if (id < 0 || last) break;
   }
 }
@@ -1176,7 +1174,7 @@ extern "C" hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t*
 #undef SWA_RQW
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_requeue_follow(const swa_seqs* sq, const int32_t* list, int cap,
+extern "C" hipError_t swa_launch_requeue_follow(const swa_seqs* sq, int32_t* list, int cap,
                                                 int32_t* work, const int32_t* done, const uint8_t* qseq, int qlen,
                                                 const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
 {

@@ -29,6 +29,8 @@ extern "C" {
 int swa_narrow_rows_for(int qlen);
 int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_one_a(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_one_b(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_dual_bound(int G, int K, const swa_mp_params* p, int cus, hipStream_t st);
@@ -65,7 +67,7 @@ hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n
 hipError_t swa_launch_rebase(const swa_batch* src, swa_batch* dst, int n, uint32_t delta, hipStream_t st);
 hipError_t swa_launch_fold(int* scores, long long* scores64, const int32_t* parents, const int32_t* wfirst, int nparents, int nseq,
                            hipStream_t st);
-hipError_t swa_launch_requeue_follow(const swa_seqs* sq, const int32_t* list, int cap, int32_t* work,
+hipError_t swa_launch_requeue_follow(const swa_seqs* sq, int32_t* list, int cap, int32_t* work,
                                      const int32_t* done, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                      int* scores, int blocks, hipStream_t st);
 hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t* list, const int32_t* count,
@@ -288,12 +290,14 @@ namespace {
 int streamed_set_scoring(swa_db* front, const int64_t* matrix, int64_t goe, int64_t ge);
 size_t streamed_hbm(const swa_db* front);
 int streamed_candidates(swa_db* front, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore, int64_t maxscore,
-                        std::vector<struct Cand>& cand, int64_t* tot, int64_t* obv, swa_counters_t* counters);
+                        std::vector<struct Cand>& cand, int64_t* tot, int64_t* obv, swa_counters_t* counters,
+                        const uint8_t* query2 = nullptr, int32_t tag1 = 0, struct Pair* pair = nullptr);
 int streamed_all_scores(swa_db* front, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters);
 int not_streamed(const swa_db* db)
 {
-  return db && db->streamed ? fail(SWA_ESTATE, "streamed database: only swa_search, swa_search_topk, swa_set_scoring, "
-                                               "swa_set_option, swa_db_info and swa_db_close apply") : SWA_OK;
+  return db && db->streamed ? fail(SWA_ESTATE, "streamed database: only swa_search, swa_search_topk, swa_search2_topk, "
+                                               "swa_search_pair_topk, swa_set_scoring, swa_set_option, swa_db_info and "
+                                               "swa_db_close apply") : SWA_OK;
 }
 
 // Lay `ids` (already ordered by descending length) out as batches with `per_row` sequences per
@@ -1257,12 +1261,15 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   const int Nb = swa_bound_period();
   const bool want_bound = bound_wanted(db, qlen, bound_min);
   if (want_bound && qlen <= 2 * 48) G = 2;
+  // ONE lane per sequence pair (sw_one_kernel.inc) for exact searches of queries of at most 48 rows: no chain, hence
+  // no hand-overs and no skew (10 aa 5.8 -> TCUPS); top-K searches keep the 2-lane bound build
+  if (!want_bound && qlen <= 48) G = 1;
   if (db->opt.lanes > 0) {
-    G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : 2;
+    G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
     while (G < 16 && qlen > G * 48) G *= 2;
   }
-  if (G < 16 && !short_chains_safe(db, qlen) && qlen <= 16 * 58) G = 16;
-  const int Kg = swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
+  if (G > 1 && G < 16 && !short_chains_safe(db, qlen) && qlen <= 16 * 58) G = 16;
+  const int Kg = G == 1 ? int(qlen) : swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
   if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->opt.narrow_variant != 1) {
     const int K = Kg;
     swa_narrow_params p{};
@@ -1284,7 +1291,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     p.negKR = f16_pair(-float(int64_t(K) * db->ge));
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
-    c.narrow_shifted = G == 8 ? 2 : G == 4 ? 3 : G == 2 ? 7 : 1;
+    c.narrow_shifted = G == 8 ? 2 : G == 4 ? 3 : G == 2 ? 7 : G == 1 ? 11 : 1;
     const int per_wave = 16 / G;                                    // a wave takes 16 / G batches at a time
     const int items = (p.nbatches + per_wave - 1) / per_wave;
     int blocks = persistent_blocks(db, items);
@@ -1294,7 +1301,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // everything at or above bound_min is recomputed by the 32-bit kernel.  Used when the threshold is far enough above
     // that slack for the recomputed share to be negligible (option "bound" = 0 never, 1 whenever a build exists); if more
     // than 2 % of the sequences come back it is switched off for this (query length, threshold) and the exact kernel runs
-    used_bound = want_bound && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
+    used_bound = want_bound && G > 1 && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
     // The re-queue list is worked off beside this kernel by a follower on the second stream (sw_kernels.hip
     // swa_requeue_follow_kernel): the head of the list is preset to -1 ("not written yet"), the kernel's last block
     // raises ctl[7].  The follower is launched AFTER the producer, so however the runtime maps the two streams onto
@@ -1312,6 +1319,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       c.narrow_shifted = 8;
       HIP_TRY(G == 2 ? swa_launch_narrow_bound_g2(K, &p, blocks, st) : G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
                      : swa_launch_narrow_bound_g16(K, &p, blocks, st));
+    } else if (G == 1) {
+      HIP_TRY(K <= 24 ? swa_launch_narrow_one_a(K, &p, blocks, st) : swa_launch_narrow_one_b(K, &p, blocks, st));
     } else {
       HIP_TRY(swa_launch_narrow_split(G, K, &p, blocks, st));
     }
@@ -1369,9 +1378,9 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   HIP_TRY(hipEventRecord(db->ev[2], st));
   pd.used_bound = used_bound;
   if (follow) {
-    // the finishing kernel takes what the follower's few waves did not get to (same work-queue head), then both are awaited
+    // the finishing kernel takes what the follower's few waves did not get to (entries not marked taken), then both are awaited
     HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, int(std::min<int64_t>(nids, REQUEUE_CAP)),
-                                    db->ctl.p + 4, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p,
+                                    db->ctl.p + 5, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p,
                                     db->cus * 8, st));
     HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
     pd.dev1 = true;
@@ -1599,6 +1608,7 @@ int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2,
       if (n <= REQUEUE_CAP) { pd.c.wide += n; continue; }
       std::vector<int32_t> list(static_cast<size_t>(n));
       HIP_TRY(hipMemcpy(list.data(), which ? db->ovf_list2.p : db->ovf_list.p, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int32_t& v : list) if (v < -1) v = -2 - v;      // entries a follower had taken
       std::sort(list.begin(), list.end());
       int64_t full = 0;
       const int64_t ql = which ? (qlen_b ? qlen_b : qlen) : (qlen_a ? qlen_a : qlen);
@@ -1989,8 +1999,8 @@ int gather_candidates(swa_db* db, bool two, int32_t tag0, int32_t tag1, int64_t 
   *obvious += int64_t(tl[1]);
   if (pair && pair->own_window) {
     std::memcpy(tl, h + CTL_TALLY_B, sizeof tl);
-    pair->total_b = int64_t(tl[0]);
-    pair->obvious_b = int64_t(tl[1]);
+    pair->total_b += int64_t(tl[0]);                     // += : a streamed database calls this once per part
+    pair->obvious_b += int64_t(tl[1]);
   }
   if (ncand <= db->cand_cap) {
     const swa_cand* rec = reinterpret_cast<const swa_cand*>(db->pin + CTL_INTS * sizeof(int32_t));
@@ -2157,15 +2167,20 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
                                 int64_t minscore, int64_t maxscore, swa_hit_t* hits, int32_t* which, int64_t* nhits,
                                 int64_t* totalhits, int64_t* obvious, swa_counters_t* counters)
 {
-  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
   if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
   *nhits = 0;
   int64_t tot = 0, obv = 0;
   std::vector<Cand> cand;
-  const int rc = search_candidates(db, query1, query2 ? query2 : query1, qlen, keep, minscore, maxscore, 0, 1, cand, &tot,
-                                   &obv, counters);
+  int rc = SWA_OK;
+  if (db && db->streamed) {
+    rc = check_query(db, query1, qlen);
+    if (rc == SWA_OK) rc = check_query(db, query2, qlen);
+    if (rc == SWA_OK) rc = streamed_candidates(db, query1, qlen, keep, minscore, maxscore, cand, &tot, &obv, counters, query2, 1, nullptr);
+  } else {
+    rc = search_candidates(db, query1, query2 ? query2 : query1, qlen, keep, minscore, maxscore, 0, 1, cand, &tot, &obv, counters);
+  }
   if (rc != SWA_OK) return rc;
   if (totalhits) *totalhits = tot;
   if (obvious) *obvious = obv;
@@ -2184,7 +2199,6 @@ extern "C" int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t q
                                     swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2, int64_t* obvious2,
                                     swa_counters_t* counters)
 {
-  if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (keep1 < 0 || keep2 < 0 || (keep1 > 0 && !hits1) || (keep2 > 0 && !hits2) || !nhits1 || !nhits2)
     return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
@@ -2199,8 +2213,15 @@ extern "C" int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t q
   pair.keep_b = keep2;
   int64_t tot = 0, obv = 0;
   std::vector<Cand> cand;
-  const int rc = search_candidates(db, query1, query2, std::max(qlen1, qlen2), keep1, minscore1, maxscore1, 0, 1, cand, &tot, &obv,
-                                   counters, &pair);
+  int rc = SWA_OK;
+  if (db && db->streamed) {
+    rc = check_query(db, query1, qlen1);
+    if (rc == SWA_OK) rc = check_query(db, query2, qlen2);
+    if (rc == SWA_OK) rc = streamed_candidates(db, query1, std::max(qlen1, qlen2), keep1, minscore1, maxscore1, cand, &tot, &obv, counters,
+                                               query2, 1, &pair);
+  } else {
+    rc = search_candidates(db, query1, query2, std::max(qlen1, qlen2), keep1, minscore1, maxscore1, 0, 1, cand, &tot, &obv, counters, &pair);
+  }
   if (rc != SWA_OK) return rc;
   if (totalhits1) *totalhits1 = tot;
   if (obvious1) *obvious1 = obv;

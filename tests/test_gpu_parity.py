@@ -142,7 +142,7 @@ def test_every_rows_per_lane_variant(qlen):
     db.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 8, 4, 2])
+@pytest.mark.parametrize("lanes", [16, 8, 4, 2, 1])
 def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
     """rows per lane K = ceil(qlen / lanes) for every K in 1..48 of all three forms (16 lanes per sequence pair, 8 for
     queries of at most 384 rows, 4 for at most 192): one query per instantiation, at both ends of its window"""
@@ -159,7 +159,7 @@ def test_every_instantiation_of_the_row_shifted_kernel(lanes, monkeypatch):
         for qlen in (lanes * K - lanes + 1, lanes * K):
             q = full[:qlen]
             scores, c = db.search(q)
-            assert c["narrow_rows"] == K and c["narrow_shifted"] == {16: 1, 8: 2, 4: 3, 2: 7}[lanes]
+            assert c["narrow_rows"] == K and c["narrow_shifted"] == {16: 1, 8: 2, 4: 3, 2: 7, 1: 11}[lanes]
             assert np.array_equal(scores, oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)), (K, qlen)
     db.close()
 
@@ -207,7 +207,7 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     assert n > 0
     # all scores are still exact when they are asked for
     scores, c = db.search(q)
-    assert c["narrow_shifted"] in (1, 2, 3, 7) and np.array_equal(scores, want)
+    assert c["narrow_shifted"] in (1, 2, 3, 7, 11) and np.array_equal(scores, want)
     db.close()
 
 
@@ -1383,7 +1383,31 @@ def test_database_larger_than_its_hbm_budget_is_streamed():
                 assert ([(s - 1000, v) for s, v in got[0]], got[1], got[2]) == exp
         with pytest.raises(swipe_amd.SwaError):
             db.search2(q, q)
+        # two different queries per pass over the parts
+        q2 = cases.Q375[::-1][:330].copy()
+        (h1, t1, o1), (h2, t2, o2), _ = db.search_pair_topk(q, q2, keep=(30, 20), minscore=(50, 45))
+        (r1, rt1, ro1), (r2, rt2, ro2), _ = resident.search_pair_topk(q, q2, keep=(30, 20), minscore=(50, 45))
+        assert (h1, t1, o1, h2, t2, o2) == (r1, rt1, ro1, r2, rt2, ro2) and t1 > 0 and t2 > 0
         db.close()
+    resident.close()
+    # a nucleotide database, both strands: parts carry the 4-bit one-sequence-per-row tables
+    tab = synth.residue_table_nucleotide()
+    qn = synth._random_residues(99, 1, 400, tab)
+    qm = blastdb.revcomp_nt16(qn)
+    res, off = swipe_amd.synth_db(3, 30_000, protein=False)
+    res = res.copy()
+    res[off[777]:off[777] + 300] = qn[:300]
+    res[off[20_001]:off[20_001] + 250] = qm[100:350]
+    resident = swipe_amd.Database.from_arrays(res, off, symtype=0)
+    resident.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+    want = resident.search2_topk(qn, qm, keep=50, minscore=25)
+    db = swipe_amd.Database.from_arrays(res, off, symtype=0, hbm_budget=int(19 * (1 << 20)))
+    assert db.info()["hbm_bytes"] < resident.info()["hbm_bytes"]
+    db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+    for rnd in range(2):
+        got = db.search2_topk(qn, qm, keep=50, minscore=25)
+        assert got[:3] == want[:3] and got[0][0][:2] == (777, 300) and (20_001, 250, 1) in got[0]
+    db.close()
     resident.close()
 
 
