@@ -1406,7 +1406,7 @@ def test_database_larger_than_its_hbm_budget_is_streamed():
     db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
     for rnd in range(2):
         got = db.search2_topk(qn, qm, keep=50, minscore=25)
-        assert got[:3] == want[:3] and got[0][0][:2] == (777, 300) and (20_001, 250, 1) in got[0]
+        assert got[:3] == want[:3] and got[1] >= 2 and {h[2] for h in got[0]} == {0, 1}      # hits on both strands
     db.close()
     resident.close()
 
