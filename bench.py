@@ -49,6 +49,8 @@ KERNEL = {0: "swa_narrow_kernel<%d>", 1: "swa_narrow_split_kernel<%d, W, 16>", 2
 def kernel_name(form, rows, qlen):
     """the first-pass kernel as rocprofv3 names it, where the template arguments follow from (form, rows, qlen) alone"""
     if form == 8:                                        # swipe_amd.cpp run_search + sw_cb_kernel.inc cb_waves_for
+        if qlen <= 48:
+            return "swa_one_bound_kernel<%d, W, true> (bound build, one lane per sequence pair)" % rows
         G = 2 if qlen <= 96 else 4 if qlen <= 192 else 8 if qlen <= 384 else 16
         W = 8 if rows <= 5 else 6 if rows <= 10 else 4 if rows <= 20 else 3 if rows <= 29 else 2
         return ("swa_narrow_bound_kernel<%d, %d, %d, 16, false> (bound build of the first pass; sequences at or above the score "

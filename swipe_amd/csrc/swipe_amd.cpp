@@ -31,6 +31,8 @@ int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_one_a(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_one_b(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_one_bound_c(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_one_bound_d(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_dual_bound(int G, int K, const swa_mp_params* p, int cus, hipStream_t st);
@@ -1261,9 +1263,9 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   const int Nb = swa_bound_period();
   const bool want_bound = bound_wanted(db, qlen, bound_min);
   if (want_bound && qlen <= 2 * 48) G = 2;
-  // ONE lane per sequence pair (sw_one_kernel.inc) for exact searches of queries of at most 48 rows: no chain, hence
-  // no hand-overs and no skew (10 aa 5.8 -> TCUPS); top-K searches keep the 2-lane bound build
-  if (!want_bound && qlen <= 48) G = 1;
+  // ONE lane per sequence pair (sw_one_kernel.inc) for queries of at most 48 rows, exact and bound build alike: no
+  // chain, hence no hand-overs and no skew
+  if (qlen <= 48) G = 1;
   if (db->opt.lanes > 0) {
     G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
     while (G < 16 && qlen > G * 48) G *= 2;
@@ -1301,7 +1303,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // everything at or above bound_min is recomputed by the 32-bit kernel.  Used when the threshold is far enough above
     // that slack for the recomputed share to be negligible (option "bound" = 0 never, 1 whenever a build exists); if more
     // than 2 % of the sequences come back it is switched off for this (query length, threshold) and the exact kernel runs
-    used_bound = want_bound && G > 1 && swa_bound_available(G, K) && f16_limit(db, K + Nb) >= 1024;
+    used_bound = want_bound && (G == 1 || swa_bound_available(G, K)) && f16_limit(db, K + Nb) >= 1024;
     // The re-queue list is worked off beside this kernel by a follower on the second stream (sw_kernels.hip
     // swa_requeue_follow_kernel): the head of the list is preset to -1 ("not written yet"), the kernel's last block
     // raises ctl[7].  The follower is launched AFTER the producer, so however the runtime maps the two streams onto
@@ -1317,7 +1319,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
       c.narrow_shifted = 8;
-      HIP_TRY(G == 2 ? swa_launch_narrow_bound_g2(K, &p, blocks, st) : G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
+      HIP_TRY(G == 1 ? (K <= 24 ? swa_launch_one_bound_c(K, &p, blocks, st) : swa_launch_one_bound_d(K, &p, blocks, st))
+                     : G == 2 ? swa_launch_narrow_bound_g2(K, &p, blocks, st) : G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
                      : swa_launch_narrow_bound_g16(K, &p, blocks, st));
     } else if (G == 1) {
       HIP_TRY(K <= 24 ? swa_launch_narrow_one_a(K, &p, blocks, st) : swa_launch_narrow_one_b(K, &p, blocks, st));

@@ -170,12 +170,14 @@ def _expected_topk(scores, keep, minscore, maxscore=1 << 62):
     return [(i, int(scores[i])) for i in kept[:keep]], len(order), int((scores > maxscore).sum())
 
 
-@pytest.mark.parametrize("lanes", [16, 8, 4, 2])
+@pytest.mark.parametrize("lanes", [16, 8, 4, 2, 1, -1])
 def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     """top-K searches may run the bound build of the row-shifted kernel (6.5 instructions per cell pair, result at most
     15 R above the score, everything at or above the threshold recomputed by the 32-bit kernel): every K = 25..48 (58)
     of every chain length (4 lanes from 11, 2 lanes from 5), hits planted at every distance from the threshold, thresholds from "everything comes back"
     to "nothing does", gap extension penalties 1..3 - hit list, totalhits and obvious must equal the exact ones"""
+    other = lanes == -1                                      # the one-lane build in the column order it does not pick by itself
+    lanes = abs(lanes)
     monkeypatch.setenv("SWA_LANES", str(lanes))
     monkeypatch.setenv("SWA_BOUND", "1")
     rtab = synth.residue_table_protein()
@@ -194,10 +196,12 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
     n = 0
-    for K in range({16: 25, 8: 25, 4: 11, 2: 5}[lanes], {16: 58, 8: 48, 4: 48, 2: 48}[lanes] + 1):
+    for K in range({16: 25, 8: 25, 4: 11, 2: 5, 1: 1}[lanes], {16: 58, 8: 48, 4: 48, 2: 48, 1: 48}[lanes] + 1):
         go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         q = full[:lanes * K - (K % lanes)]
+        if other:
+            db.set_option("pipe", 0 if K <= 28 else 1)       # two columns at a time up to 28 rows by default, one beyond
         want = oracle.search_all63(r2, o2, q, Mo, go + ge, ge, threads=THREADS)
         for minscore, maxscore in ((1, 1 << 62), (35, 90), (60, 1 << 62), (100, 300), (400, 1 << 62)):
             hits, tot, obv, c = db.search_topk(q, keep=40, minscore=minscore, maxscore=maxscore)
