@@ -276,6 +276,33 @@ def nucleotide_section(a, rank, local, world, nseq, steps, want_cpu):
                                   f"top-{KEEP} hits by E<=10 (score >= {st.scorethreshold})"},
            "roofline": roof, "valu_roofline": valu, "totalhits": int(tot),
            "hbm_bytes_per_base": round(info["hbm_bytes"] / max(1, nsym), 3), "setup_s": {"load_format": round(t_load, 2)}}
+    if not a.no_verify:
+        # checker leg: all scores of both strands (swa_search2), the merged hit list recomputed on the host over every
+        # sequence, the hits + a seeded sample of sequences recomputed by the oracle's scalar recurrence
+        import oracle
+        s1, s2, _ = db.search2(q, qm)
+        minscore = st.scorethreshold
+        cand = sorted([(int(v), int(i), 0) for i, v in zip(np.flatnonzero(s1 >= minscore), s1[s1 >= minscore])] +
+                      [(int(v), int(i), 1) for i, v in zip(np.flatnonzero(s2 >= minscore), s2[s2 >= minscore])],
+                      key=lambda t: (-t[0], -t[1], t[2]))[:KEEP]
+        bad = int([(i, v, w) for v, i, w in cand] != [tuple(h) for h in hits])
+        bad += int(int((s1 >= minscore).sum()) + int((s2 >= minscore).sum()) != tot)
+        rng = np.random.default_rng(20260929)
+        pick = np.unique(np.concatenate([rng.integers(0, nseq, size=min(max(1, a.verify_sample // 5), nseq)),
+                                         np.array([h[0] for h in hits], dtype=np.int64)]))
+        lens = off[pick + 1] - off[pick]
+        o2 = np.zeros(len(pick) + 1, dtype=np.int64)
+        np.cumsum(lens, out=o2[1:])
+        r2 = np.empty(int(o2[-1]), dtype=np.uint8)
+        for k, i in enumerate(pick):
+            r2[o2[k]:o2[k + 1]] = res[off[i]:off[i + 1]]
+        Mo = oracle.matrix_nucleotide(1, -3)
+        thr = os.cpu_count() or 1
+        bad += int((oracle.search_all63(r2, o2, q, Mo, 7, 2, threads=thr) != s1[pick]).sum())
+        bad += int((oracle.search_all63(r2, o2, qm, Mo, 7, 2, threads=thr) != s2[pick]).sum())
+        if bad:
+            raise SystemExit(f"bench (nucleotide): {bad} mismatches against the oracle")
+        out["verified_vs_oracle"] = int(len(pick))
     if want_cpu:
         try:
             qtext = "".join("-ACMGRSVTWYHKDBN"[int(x)] for x in q)
