@@ -284,7 +284,9 @@ struct swa_db {
            scratch.slots.bytes() + scratch.batches.bytes() + scratch.stream.bytes() + single.slots.bytes() +
            single.batches.bytes() + single.stream.bytes() + single4.slots.bytes() + single4.batches.bytes() +
            single4.stream.bytes() + scores2.bytes() + boundary.bytes() + scores.bytes() +
-           scores64.bytes() + scores64b.bytes() + ovf_list.bytes() + ovf_list2.bytes() + ctl.bytes();
+           scores64.bytes() + scores64b.bytes() + ovf_list.bytes() + ovf_list2.bytes() + ctl.bytes() + view.slots.bytes() +
+           view.batches.bytes() + view.stream.bytes() + wstart.bytes() + wlen.bytes() + wparents.bytes() + wfirst.bytes() +
+           qblock.bytes() + matrix.bytes();
   }
 };
 

@@ -1437,3 +1437,60 @@ def test_bench_shards_one_database_over_two_ranks():
     assert two["config"]["residues_total"] == one["config"]["residues_total"]
     assert abs(two["config"]["residues_rank0"] * 2 - two["config"]["residues_total"]) < 40_000      # balanced by residues
     assert two["verified_vs_oracle"] >= 2000
+
+
+def test_windows_compose_with_subsets_translation_and_streaming():
+    """long sequences cut into windows inside the other ways a shard can be held: with an inclusion subset (excluded long
+    sequences are not windowed at all, included ones are), as six translated frames of a long nucleotide sequence
+    (tblastn), and in a streamed database whose parts each hold a long sequence"""
+    rng = np.random.default_rng(11)
+    rtab = synth.residue_table_protein()
+    q = cases.Q375[:200]
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    res, off = swipe_amd.synth_db(23, 600)
+    seqs = [res[off[i]:off[i + 1]] for i in range(600)]
+    for k in range(3):                                       # three long sequences, each carrying the query somewhere
+        body = rtab[rng.integers(0, len(rtab), 20_000 + 3_000 * k)].astype(np.uint8)
+        at = int(rng.integers(0, len(body) - len(q)))
+        body[at:at + len(q)] = q
+        seqs.insert(200 * k + 7, body)
+    r2, o2 = oracle.pack(seqs)
+    want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    got, _ = db.search(q)
+    assert np.array_equal(got, want)
+    inc = np.ones(len(seqs), dtype=np.uint8)
+    inc[7] = 0                                               # one of the long ones is excluded
+    inc[::5] = 0
+    db.set_inclusion(inc)
+    got, _ = db.search(q)
+    assert np.array_equal(got[inc == 1], want[inc == 1]) and np.all(got[inc == 0] == -1)
+    hits, tot, obv, _ = db.search_topk(q, keep=20, minscore=60)
+    sub = np.where(inc == 1, want, -1)
+    assert (hits, tot, obv) == _expected_topk(sub, 20, 60)
+    db.close()
+    # streamed: two slots, parts of a few hundred sequences
+    sdb = swipe_amd.Database.from_arrays(r2, o2, hbm_budget=int(17.5 * (1 << 20)))
+    sdb.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    got, _ = sdb.search(q)
+    assert np.array_equal(got, want)
+    sdb.close()
+    # tblastn: a 90 kb nucleotide sequence among short ones, six frames each; windows are cut in the translated frames
+    tab = synth.residue_table_nucleotide()
+    nres, noff = swipe_amd.synth_db(3, 300, protein=False)
+    nseqs = [nres[noff[i]:noff[i + 1]] for i in range(300)]
+    nseqs.insert(50, tab[rng.integers(0, len(tab), 90_000)].astype(np.uint8))
+    n2, no2 = oracle.pack(nseqs)
+    tdb = swipe_amd.Database.from_arrays(n2, no2, translate_gencode=1)
+    tdb.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    tdb.set_option("window", 3000)                           # 30 000-residue frames: windowed
+    s_win, _ = tdb.search(q)
+    tdb.set_option("window", 0)
+    s_whole, _ = tdb.search(q)
+    assert np.array_equal(s_win, s_whole) and len(s_win) == 6 * len(nseqs)
+    table = oracle.translate_table(1)
+    for frame in range(6):
+        prot = oracle.translate(nseqs[50], frame // 3, frame % 3, table)
+        assert int(s_win[6 * 50 + frame]) == oracle.fullsw(prot, q, Mo, 12, 1)
+    tdb.close()
