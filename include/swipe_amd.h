@@ -92,7 +92,8 @@ typedef struct {
                             8: bound build of the row-shifted form (swa_search_topk only, see there);
                             9: bound build, one launch per pass (queries > 928 rows);
                             10: bound build of the two-query kernel (non-nucleotide pairs of 129..512 rows);
-                            11: row-shifted form, ONE lane per sequence pair (exact searches of queries of at most 48 rows) */
+                            11: row-shifted form, ONE lane per sequence pair (queries of at most 48 rows);
+                            12: two-query kernel, ONE lane per sequence (at most 48 nucleotide / 32 other rows) */
 } swa_counters_t;
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;

@@ -1,0 +1,182 @@
+// Two queries of equal length against ONE database sequence per LANE (swa_dual_one_kernel<K, W, NRES>): the two-query
+// kernel of sw_mp_kernel.inc for queries short enough to live in a single lane's registers - both strands of a primer
+// or probe, a pair of short frames or of short queries of a file.
+//
+// As in sw_one_kernel.inc there is no chain: no DPP hand-overs, no hand-over FMAs, no residue shift register, no skew
+// to drain per batch - per step only the lane's residue turned into an LDS address.  The profile holds ready-made
+// (query 1, query 2) score pairs, 4 rows per 16-byte unit, one copy per lane position of a DPP row (conflict-free
+// whatever residues the lanes hold); 6.5 instructions per cell pair, rows in software-pipelined order exactly as in
+// swa_dual_kernel.  Data: the pair stream; a wave takes 8 consecutive batches = 64 sequences, lane l works on half l & 1
+// of row (l >> 1) & 3 of batch l >> 3 and reads its 16 columns of a chunk as 32 contiguous bytes (shared with the lane
+// of the other half).  Nucleotide alphabets: up to 48 rows; others: up to 32 (the table of 33 residue codes must leave
+// room for two blocks per CU).
+#include "sw_common.cuh"
+
+template <int K, int W, int NRES>
+__global__ void __launch_bounds__(256, W)
+swa_dual_one_kernel(swa_mp_params p)
+{
+  constexpr int C = (K + 3) / 4;
+  constexpr u32 CS = C * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  {
+    u32* t = (u32*)lds;
+    const int total = (NRES + 1) * C * 16 * 4;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int k = e & 3, c = (e >> 6) % C, d = (e >> 6) / C;
+      const int row = c * 4 + k;
+      const bool live = row < K && row < p.qlen && d < NRES;
+      const float v1 = live && row < (p.qlen_a ? p.qlen_a : p.qlen) ? (float)p.matrix[(d << 5) + p.qseq[row]] : -1.0f;
+      const float v2 = live && row < (p.qlen_b ? p.qlen_b : p.qlen) ? (float)p.matrix[(d << 5) + p.qseq2[row]] : -1.0f;
+      t[e] = float_to_half_bits(v1 + p.gapextend_f) | (float_to_half_bits(v2 + p.gapextend_f) << 16);
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const u32 l16 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (u32)(lane & 15) * 16;
+  const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR);
+  const h2 zero = {0, 0};
+  const u32 PADW = SWA_PAD | (SWA_PAD << 8) | (SWA_PAD << 16) | ((u32)SWA_PAD << 24);
+  const int sh0 = 8 * (lane & 1), sh1 = 16 + sh0;
+
+  for (;;) {
+    int w = 0;
+    if (lane == 0) w = atomicAdd(p.counter, 1);
+    w = __builtin_amdgcn_readfirstlane(w);
+    const int b0 = 8 * w;
+    if (b0 >= p.nbatches) break;
+    const int b = b0 + (lane >> 3);
+    swa_batch bd;
+    bd.offset = 0;
+    bd.steps = 0;
+    if (b < p.nbatches) bd = p.batches[b];
+    int steps = bd.steps;
+#pragma unroll
+    for (int s2 = 8; s2 < 64; s2 <<= 1) { const int o = __shfl_xor(steps, s2); steps = o > steps ? o : steps; }
+    steps = __builtin_amdgcn_readfirstlane(steps);
+    const int mychunks = (bd.steps + 15) >> 4;
+    const uint4* s = (const uint4*)(p.stream + (int64_t)bd.offset * 64 + ((lane >> 1) & 3) * 16);
+
+    h2 H[K], E[K], SR[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { H[r] = as_h2(p.rowc[r + 1]); E[r] = H[r]; SR[r] = H[r]; }
+    uint4 c0 = {PADW, PADW, PADW, PADW}, c1 = c0;
+    if (mychunks > 0) { c0 = s[0]; c1 = s[1]; }
+
+    // one column; RAW = this lane's residue code
+#define SWA_D1_STEP(RAW, ODD)                                                                  \
+    {                                                                                          \
+      const u32 code = (RAW) < (u32)NRES ? (RAW) : (u32)NRES;                                  \
+      const u32 aoff = code * CS + l16;                                                        \
+      h2 F = zero;                                       /* the top edge: H = 0, no gap open */ \
+      u4v nx = *(lds_u4_ptr)(uintptr_t)(aoff);                                                 \
+      h2 a = as_h2(nx.x);                                /* 0 + score of row 0 */              \
+      h2 eprev = zero;                                                                         \
+      _Pragma("unroll") for (int c = 0; c < C; ++c) {                                          \
+        const u4v pa = nx;                                                                     \
+        if (c + 1 < C) nx = *(lds_u4_ptr)(uintptr_t)(aoff + (c + 1) * 256);                    \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                        \
+          const int r = c * 4 + k;                                                             \
+          if (r < K) {                                                                         \
+            const h2 h = pk_max3(a, E[r], F);                                                  \
+            const u32 w1 = k == 0 ? pa.y : k == 1 ? pa.z : k == 2 ? pa.w : nx.x;               \
+            const h2 t = h + negQR;                                                            \
+            const h2 hold = H[r];                                                              \
+            if (r + 1 < K) a = hold + as_h2(w1);                                               \
+            if (r > 0) E[r - 1] = eprev + negR;                                                \
+            if (ODD) SR[r] = pk_max3(SR[r], hold, h);                                          \
+            H[r] = h;                                                                          \
+            F = pk_max(F, t);                                                                  \
+            eprev = pk_max3(E[r], t, as_h2(p.rowc[r + 2]));                                    \
+            if (r == K - 1) E[r] = eprev + negR;                                               \
+          }                                                                                    \
+        }                                                                                      \
+      }                                                                                        \
+    }
+#define SWA_D1_PAIR(WORD) { SWA_D1_STEP(((WORD) >> sh0) & 0xFFu, 0) SWA_D1_STEP(((WORD) >> sh1) & 0xFFu, 1) }
+
+    for (int m = 0; 16 * m < steps; ++m) {
+      const uint4 x0 = c0, x1 = c1;
+      c0 = uint4{PADW, PADW, PADW, PADW};
+      c1 = c0;
+      if (m + 1 < mychunks) { c0 = s[(int64_t)(m + 1) * 8]; c1 = s[(int64_t)(m + 1) * 8 + 1]; }
+      const int n = steps - 16 * m;
+      SWA_D1_PAIR(x0.x)
+      if (n > 2) SWA_D1_PAIR(x0.y)
+      if (n > 4) SWA_D1_PAIR(x0.z)
+      if (n > 6) SWA_D1_PAIR(x0.w)
+      if (n > 8) SWA_D1_PAIR(x1.x)
+      if (n > 10) SWA_D1_PAIR(x1.y)
+      if (n > 12) SWA_D1_PAIR(x1.z)
+      if (n > 14) SWA_D1_PAIR(x1.w)
+    }
+#undef SWA_D1_PAIR
+#undef SWA_D1_STEP
+
+    h2 S = zero;
+#pragma unroll
+    for (int r = 0; r < K; ++r) S = pk_max(S, SR[r] - as_h2(p.rowc[r + 1]));
+    int id = -1, s1 = -1, s2 = -1;
+    if (b < p.nbatches) {
+      id = p.slots[(int64_t)b * SWA_SLOTS + ((lane >> 1) & 3) * 2 + (lane & 1)];
+      s1 = (int)(float)S.x;
+      s2 = (int)(float)S.y;
+      if (id >= 0) { p.scores[id] = s1; p.scores2[id] = s2; }
+    }
+    const bool o1 = id >= 0 && s1 >= p.limit, o2 = id >= 0 && s2 >= p.limit;
+    const u64 m1 = __ballot(o1), m2 = __ballot(o2);
+    const int n1 = __popcll(m1), n2 = __popcll(m2);
+    const u64 below = (1ull << lane) - 1;
+    if (n1) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(p.ovf_count, n1);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (o1) p.ovf_list[base + __popcll(m1 & below)] = id;
+    }
+    if (n2) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(p.ovf_count2, n2);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (o2) p.ovf_list2[base + __popcll(m2 & below)] = id;
+    }
+  }
+}
+
+static constexpr int dual_one_waves_for(int K, int NRES)
+{
+  const int by_regs = K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 29 ? 3 : 2;
+  const int lds = (NRES + 1) * ((K + 3) / 4) * 256;
+  const int by_lds = 160 * 1024 / lds;
+  return by_regs < by_lds ? by_regs : (by_lds < 1 ? 1 : by_lds);
+}
+template <int K, int NRES>
+static hipError_t launch_dual_one(const swa_mp_params& p, int cus, hipStream_t st)
+{
+  constexpr int W = dual_one_waves_for(K, NRES);
+  const size_t lds = (size_t)(NRES + 1) * ((K + 3) / 4) * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)swa_dual_one_kernel<K, W, NRES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int items = (p.nbatches + 7) / 8;
+  int blocks = (items + 3) / 4;
+  if (blocks > cus * W) blocks = cus * W;
+  hipLaunchKernelGGL((swa_dual_one_kernel<K, W, NRES>), dim3(blocks < 1 ? 1 : blocks), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+// rows the one-lane two-query kernel takes: 48 for nucleotide alphabets, 32 otherwise
+extern "C" int swa_dual_one_rows(int nres) { return nres == 16 ? 48 : 32; }
+extern "C" hipError_t swa_launch_dual_one(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st)
+{
+#define SWA_D1(KK) case KK: return nres == 16 ? launch_dual_one<KK, 16>(*p, cus, st) : launch_dual_one<KK, 32>(*p, cus, st);
+#define SWA_D1N(KK) case KK: return nres == 16 ? launch_dual_one<KK, 16>(*p, cus, st) : hipErrorInvalidValue;
+  switch (K) {
+    SWA_D1(1) SWA_D1(2) SWA_D1(3) SWA_D1(4) SWA_D1(5) SWA_D1(6) SWA_D1(7) SWA_D1(8) SWA_D1(9) SWA_D1(10) SWA_D1(11) SWA_D1(12)
+    SWA_D1(13) SWA_D1(14) SWA_D1(15) SWA_D1(16) SWA_D1(17) SWA_D1(18) SWA_D1(19) SWA_D1(20) SWA_D1(21) SWA_D1(22) SWA_D1(23) SWA_D1(24)
+    SWA_D1(25) SWA_D1(26) SWA_D1(27) SWA_D1(28) SWA_D1(29) SWA_D1(30) SWA_D1(31) SWA_D1(32)
+    SWA_D1N(33) SWA_D1N(34) SWA_D1N(35) SWA_D1N(36) SWA_D1N(37) SWA_D1N(38) SWA_D1N(39) SWA_D1N(40)
+    SWA_D1N(41) SWA_D1N(42) SWA_D1N(43) SWA_D1N(44) SWA_D1N(45) SWA_D1N(46) SWA_D1N(47) SWA_D1N(48)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_D1
+#undef SWA_D1N
+}

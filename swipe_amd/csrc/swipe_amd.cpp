@@ -60,6 +60,8 @@ hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const i
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
 int swa_dual_rows_for(int qlen, int nres, int G);
 hipError_t swa_launch_dual(int K, int nres, int G, const swa_mp_params* p, int cus, hipStream_t st);
+hipError_t swa_launch_dual_one(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
+int swa_dual_one_rows(int nres);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const swa_seqs* sq, const int32_t* slots, const swa_batch* batches, int nbatches, void* stream,
                              int nibbles, hipStream_t st);
@@ -1456,13 +1458,16 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
   const bool dual_mp = db->opt.dual_mp == 1;
   // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
-  int Gd = qlen <= 2 * 32 ? 2 : qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
+  // ... and ONE lane per sequence (sw_one_dual.hip) for queries of at most 48 nucleotide / 32 other rows: no chain at all
+  const int64_t one_rows = swa_dual_one_rows(nres);
+  int Gd = qlen <= one_rows ? 1 : qlen <= 2 * 32 ? 2 : qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
   if (db->opt.lanes > 0) {
-    Gd = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : 2;
-    while (Gd < 16 && qlen > Gd * 32) Gd *= 2;
+    Gd = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
+    if (Gd == 1 && qlen > one_rows) Gd = 2;
+    while (Gd > 1 && Gd < 16 && qlen > Gd * 32) Gd *= 2;
   }
-  if (Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
-  int Kd = dual_mp ? 0 : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
+  if (Gd > 1 && Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
+  int Kd = dual_mp ? 0 : Gd == 1 ? int(qlen) : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
   if (db->opt.dual_kmax > 0 && Kd > db->opt.dual_kmax) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
@@ -1502,16 +1507,18 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     for (int i = 0; i <= Kd + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
     // bound build (sw_cb_dual.hip) under the same rule as in run_search
     const int Nb = swa_bound_period();
-    used_bound = bound_wanted(db, qlen, bound_min) && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024;
+    used_bound = Gd > 1 && bound_wanted(db, qlen, bound_min) && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024;
     if (used_bound) {
       p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
       for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
       HIP_TRY(swa_launch_dual_bound(Gd, Kd, &p, db->cus, st));
+    } else if (Gd == 1) {
+      HIP_TRY(swa_launch_dual_one(Kd, nres, &p, db->cus, st));
     } else {
       HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
     }
     c.narrow_rows = Kd;
-    c.narrow_shifted = used_bound ? 10 : 4;              // single-pass dual kernel / its bound build
+    c.narrow_shifted = used_bound ? 10 : Gd == 1 ? 12 : 4;   // single-pass dual kernel / its bound build / one lane per sequence
     c.narrow = db->nseq;
     listed = true;
   } else if (f16_applicable(db) && !dual_mp && Gd == 16 && f16_limit(db, dual_pass_rows(qlen, nres)) >= 1024) {

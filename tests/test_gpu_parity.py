@@ -538,7 +538,7 @@ def test_dual_query_kernel_both_strands(qlen):
     db.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 8, 4, 2])
+@pytest.mark.parametrize("lanes", [16, 8, 4, 2, 1])
 @pytest.mark.parametrize("protein", [False, True])
 def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monkeypatch):
     """two queries of equal length in one pass, K = ceil(qlen / lanes): every K of the nucleotide build (1..63 with
@@ -558,12 +558,12 @@ def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monk
     else:
         db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
         Mo, goe, ge = oracle.matrix_nucleotide(1, -3), 7, 2
-    for K in range(1, (32 if (protein or lanes < 16) else 63) + 1):
+    for K in range(1, (48 if (lanes == 1 and not protein) else 32 if (protein or lanes < 16) else 63) + 1):
         qlen = lanes * K - (K % lanes)
         q1 = full[:qlen]
         q2 = q1[::-1].copy() if protein else blastdb.revcomp_nt16(q1)
         s1, s2, c = db.search2(q1, q2)
-        assert c["narrow_rows"] == K and c["narrow_shifted"] == 4
+        assert c["narrow_rows"] == K and c["narrow_shifted"] == (12 if lanes == 1 else 4)   # 12: one lane per sequence
         assert np.array_equal(s1, oracle.search_all63(r2, o2, q1, Mo, goe, ge, threads=THREADS)), K
         assert np.array_equal(s2, oracle.search_all63(r2, o2, q2, Mo, goe, ge, threads=THREADS)), K
     db.set_option("dual_mp", 1)
