@@ -43,6 +43,11 @@ def one_config(rng, threads, max_qlen=2500, max_nseq=3000):
         mut = rng.random(len(piece)) < rng.random() * 0.3
         piece[mut] = tab[rng.integers(0, len(tab), int(mut.sum()))]
         seqs.append(np.concatenate([seqs[k][:20], piece, seqs[k + 1][:int(rng.integers(0, 30))]]))
+    if rng.random() < 0.3:                                  # a long sequence carrying the query: searched as windows
+        body = tab[rng.integers(0, len(tab), int(rng.integers(6000, 30000)))].astype(np.uint8)
+        at = int(rng.integers(0, len(body) - qlen))
+        body[at:at + qlen] = q
+        seqs.append(body)
     r2, o2 = oracle.pack(seqs)
     db = swipe_amd.Database.from_arrays(r2, o2, symtype=1 if protein else 0)
     db.set_scoring(M, go, ge)
@@ -71,6 +76,16 @@ def one_config(rng, threads, max_qlen=2500, max_nseq=3000):
                     [(int(s), i, 1) for i, s in enumerate(want2) if lo <= s <= hi], key=lambda t: (-t[0], -t[1], t[2]))[:keep]
         ok4 = ok4 and h2 == [(i, s, w) for s, i, w in e2] and t2 == int((want >= lo).sum() + (want2 >= lo).sum())
     db.set_option("bound", None)
+    # two DIFFERENT queries in one pass, each with its own window
+    if protein:
+        q3 = synth._random_residues(int(rng.integers(1 << 30)), 1, max(1, int(qlen * rng.uniform(0.75, 1.0))), tab)
+        want3 = oracle.search_all63(r2, o2, q3, Mo, go + ge, ge, threads=threads)
+        lo1, lo3 = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+        (h1, t1, o1), (h3, t3, o3), _ = db.search_pair_topk(q, q3, keep=(25, 40), minscore=(lo1, lo3))
+        def exp(w, keep, lo):
+            order = sorted((i for i in range(len(w)) if w[i] >= lo), key=lambda i: (-int(w[i]), -i))
+            return [(i, int(w[i])) for i in order[:keep]], len(order)
+        ok4 = ok4 and (h1, t1) == exp(want, 25, lo1) and (h3, t3) == exp(want3, 40, lo3)
     inc = (rng.random(len(seqs)) < 0.6).astype(np.uint8)
     db.set_inclusion(inc)
     g3, _ = db.search(q)
