@@ -19,6 +19,10 @@ if stats:
     with open(os.path.join(out, "r02_kernel_stats_bench.csv"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-cold\n")
         f.write("# (protein headline 1 + 3 steps, exact first pass 1 + 3 steps, nucleotide secondary 1 + 3 steps; durations in ns)\n")
+        f.write("# Calls = 1 untimed warm-up + 3 timed steps: MinNs is the steady-state launch (bench.py reports the mean of the timed ones);\n")
+        f.write("# the first launch of a kernel includes its code-object load (swa_narrow_split_kernel: 144.6 ms, then 127.3 x 3).\n")
+        f.write("# swa_requeue_follow_kernel runs BESIDE the first-pass kernel on a second stream (DESIGN.md 4.10): its duration is its\n")
+        f.write("# lifetime = the producer's, not work; swa_requeue_wave_kernel is the finishing kernel after it.\n")
         cols = list(rows[0].keys())
         f.write(",".join(cols) + "\n")
         for r in rows[:14]:
