@@ -829,12 +829,16 @@ template <int K>
 __global__ void __launch_bounds__(64)
 swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
                           const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
-                          int* __restrict__ scores)
+                          int* __restrict__ scores, int32_t* list_b, int32_t* __restrict__ work_b,
+                          const uint8_t* __restrict__ qseq_b, int qlen_b, int* __restrict__ scores_b)
 {
   __shared__ int M[1024];
   __shared__ uint8_t ring[128];
   __shared__ int next, leave;
   const int g = threadIdx.x;
+  if (list_b && (blockIdx.x & 1)) {                        // two-query searches: odd blocks follow the second query's list
+    list = list_b; work = work_b; qseq = qseq_b; qlen = qlen_b; scores = scores_b;
+  }
   for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
   bool started = false;                                    // lane 0: the producer has been seen on the device
   for (;;) {
@@ -1176,11 +1180,13 @@ extern "C" hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t*
 }
 extern "C" hipError_t swa_launch_requeue_follow(const swa_seqs* sq, int32_t* list, int cap,
                                                 int32_t* work, const int32_t* done, const uint8_t* qseq, int qlen,
-                                                const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
+                                                const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st,
+                                                int32_t* list_b, int32_t* work_b, const uint8_t* qseq_b, int qlen_b, int* scores_b)
 {
+  if (list_b) blocks *= 2;
 #define SWA_RQF(KK) hipLaunchKernelGGL((swa_requeue_follow_kernel<KK>), dim3(blocks), dim3(64), 0, st, *sq, list, cap, \
-                                       work, done, qseq, qlen, matrix, Q, R, scores)
-  switch (swa_endpoints_rows_for(qlen)) {
+                                       work, done, qseq, qlen, matrix, Q, R, scores, list_b, work_b, qseq_b, qlen_b, scores_b)
+  switch (swa_endpoints_rows_for(qlen > qlen_b ? qlen : qlen_b)) {
     case 2: SWA_RQF(2); break;
     case 4: SWA_RQF(4); break;
     case 6: SWA_RQF(6); break;

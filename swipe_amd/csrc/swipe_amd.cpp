@@ -73,7 +73,8 @@ hipError_t swa_launch_fold(int* scores, long long* scores64, const int32_t* pare
                            hipStream_t st);
 hipError_t swa_launch_requeue_follow(const swa_seqs* sq, int32_t* list, int cap, int32_t* work,
                                      const int32_t* done, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
-                                     int* scores, int blocks, hipStream_t st);
+                                     int* scores, int blocks, hipStream_t st, int32_t* list_b, int32_t* work_b,
+                                     const uint8_t* qseq_b, int qlen_b, int* scores_b);
 hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t* list, const int32_t* count,
                                    int cap, int32_t* work, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                    int* scores, int blocks, hipStream_t st);
@@ -1312,7 +1313,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // swa_requeue_follow_kernel): the head of the list is preset to -1 ("not written yet"), the kernel's last block
     // raises ctl[7].  The follower is launched AFTER the producer, so however the runtime maps the two streams onto
     // hardware queues it can never wait for a kernel that has not been submitted.
-    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0;
+    // Only beside kernels that leave it register room: the bound builds (2 K + 40 registers) and exact builds of at most 32
+    // rows per lane.  An exact build of 47 rows fills the register file with its two waves per SIMD; its list is the handful
+    // of sequences that leave the f16 range, which the device-driven kernel after it takes in microseconds
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && (used_bound || K <= 32 || db->opt.requeue_follow > 1);
     if (follow) {
       HIP_TRY(hipMemsetAsync(db->ovf_list.p, 0xFF, size_t(std::min<int64_t>(nids, REQUEUE_CAP)) * sizeof(int32_t), st));
       HIP_TRY(hipEventRecord(db->ev2[0], st));
@@ -1338,7 +1342,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       const int fblocks = db->opt.requeue_follow > 1 ? int(db->opt.requeue_follow) : std::max(1, db->cus / 2);
       HIP_TRY(swa_launch_requeue_follow(&sq, db->ovf_list.p, int(std::min<int64_t>(nids, REQUEUE_CAP)), db->ctl.p + 4,
                                         db->ctl.p + CTL_DONE, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge),
-                                        db->scores.p, fblocks, db->stream2));
+                                        db->scores.p, fblocks, db->stream2, nullptr, nullptr, nullptr, 0, nullptr));
       HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
     }
     c.narrow = db->nseq;
@@ -1451,7 +1455,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     return SWA_OK;
   };                 // nucleotide shard: 16-lane chains stream 4 bits per base
   bool listed = false;                                   // the first pass left re-queue lists on the device
-  bool used_bound = false;
+  bool used_bound = false, follow = false;
   HIP_TRY(hipEventRecord(db->ev[1], st));
   // single pass with the whole query in registers when it fits (nucleotide alphabets: 1008 rows, others 512);
   // option "dual_mp" = 1 forces the multi-pass kernel (A/B, tests)
@@ -1508,6 +1512,20 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     // bound build (sw_cb_dual.hip) under the same rule as in run_search
     const int Nb = swa_bound_period();
     used_bound = Gd > 1 && bound_wanted(db, qlen, bound_min) && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024;
+    // the re-queue follower beside the kernel, as in run_search: one grid, odd blocks on the second query's list
+    // ... where the kernel leaves register room for its waves: the bound build (2 K + 40 registers) and exact builds of at most
+    // 32 rows per lane.  Beside the 63-row nucleotide kernel (two waves x 256 registers) a follower that lands on a SIMD first
+    // keeps a producer wave out for the whole pass: measured 603 -> 612 ms for the nucleotide bench, so it runs after it there
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && Kd <= 32;
+    const int64_t nids2 = db->nseq + (windows ? db->nwin : 0);
+    if (follow) {
+      const size_t head = size_t(std::min<int64_t>(nids2, REQUEUE_CAP)) * sizeof(int32_t);
+      HIP_TRY(hipMemsetAsync(db->ovf_list.p, 0xFF, head, st));
+      HIP_TRY(hipMemsetAsync(db->ovf_list2.p, 0xFF, head, st));
+      HIP_TRY(hipEventRecord(db->ev2[0], st));
+      p.finished = db->ctl.p + CTL_FINISHED;
+      p.done = db->ctl.p + CTL_DONE;
+    }
     if (used_bound) {
       p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
       for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
@@ -1516,6 +1534,16 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
       HIP_TRY(swa_launch_dual_one(Kd, nres, &p, db->cus, st));
     } else {
       HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
+    }
+    if (follow) {
+      const swa_seqs sqf = db->seqs();
+      const int fblocks = db->opt.requeue_follow > 1 ? int(db->opt.requeue_follow) : std::max(1, db->cus / 2);
+      HIP_TRY(hipStreamWaitEvent(db->stream2, db->ev2[0], 0));
+      HIP_TRY(swa_launch_requeue_follow(&sqf, db->ovf_list.p, int(std::min<int64_t>(nids2, REQUEUE_CAP)), db->ctl.p + 4,
+                                        db->ctl.p + CTL_DONE, db->qseq_p, int(qa), db->matrix.p, int(db->goe), int(db->ge),
+                                        db->scores.p, fblocks, db->stream2, db->ovf_list2.p, db->ctl.p + 6, db->qseq2_p, int(qb),
+                                        db->scores2.p));
+      HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
     }
     c.narrow_rows = Kd;
     c.narrow_shifted = used_bound ? 10 : Gd == 1 ? 12 : 4;   // single-pass dual kernel / its bound build / one lane per sequence
@@ -1564,7 +1592,16 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   pd.used_bound = used_bound;
   if (!listed) { rc = reserve2(false); if (rc != SWA_OK) return rc; }
   const swa_seqs sq = db->seqs();
-  if (listed && device_requeue_ok(db, qlen)) {
+  if (follow) {
+    // finishing kernels (entries no follower took), then the follower is awaited
+    const int cap2 = int(std::min<int64_t>(db->nseq + (windows ? db->nwin : 0), REQUEUE_CAP));
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, cap2, db->ctl.p + 5, db->qseq_p, int(qa), db->matrix.p,
+                                    int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
+    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list2.p, db->ctl.p + 3, cap2, db->ctl.p + 7, db->qseq2_p, int(qb), db->matrix.p,
+                                    int(db->goe), int(db->ge), db->scores2.p, db->cus * 8, st));
+    HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
+    pd.dev1 = pd.dev2 = true;
+  } else if (listed && device_requeue_ok(db, qlen)) {
     HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
                                     db->qseq_p, int(qa), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
     HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list2.p, db->ctl.p + 3, REQUEUE_CAP, db->ctl.p + 5,
