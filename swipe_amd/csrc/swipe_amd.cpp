@@ -1261,8 +1261,9 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   HIP_TRY(hipEventRecord(db->ev[1], st));
   // G = 2 (up to 40 rows), 4 (up to 192), 8 (up to 384) or 16 (up to 928) lanes per sequence pair, K = ceil(qlen / G)
   // rows per lane (option "lanes" = 2 / 4 / 8 / 16 picks the chain length if the query fits it: A/B runs and tests)
-  // (2 lanes: measured ahead of 4 up to 40 rows - 10 aa 4.5 -> 5.7, 30 aa 7.3 -> 7.9 TCUPS - and level or behind beyond)
-  int G = qlen <= 40 ? 2 : qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
+  // (2 lanes: measured ahead of 4 up to 40 rows - 10 aa 4.5 -> 5.7, 30 aa 7.3 -> 7.9 TCUPS; level at 50..80 rows, and
+  // ahead again where 4 lanes would leave K at 21..24: 88 aa 8.61 -> 8.89, 96 aa 8.96 -> 9.34 TCUPS exact)
+  int G = qlen <= 40 || (qlen > 80 && qlen <= 2 * 48) ? 2 : qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
   // Bound build (top-K searches, see below): wanted when the threshold is far enough above its slack.  It keeps two
   // values per row instead of three, and with them 2-lane chains stay ahead of 4 lanes up to 96 rows (+2..8 %)
   const int Nb = swa_bound_period();
