@@ -88,7 +88,7 @@ typedef struct {
                             per sequence pair (queries of at most 928 / 384 / 192 rows); 4: single-pass two-query kernel;
                             5: row-shifted form, one launch per pass of 16 x narrow_rows query rows (queries > 928 rows);
                             6: two-query kernel, one launch per pass (queries > 1008 nucleotide / 512 other rows);
-                            7: row-shifted form with 2 lanes per sequence pair (queries of at most 40 rows);
+                            7: row-shifted form with 2 lanes per sequence pair (queries of 81..96 rows; at most 96 with lanes=2);
                             8: bound build of the row-shifted form (swa_search_topk only, see there);
                             9: bound build, one launch per pass (queries > 928 rows);
                             10: bound build of the two-query kernel (non-nucleotide pairs of 129..512 rows);
