@@ -33,6 +33,7 @@ hipError_t swa_launch_narrow_one_a(int K, const swa_narrow_params* p, int blocks
 hipError_t swa_launch_narrow_one_b(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_one_bound_c(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_one_bound_d(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_one_bound_e(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_dual_bound(int G, int K, const swa_mp_params* p, int cus, hipStream_t st);
@@ -996,6 +997,7 @@ int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, h
 constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] blocks finished | [32] done flag (polled)
 constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
+constexpr int ONE_BOUND_ROWS = 60;          // longest query of the one-lane bound build (sw_one_e.hip; rowc[] ends at K + period + 2 <= 80)
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
 
@@ -1271,10 +1273,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   if (want_bound && qlen <= 2 * 48) G = 2;
   // ONE lane per sequence pair (sw_one_kernel.inc) for queries of at most 48 rows, exact and bound build alike: no
   // chain, hence no hand-overs and no skew
-  if (qlen <= 48) G = 1;
+  // (the bound build keeps 2 K state registers, not 3 K: its one-lane form reaches 60 rows at two waves per SIMD)
+  const bool one_bound_long = want_bound && qlen > 48 && qlen <= ONE_BOUND_ROWS && f16_limit(db, int(qlen) + Nb) >= 1024;
+  if (qlen <= 48 || one_bound_long) G = 1;
   if (db->opt.lanes > 0) {
     G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
-    while (G < 16 && qlen > G * 48) G *= 2;
+    while (G < 16 && qlen > G * 48 && !(G == 1 && one_bound_long)) G *= 2;
   }
   if (G > 1 && G < 16 && !short_chains_safe(db, qlen) && qlen <= 16 * 58) G = 16;
   const int Kg = G == 1 ? int(qlen) : swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
@@ -1328,7 +1332,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       p.limit = int32_t(std::min<int64_t>(f16_limit(db, K + Nb), bound_min));
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
       c.narrow_shifted = 8;
-      HIP_TRY(G == 1 ? (K <= 24 ? swa_launch_one_bound_c(K, &p, blocks, st) : swa_launch_one_bound_d(K, &p, blocks, st))
+      HIP_TRY(G == 1 ? (K <= 24 ? swa_launch_one_bound_c(K, &p, blocks, st) : K <= 48 ? swa_launch_one_bound_d(K, &p, blocks, st) : swa_launch_one_bound_e(K, &p, blocks, st))
                      : G == 2 ? swa_launch_narrow_bound_g2(K, &p, blocks, st) : G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
                      : swa_launch_narrow_bound_g16(K, &p, blocks, st));
     } else if (G == 1) {

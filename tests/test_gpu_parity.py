@@ -196,8 +196,8 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
     n = 0
-    for K in range({16: 25, 8: 25, 4: 11, 2: 5, 1: 1}[lanes], {16: 58, 8: 48, 4: 48, 2: 48, 1: 48}[lanes] + 1):
-        go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
+    for K in range({16: 25, 8: 25, 4: 11, 2: 5, 1: 1}[lanes], {16: 58, 8: 48, 4: 48, 2: 48, 1: 48 if other else 60}[lanes] + 1):
+        go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]       # (one lane: 49..60 rows exist as the bound build only)
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         q = full[:lanes * K - (K % lanes)]
         if other:
@@ -212,6 +212,26 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     # all scores are still exact when they are asked for
     scores, c = db.search(q)
     assert c["narrow_shifted"] in (1, 2, 3, 7, 11) and np.array_equal(scores, want)
+    db.close()
+
+
+def test_one_lane_bound_build_is_the_default_up_to_60_rows():
+    """top-K searches of 49..60-row queries take the one-lane bound build by themselves (no option set), 61 rows and
+    exact searches of the same queries go to chains; same hits either way"""
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(5, 1, 80, rtab)
+    res, off = swipe_amd.synth_db(8, 3000, query=full)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    for qlen, form, rows in ((49, 8, 49), (60, 8, 60), (61, 8, 31)):
+        q = full[:qlen]
+        want = oracle.search_all63(res, off, q, Mo, 12, 1, threads=THREADS)
+        hits, tot, obv, c = db.search_topk(q, keep=30, minscore=70)
+        assert (c["narrow_shifted"], c["narrow_rows"]) == (form, rows), c
+        assert (hits, tot, obv) == _expected_topk(want, 30, 70)
+        scores, c = db.search(q)
+        assert c["narrow_shifted"] == 3 and np.array_equal(scores, want)
     db.close()
 
 
