@@ -512,6 +512,28 @@ def test_properties_at_scale():
     db.close()
 
 
+def test_all_scores_of_a_100k_slice_of_the_bench_database():
+    """BASELINE config 3: EVERY score of a 100 000-sequence slice of the bench's database (seed 1, planted homologs, the
+    375-aa query) against the scalar 63-bit oracle - and every sequence the reference would escalate (score >= 117 to 16
+    bits, search.cc thresholds via oracle.score_limits) is among them with its exact score, whatever width ran here (packed f16 up to ~2 000, 32 bits beyond)"""
+    q = cases.Q375
+    n = 100_000
+    res, off = swipe_amd.synth_db(1, n, query=q)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    want = oracle.search_all63(res, off, q, Mo, 12, 1, threads=THREADS)
+    got, c = db.search(q)
+    assert np.array_equal(got, want)
+    lim7 = oracle.score_limits(Mo)[2]                      # 117: matrices.cc:574-578
+    assert lim7 == 117 and int((want >= lim7).sum()) > 0
+    # the same through the top-K entry point with the bound build: list, totalhits, obvious
+    hits, tot, obv, c2 = db.search_topk(q, keep=250, minscore=int(lim7))
+    assert c2["narrow_shifted"] == 8
+    assert (hits, tot, obv) == _expected_topk(want, 250, int(lim7))
+    db.close()
+
+
 def test_permissive_threshold_takes_the_histogram_path():
     """minscore 1 on 1.3 M short sequences: more candidates than the device compaction buffer holds, so the top-K floor
     comes from the host-side histogram; list, totalhits and the obvious count must still be exact"""
