@@ -129,9 +129,15 @@ class Database:
         self._h = handle
 
     @classmethod
-    def open(cls, basename: str, *, symtype: int = 1, device: int = 0, first_seqno: int = 0, last_seqno: int = -1):
+    def open(cls, basename: str, *, symtype: int = 1, device: int = 0, first_seqno: int = 0, last_seqno: int = -1,
+             hbm_budget: int = 0):
+        """hbm_budget > 0 (bytes): volumes that may not be resident are streamed (swa_db_open_streamed, see from_arrays)."""
         h = C.c_void_p()
-        _check(_lib.load().swa_db_open(os.fsencode(basename), symtype, device, first_seqno, last_seqno, C.byref(h)))
+        if hbm_budget > 0:
+            _check(_lib.load().swa_db_open_streamed(os.fsencode(basename), symtype, device, first_seqno, last_seqno,
+                                                    hbm_budget, C.byref(h)))
+        else:
+            _check(_lib.load().swa_db_open(os.fsencode(basename), symtype, device, first_seqno, last_seqno, C.byref(h)))
         return cls(h)
 
     @classmethod

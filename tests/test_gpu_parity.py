@@ -1400,6 +1400,31 @@ def test_two_different_queries_in_one_pass(lens):
     db.close()
 
 
+def test_blast_volumes_opened_with_an_hbm_budget_are_streamed(tmp_path):
+    """swa_db_open_streamed: two BLAST v4 volumes behind an alias, a slice of them opened with a budget below what it
+    needs resident - same hits, counts and scores as swa_db_open of the same slice"""
+    q = cases.Q375
+    res, off = swipe_amd.synth_db(5, 40_000, query=q)
+    cut = 22_000
+    swipe_amd.write_blastdb(str(tmp_path / "v0"), res[:off[cut]], off[:cut + 1], first_id=0)
+    swipe_amd.write_blastdb(str(tmp_path / "v1"), res[off[cut]:], off[cut:] - off[cut], first_id=cut)
+    blastdb.write_alias(str(tmp_path / "both"), [str(tmp_path / "v0"), str(tmp_path / "v1")])
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    for first, last in ((0, -1), (3_000, 36_999)):
+        resident = swipe_amd.Database.open(str(tmp_path / "both"), first_seqno=first, last_seqno=last)
+        streamed = swipe_amd.Database.open(str(tmp_path / "both"), first_seqno=first, last_seqno=last, hbm_budget=20 << 20)
+        assert streamed.info()["hbm_bytes"] < 0.8 * resident.info()["hbm_bytes"]
+        assert streamed.info()["seqcount"] == resident.info()["seqcount"]
+        for db in (resident, streamed):
+            db.set_scoring(M, 11, 1)
+        assert np.array_equal(resident.search(q)[0], streamed.search(q)[0])
+        for minscore in (45, 80):
+            a, b = resident.search_topk(q, keep=100, minscore=minscore), streamed.search_topk(q, keep=100, minscore=minscore)
+            assert a[:3] == b[:3] and a[1] > 0
+        resident.close()
+        streamed.close()
+
+
 def test_database_larger_than_its_hbm_budget_is_streamed():
     """a shard that may use less device memory than its resident form needs stays in page-locked host memory and is
     walked through two device slots, part by part, double-buffered: same scores, hit lists and counts as the resident
