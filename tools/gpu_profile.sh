@@ -10,7 +10,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- 
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_ANY" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc$i -- $CMD > $O/bench_under_pmc$i.json 2> $O/pmc$i.err
+  timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc$i -- $CMD > $O/bench_under_pmc$i.json 2> $O/pmc$i.err
 done
 find $O -name "*.csv" | head -40
 du -sh $O

@@ -18,9 +18,9 @@ if stats:
         rows.append(r)
     with open(os.path.join(out, "r02_kernel_stats_bench.csv"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-cold\n")
-        f.write("# (protein headline 1 + 3 steps, exact first pass 1 + 3 steps, nucleotide secondary 1 + 3 steps; durations in ns)\n")
-        f.write("# Calls = 1 untimed warm-up + 3 timed steps: MinNs is the steady-state launch (bench.py reports the mean of the timed ones);\n")
-        f.write("# the first launch of a kernel includes its code-object load (swa_narrow_split_kernel: 144.6 ms, then 127.3 x 3).\n")
+        f.write("# (protein headline 1 + 3 steps, exact first pass 1 + 3 steps, nucleotide secondary 1 + 3 steps, pair section: two 375-aa queries\n")
+        f.write("# per pass = swa_dual_bound_kernel 1 + 3 steps, then each of the two alone through swa_narrow_bound_kernel; durations in ns)\n")
+        f.write("# Calls = 1 untimed warm-up + 3 timed steps: bench.py reports the mean of the timed ones (AverageNs within 0.3 % of it).\n")
         f.write("# swa_requeue_follow_kernel runs BESIDE the first-pass kernel on a second stream (DESIGN.md 4.10): its duration is its\n")
         f.write("# lifetime = the producer's, not work; swa_requeue_wave_kernel is the finishing kernel after it.\n")
         cols = list(rows[0].keys())
