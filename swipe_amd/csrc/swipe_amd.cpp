@@ -1477,6 +1477,14 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   }
   if (Gd > 1 && Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
   int Kd = dual_mp ? 0 : Gd == 1 ? int(qlen) : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
+  // Pairs of 257..384-row queries whose search takes the bound build: 8-lane chains of 33..48 rows (sw_cb_dual_long.hip)
+  // instead of 16 lanes x 17..24 - half the hand-overs per row and half the skew.  (The exact two-query kernel has no such
+  // build - three state registers per row - so whatever switches the bound build off falls back to 16 lanes.)
+  if (!dual_mp && Gd == 16 && nres == 32 && qlen > 8 * 32 && qlen <= 8 * 48 && (db->opt.lanes == 0 || db->opt.lanes == 8) &&
+      (db->opt.dual_kmax == 0 || db->opt.dual_kmax >= 48) && bound_wanted(db, qlen, bound_min) && short_chains_safe(db, qlen)) {
+    const int K8 = int((qlen + 7) / 8);
+    if (swa_dual_bound_available(8, K8, nres) && f16_limit(db, K8 + swa_bound_period()) >= 1024) { Gd = 8; Kd = K8; }
+  }
   if (db->opt.dual_kmax > 0 && Kd > db->opt.dual_kmax) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
@@ -1521,7 +1529,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     // ... where the kernel leaves register room for its waves: the bound build (2 K + 40 registers) and exact builds of at most
     // 32 rows per lane.  Beside the 63-row nucleotide kernel (two waves x 256 registers) a follower that lands on a SIMD first
     // keeps a producer wave out for the whole pass: measured 603 -> 612 ms for the nucleotide bench, so it runs after it there
-    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && Kd <= 32;
+    // (the 33..48-row bound build: 205 registers x two waves leave room, like the one-query bound build's 219)
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && (Kd <= 32 || (used_bound && Gd == 8));
     const int64_t nids2 = db->nseq + (windows ? db->nwin : 0);
     if (follow) {
       const size_t head = size_t(std::min<int64_t>(nids2, REQUEUE_CAP)) * sizeof(int32_t);

@@ -279,7 +279,7 @@ def test_bound_build_of_the_two_query_kernel(lanes, monkeypatch):
     r2, o2 = oracle.pack(seqs)
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
-    for K in range(17, 33):
+    for K in range(17, 49 if lanes == 8 else 33):            # 8-lane chains: 33..48 rows too (sw_cb_dual_long.hip)
         go, ge = ((11, 1), (10, 2))[K % 2]
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         qlen = lanes * K - (K % lanes)
