@@ -201,6 +201,8 @@ SWA_API void swa_db_close(swa_db* db);
                       the overlap is the longest span a positive-scoring alignment can have): -1 auto, 0 never,
                       n > 0 every sequence longer than n
      window_step      distance between window starts; 0 = from the query length and scoring system
+     long_lanes       0: the bound build's 2-, 4- and 8-lane chains stop at 48 rows per lane like the exact build's
+                      (default 1: up to 62 rows, i.e. queries of 97..124 / 193..248 / 385..496 rows on half the lanes)
      endpoints_thread 1 ("thread"): one-thread 64-bit end-point kernel; 0 ("wave")
    A new handle takes its initial values from the environment variables SWA_<KEY> ONCE, at creation; the search path
    never reads the environment.  Unknown keys and unparsable values return SWA_EINVAL. */

@@ -17,8 +17,8 @@ extern "C" int swa_bound_period(void) { return SWA_CB_PERIOD; }
 // 1 if there is a bound build for chains of G lanes with K rows each
 extern "C" int swa_bound_available(int G, int K)
 {
-  if (G == 2) return K >= 5 && K <= 48;
-  if (G == 4) return K >= 11 && K <= 48;
-  if (G == 8) return K >= SWA_CB_KMIN && K <= 48;
+  if (G == 2) return K >= 5 && K <= SWA_CB_KLONG;          // 49..62: sw_cb_long2/4/8.hip
+  if (G == 4) return K >= 11 && K <= SWA_CB_KLONG;
+  if (G == 8) return K >= SWA_CB_KMIN && K <= SWA_CB_KLONG;
   return G == 16 && K >= SWA_CB_KMIN && K <= SWA_CB_KMAX;
 }

@@ -42,6 +42,9 @@ hipError_t swa_launch_narrow_bound_pass(int K, const swa_narrow_params* p, int b
 hipError_t swa_launch_narrow_bound_g2(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_bound_long2(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_bound_long4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
+hipError_t swa_launch_narrow_bound_long8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g16(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_bound_period(void);
 int swa_bound_available(int G, int K);
@@ -153,6 +156,7 @@ struct Options {
   int64_t requeue_follow = 1;    // 1: the re-queue kernel runs BESIDE the first pass on a second stream (single-launch first passes)
   int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
   int64_t window_step = 0;       // distance between window starts; 0 = from the query (the overlap is never a knob: it is what makes it exact)
+  int64_t long_lanes = 1;        // bound build: chains of 2 / 4 / 8 lanes with up to 62 rows per lane where the query fits them (0: 48)
 };
 struct OptionKey { const char* key; int64_t Options::*field; };
 const OptionKey kOptionKeys[] = {
@@ -162,6 +166,7 @@ const OptionKey kOptionKeys[] = {
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
   {"requeue_follow", &Options::requeue_follow}, {"window", &Options::window}, {"window_step", &Options::window_step},
+  {"long_lanes", &Options::long_lanes},
 };
 bool parse_option_value(const char* key, const char* value, int64_t* out)
 {
@@ -997,6 +1002,7 @@ int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, h
 constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] blocks finished | [32] done flag (polled)
 constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
+constexpr int BOUND_LONG_ROWS = 62;         // longest lane of the bound build on 2-, 4- and 8-lane chains (sw_cb_long*.hip)
 constexpr int ONE_BOUND_ROWS = 60;          // longest query of the one-lane bound build (sw_one_e.hip; rowc[] ends at K + period + 2 <= 80)
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
@@ -1276,12 +1282,20 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   // (the bound build keeps 2 K state registers, not 3 K: its one-lane form reaches 60 rows at two waves per SIMD)
   const bool one_bound_long = want_bound && qlen > 48 && qlen <= ONE_BOUND_ROWS && f16_limit(db, int(qlen) + Nb) >= 1024;
   if (qlen <= 48 || one_bound_long) G = 1;
+  // ... and its chains reach 62 rows per lane (sw_cb_long2/4/8.hip): 97..124 rows on 2 lanes instead of 4, 193..248 on 4
+  // instead of 8, 385..496 on 8 instead of 16 - half the hand-overs per row and half the skew (option "long_lanes" = 0: off)
+  const int bound_rows = want_bound && db->opt.long_lanes != 0 && f16_limit(db, BOUND_LONG_ROWS + Nb) >= 1024 ? BOUND_LONG_ROWS : 48;
+  if (bound_rows > 48 && G > 1) {
+    for (int g = 2; g < G; g *= 2)
+      if (qlen > g * 48 && qlen <= int64_t(g) * bound_rows) { G = g; break; }
+  }
   if (db->opt.lanes > 0) {
     G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
-    while (G < 16 && qlen > G * 48 && !(G == 1 && one_bound_long)) G *= 2;
+    while (G < 16 && qlen > G * (G > 1 ? bound_rows : 48) && !(G == 1 && one_bound_long)) G *= 2;
   }
   if (G > 1 && G < 16 && !short_chains_safe(db, qlen) && qlen <= 16 * 58) G = 16;
-  const int Kg = G == 1 ? int(qlen) : swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
+  const int Kg = G == 1 ? int(qlen) : G < 16 && qlen > G * 48 && qlen <= int64_t(G) * bound_rows ? int((qlen + G - 1) / G)
+                                    : swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
   if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->opt.narrow_variant != 1) {
     const int K = Kg;
     swa_narrow_params p{};
@@ -1333,6 +1347,8 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       for (int r = 0; r <= K + Nb + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
       c.narrow_shifted = 8;
       HIP_TRY(G == 1 ? (K <= 24 ? swa_launch_one_bound_c(K, &p, blocks, st) : K <= 48 ? swa_launch_one_bound_d(K, &p, blocks, st) : swa_launch_one_bound_e(K, &p, blocks, st))
+                     : K > 48 && G == 2 ? swa_launch_narrow_bound_long2(K, &p, blocks, st) : K > 48 && G == 4 ? swa_launch_narrow_bound_long4(K, &p, blocks, st)
+                     : K > 48 && G == 8 ? swa_launch_narrow_bound_long8(K, &p, blocks, st)
                      : G == 2 ? swa_launch_narrow_bound_g2(K, &p, blocks, st) : G == 4 ? swa_launch_narrow_bound_g4(K, &p, blocks, st) : G == 8 ? swa_launch_narrow_bound_g8(K, &p, blocks, st)
                      : swa_launch_narrow_bound_g16(K, &p, blocks, st));
     } else if (G == 1) {
