@@ -91,7 +91,7 @@ typedef struct {
                             7: row-shifted form with 2 lanes per sequence pair (queries of 81..96 rows; at most 96 with lanes=2);
                             8: bound build of the row-shifted form (swa_search_topk only, see there);
                             9: bound build, one launch per pass (queries > 928 rows);
-                            10: bound build of the two-query kernel (non-nucleotide pairs of 129..512 rows; 257..384 rows on 8 lanes);
+                            10: bound build of the two-query kernel (non-nucleotide pairs of 65..512 rows);
                             11: row-shifted form, ONE lane per sequence pair (queries of at most 48 rows);
                             12: two-query kernel, ONE lane per sequence (at most 48 nucleotide / 32 other rows) */
 } swa_counters_t;

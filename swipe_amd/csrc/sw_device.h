@@ -104,6 +104,6 @@ struct swa_mp_params {
   long long gapopenextend, gapextend;
   float gapextend_f;
   uint32_t negQR, negR, negKR;
-  uint32_t rowc[68];
+  uint32_t rowc[80];
 };
 #endif

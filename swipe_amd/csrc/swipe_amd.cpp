@@ -1493,15 +1493,16 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   }
   if (Gd > 1 && Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
   int Kd = dual_mp ? 0 : Gd == 1 ? int(qlen) : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
-  // Pairs of 257..384-row queries whose search takes the bound build: 8-lane chains of 33..48 rows (sw_cb_dual_long.hip)
-  // instead of 16 lanes x 17..24 - half the hand-overs per row and half the skew.  (The exact two-query kernel has no such
-  // build - three state registers per row - so whatever switches the bound build off falls back to 16 lanes.)
-  if (!dual_mp && Gd == 16 && nres == 32 && qlen > 8 * 32 && qlen <= 8 * 48 && (db->opt.lanes == 0 || db->opt.lanes == 8) &&
-      (db->opt.dual_kmax == 0 || db->opt.dual_kmax >= 48) && bound_wanted(db, qlen, bound_min) && short_chains_safe(db, qlen)) {
-    const int K8 = int((qlen + 7) / 8);
-    if (swa_dual_bound_available(8, K8, nres) && f16_limit(db, K8 + swa_bound_period()) >= 1024) { Gd = 8; Kd = K8; }
+  // Pairs whose search takes the bound build (sw_cb_dual_*.hip, two state registers per row) run on chains of up to 62
+  // rows per lane: 129..248 rows on 4 lanes instead of 8, 257..496 on 8 instead of 16 - half the hand-overs per row and
+  // half the skew.  (The exact two-query kernel stops at 32 rows - three state registers per row - so whatever switches
+  // the bound build off falls back to the shorter lanes; option "long_lanes" = 0 does.)
+  if (!dual_mp && nres == 32 && Gd >= 8 && db->opt.long_lanes != 0 && (db->opt.lanes == 0 || db->opt.lanes == Gd / 2) &&
+      db->opt.dual_kmax == 0 && bound_wanted(db, qlen, bound_min) && short_chains_safe(db, qlen)) {
+    const int g = qlen <= 4 * BOUND_LONG_ROWS ? 4 : 8;
+    const int Kl = int((qlen + g - 1) / g);
+    if (g < Gd && qlen > g * 32 && swa_dual_bound_available(g, Kl, nres) && f16_limit(db, Kl + swa_bound_period()) >= 1024) { Gd = g; Kd = Kl; }
   }
-  if (db->opt.dual_kmax > 0 && Kd > db->opt.dual_kmax) Kd = 0;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
     if (rc != SWA_OK) return rc;
@@ -1546,7 +1547,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     // 32 rows per lane.  Beside the 63-row nucleotide kernel (two waves x 256 registers) a follower that lands on a SIMD first
     // keeps a producer wave out for the whole pass: measured 603 -> 612 ms for the nucleotide bench, so it runs after it there
     // (the 33..48-row bound build: 205 registers x two waves leave room, like the one-query bound build's 219)
-    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && (Kd <= 32 || (used_bound && Gd == 8));
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && (Kd <= 32 || used_bound);
     const int64_t nids2 = db->nseq + (windows ? db->nwin : 0);
     if (follow) {
       const size_t head = size_t(std::min<int64_t>(nids2, REQUEUE_CAP)) * sizeof(int32_t);

@@ -255,7 +255,7 @@ def test_bound_build_under_a_translated_search(monkeypatch):
     db.close()
 
 
-@pytest.mark.parametrize("lanes", [16, 8])
+@pytest.mark.parametrize("lanes", [16, 8, 4])
 def test_bound_build_of_the_two_query_kernel(lanes, monkeypatch):
     """pairs of protein queries (frames of a translated search) with a score threshold: bound build of swa_dual_kernel,
     K = 17..32 rows per lane for chains of 16 and 8 lanes - the merged hit list of both queries, totalhits and obvious
@@ -279,7 +279,7 @@ def test_bound_build_of_the_two_query_kernel(lanes, monkeypatch):
     r2, o2 = oracle.pack(seqs)
     db = swipe_amd.Database.from_arrays(r2, o2)
     Mo = oracle.matrix_builtin("BLOSUM62")
-    for K in range(17, 49 if lanes == 8 else 33):            # 8-lane chains: 33..48 rows too (sw_cb_dual_long.hip)
+    for K in range(17, 33 if lanes == 16 else 63):           # 4- and 8-lane chains: up to 62 rows (sw_cb_dual_g4 / _long.hip)
         go, ge = ((11, 1), (10, 2))[K % 2]
         db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
         qlen = lanes * K - (K % lanes)
