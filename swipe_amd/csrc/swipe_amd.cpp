@@ -1485,11 +1485,14 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
   // ... and ONE lane per sequence (sw_one_dual.hip) for queries of at most 48 nucleotide / 32 other rows: no chain at all
   const int64_t one_rows = swa_dual_one_rows(nres);
-  int Gd = qlen <= one_rows ? 1 : qlen <= 2 * 32 ? 2 : qlen <= 4 * 32 ? 4 : qlen <= 8 * 32 ? 8 : 16;
+  // (nucleotide: 4- and 8-lane chains carry up to 60 rows per lane, sw_dual_long4/8.hip - the registers and the 16-symbol
+  // table that give the 16-lane build its 63 - so 129..240 rows run on 4 lanes and 257..480 on 8; "long_lanes" = 0: 32)
+  const int lane_rows = nres == 16 && db->opt.long_lanes != 0 ? 60 : 32;
+  int Gd = qlen <= one_rows ? 1 : qlen <= 2 * 32 ? 2 : qlen <= 4 * lane_rows ? 4 : qlen <= 8 * lane_rows ? 8 : 16;
   if (db->opt.lanes > 0) {
     Gd = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
     if (Gd == 1 && qlen > one_rows) Gd = 2;
-    while (Gd > 1 && Gd < 16 && qlen > Gd * 32) Gd *= 2;
+    while (Gd > 1 && Gd < 16 && qlen > Gd * (Gd >= 4 ? lane_rows : 32)) Gd *= 2;
   }
   if (Gd > 1 && Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
   int Kd = dual_mp ? 0 : Gd == 1 ? int(qlen) : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);

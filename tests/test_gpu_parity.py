@@ -584,7 +584,7 @@ def test_dual_query_kernel_both_strands(qlen):
 @pytest.mark.parametrize("protein", [False, True])
 def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monkeypatch):
     """two queries of equal length in one pass, K = ceil(qlen / lanes): every K of the nucleotide build (1..63 with
-    16-lane chains, 1..32 with 8 / 4) and of the protein build (1..32), and the multi-pass kernel as cross-check"""
+    16-lane chains, 1..60 with 8 / 4, 1..32 with 2) and of the protein build (1..32), and the multi-pass kernel as cross-check"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     tab = synth.residue_table_protein() if protein else synth.residue_table_nucleotide()
     full = synth._random_residues(55, 1, 1024, tab)
@@ -600,7 +600,8 @@ def test_every_instantiation_of_the_single_pass_dual_kernel(protein, lanes, monk
     else:
         db.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
         Mo, goe, ge = oracle.matrix_nucleotide(1, -3), 7, 2
-    for K in range(1, (48 if (lanes == 1 and not protein) else 32 if (protein or lanes < 16) else 63) + 1):
+    kmax = 32 if protein else {1: 48, 2: 32, 4: 60, 8: 60, 16: 63}[lanes]     # nucleotide: long lanes on 4 / 8 too (sw_dual_long*.hip)
+    for K in range(1, kmax + 1):
         qlen = lanes * K - (K % lanes)
         q1 = full[:qlen]
         q2 = q1[::-1].copy() if protein else blastdb.revcomp_nt16(q1)
