@@ -30,3 +30,10 @@ for _ in range(3):
     print("tblastn: %.0f GCUPS kernel (%.2f ms), total %.0f GCUPS, cells %.3e" % (c['cells'] / c['kernel_ms'] / 1e6, c['kernel_ms'], c['cells'] / c['total_ms'] / 1e6, c['cells']))
 hits, tot, obv, c = db.search_frames_topk([q], keep=250, minscore=40)
 print("top hit", hits[:3], "totalhits", tot)
+for minscore in (60, 80):
+    best = None
+    for _ in range(3):
+        hits, tot, obv, c = db.search_frames_topk([q], keep=250, minscore=minscore)
+        if best is None or c["kernel_ms"] < best["kernel_ms"]: best = c
+    print("tblastn top-250, minscore %d: form %d K=%d kernel %.0f GCUPS, search %.0f GCUPS, totalhits %d" % (
+        minscore, best["narrow_shifted"], best["narrow_rows"], best["cells"] / best["kernel_ms"] / 1e6, best["cells"] / best["total_ms"] / 1e6, tot))
