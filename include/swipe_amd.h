@@ -333,6 +333,63 @@ SWA_API int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nl
 SWA_API int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, int nlists, int64_t stride,
                     int64_t keep, swa_fhit_t* out, int64_t* nout);
 
+/* ---- several devices behind one handle ------------------------------------------------------------------------
+   The reference parallelises INSIDE the binary: run_threads / worker (swipe.cc:1599-1699) hand chunks of sequence
+   numbers to -a N pthreads that all enter one hit list under hitsmutex, and mpiswipe's master farms chunks out and
+   re-enters the workers' reported hits (swipe.cc:1812-2160, tag_search_report 1951-1974, 2320).  A swa_group is that
+   layer for N devices: the database is cut into N contiguous, residue-balanced shards (swa_shard_bounds), shard i
+   lives on devices[i] and is served by ONE host thread of its own for the whole life of the group (the "one host
+   thread per device handle" rule above); a search runs on all shards at once, every shard reduces to its own top-K
+   on its device, and the N short lists are merged on the host with the reference comparator (swa_hits_merge /
+   swa_fhits_merge) - provably the single-list result because the reference's list is exactly the global top-K under
+   (score desc, seqno desc) (hits.cc:188-219).  4 KB per device and search cross the host: an in-process group needs
+   no RCCL; the RCCL gather belongs to the one-process-per-GPU launch (swipe_amd/parallel.py, bench.py --gpus N).
+   devices may name one device several times (two shards on one GPU: how the 1-GPU test box exercises this layer).
+   Shards that would be empty (more shards than sequences) are not created.  Every call below is the group form of
+   the swa_* call of the same name and returns what that call returns on one shard holding the whole database;
+   counters are summed over the shards, the two times are the slowest shard's. */
+typedef struct swa_group swa_group;
+/* cuts[0..nshards]: shard r = sequences [cuts[r], cuts[r+1]) of a database whose sequence s starts at residue
+   offsets[s] (nseq + 1 prefix sums, offsets[0] may be non-zero): the first sequence at or beyond each r/nshards of
+   the residues.  swa_blastdb_shard_bounds reads the lengths from the index files of a BLAST v4 database. */
+SWA_API int swa_shard_bounds(const int64_t* offsets, int64_t nseq, int nshards, int64_t* cuts);
+SWA_API int swa_blastdb_shard_bounds(const char* basename, int symtype, int nshards, int64_t* cuts);
+/* db_gencode = 0: the database as it is (symtype 0 / 1); 1..23: a nucleotide database held as its six translations
+   (swa_db_open_translated).  devices[i] = HIP device of shard i. */
+SWA_API int swa_group_open(const char* basename, int symtype, int db_gencode, int nshards, const int* devices, swa_group** out);
+SWA_API int swa_group_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int db_gencode,
+                          int nshards, const int* devices, int64_t first_seqno, int64_t total_seqcount,
+                          int64_t total_symcount, swa_group** out);
+SWA_API void swa_group_close(swa_group* g);
+/* *nshards = shards actually created; info describes the union of the shards (hbm_bytes summed) */
+SWA_API int swa_group_info(const swa_group* g, swa_db_info_t* info, int* nshards);
+/* shard i's own handle (borrowed; for swa_db_info and the A/B tools - searches go through the group) */
+SWA_API int swa_group_shard(const swa_group* g, int i, swa_db** db);
+SWA_API int swa_group_set_scoring(swa_group* g, const int64_t* matrix, int64_t gapopenextend, int64_t gapextend);
+SWA_API int swa_group_set_option(swa_group* g, const char* key, const char* value);
+/* include[i] for sequence first_seqno + i of the whole range the group holds (NULL = all) */
+SWA_API int swa_group_set_inclusion(swa_group* g, const uint8_t* include, int64_t n);
+SWA_API int swa_group_search(swa_group* g, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters);
+SWA_API int swa_group_search_topk(swa_group* g, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore,
+                          int64_t maxscore, swa_hit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
+                          swa_counters_t* counters);
+SWA_API int swa_group_search_pair_topk(swa_group* g, const uint8_t* query1, int64_t qlen1, const uint8_t* query2, int64_t qlen2,
+                               int64_t keep1, int64_t minscore1, int64_t maxscore1, int64_t keep2, int64_t minscore2,
+                               int64_t maxscore2, swa_hit_t* hits1, int64_t* nhits1, int64_t* totalhits1, int64_t* obvious1,
+                               swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2, int64_t* obvious2,
+                               swa_counters_t* counters);
+SWA_API int swa_group_search_frames_topk(swa_group* g, int nq, const uint8_t* const* queries, const int64_t* qlens,
+                                 const int32_t* qtags, int64_t keep, int64_t minscore, int64_t maxscore,
+                                 swa_fhit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
+                                 swa_counters_t* counters);
+/* the alignment phase: every hit is aligned by the shard that holds its sequence (align_chunk on the worker that
+   owns the chunk, swipe.cc:339-414), all shards at once; out[] / text in the order of the hit list */
+SWA_API int swa_group_align_hits(swa_group* g, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
+                         const int32_t* dstrands, const int32_t* dframes, int64_t n, swa_alignment_t* out, char* text,
+                         int64_t text_cap, int64_t* text_used);
+SWA_API int swa_group_db_sequence(swa_group* g, int64_t seqno, int dstrand, int dframe, uint8_t* buf, int64_t cap,
+                          int64_t* len, int64_t* ntlen);
+
 /* ---- statistics (host arithmetic, bit-exact with hits.cc/stats.cc) ------------------------- */
 typedef struct {
   int available;                       /* 0: no K-A parameters for this scoring system */

@@ -58,6 +58,10 @@ EXPORTS = [
     "swa_stats_init", "swa_evalue", "swa_bits", "swa_matrix_builtin", "swa_matrix_nucleotide",
     "swa_matrix_parse", "swa_default_gaps",
     "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
+    "swa_shard_bounds", "swa_blastdb_shard_bounds", "swa_group_open", "swa_group_from_memory", "swa_group_close", "swa_group_info",
+    "swa_group_shard", "swa_group_set_scoring", "swa_group_set_option", "swa_group_set_inclusion", "swa_group_search",
+    "swa_group_search_topk", "swa_group_search_pair_topk", "swa_group_search_frames_topk", "swa_group_align_hits",
+    "swa_group_db_sequence",
 ]
 
 _lib = None
@@ -134,5 +138,23 @@ def load():
     L.swa_synth_offsets.argtypes = [C.c_uint64, i64, i64, vp, vp, i64, vp, C.c_int]
     L.swa_synth_offsets.restype = i64
     L.swa_synth_fill.argtypes = [C.c_uint64, i64, i64, vp, vp, vp, i64, vp, vp, C.c_int]
+    ip = C.POINTER(C.c_int)
+    L.swa_shard_bounds.argtypes = [vp, i64, C.c_int, vp]
+    L.swa_blastdb_shard_bounds.argtypes = [C.c_char_p, C.c_int, C.c_int, vp]
+    L.swa_group_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, ip, C.POINTER(vp)]
+    L.swa_group_from_memory.argtypes = [vp, vp, i64, C.c_int, C.c_int, C.c_int, ip, i64, i64, i64, C.POINTER(vp)]
+    L.swa_group_close.argtypes = [vp]
+    L.swa_group_close.restype = None
+    L.swa_group_info.argtypes = [vp, C.POINTER(DbInfo), ip]
+    L.swa_group_shard.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.swa_group_set_scoring.argtypes = [vp, vp, i64, i64]
+    L.swa_group_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.swa_group_set_inclusion.argtypes = [vp, vp, i64]
+    L.swa_group_search.argtypes = L.swa_search.argtypes
+    L.swa_group_search_topk.argtypes = L.swa_search_topk.argtypes
+    L.swa_group_search_pair_topk.argtypes = L.swa_search_pair_topk.argtypes
+    L.swa_group_search_frames_topk.argtypes = L.swa_search_frames_topk.argtypes
+    L.swa_group_align_hits.argtypes = L.swa_align_hits.argtypes
+    L.swa_group_db_sequence.argtypes = L.swa_db_sequence.argtypes
     _lib = L
     return L

@@ -358,6 +358,159 @@ class Database:
             pass
 
 
+class Group(Database):
+    """One database over several devices behind one handle (swa_group): N residue-balanced shards, one host thread per
+    shard inside the library, per-shard top-K merged on the host with the reference comparator - what SWIPE's -a N
+    threads / mpiswipe's workers do (swipe.cc:1599-1699, 1951-1974).  devices may repeat a device (two shards on one GPU).
+    Same search / align interface as Database; the per-shard entry points that make no sense on a group raise."""
+    _F = {"set_scoring": "swa_group_set_scoring", "set_option": "swa_group_set_option", "info": "swa_group_info"}
+
+    @classmethod
+    def open(cls, basename: str, *, symtype: int = 1, devices=(0,), db_gencode: int = 0):
+        h = C.c_void_p()
+        dev = (C.c_int * len(devices))(*devices)
+        _check(_lib.load().swa_group_open(os.fsencode(basename), symtype, db_gencode, len(devices), dev, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, residues, offsets, *, symtype: int = 1, devices=(0,), first_seqno: int = 0, total_seqcount: int = 0,
+                    total_symcount: int = 0, translate_gencode: Optional[int] = None):
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = _i64(offsets)
+        h = C.c_void_p()
+        dev = (C.c_int * len(devices))(*devices)
+        _check(_lib.load().swa_group_from_memory(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1, symtype,
+                                                 translate_gencode or 0, len(devices), dev, first_seqno, total_seqcount,
+                                                 total_symcount, C.byref(h)))
+        return cls(h)
+
+    def info(self):
+        i, n = _lib.DbInfo(), C.c_int()
+        _check(_lib.load().swa_group_info(self._h, C.byref(i), C.byref(n)))
+        return dict({f: getattr(i, f) for f, _ in i._fields_}, nshards=n.value)
+
+    def shard_info(self, k: int):
+        h, i = C.c_void_p(), _lib.DbInfo()
+        _check(_lib.load().swa_group_shard(self._h, k, C.byref(h)))
+        _check(_lib.load().swa_db_info(h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in i._fields_}
+
+    def set_inclusion(self, include=None):
+        if include is None:
+            _check(_lib.load().swa_group_set_inclusion(self._h, None, 0))
+            return
+        inc = np.ascontiguousarray(include, dtype=np.uint8)
+        _check(_lib.load().swa_group_set_inclusion(self._h, inc.ctypes.data, len(inc)))
+
+    def set_scoring(self, matrix: np.ndarray, gapopen: int, gapextend: int):
+        M = _i64(matrix)
+        _check(_lib.load().swa_group_set_scoring(self._h, M.ctypes.data, gapopen + gapextend, gapextend))
+
+    def set_option(self, key: str, value=None):
+        _check(_lib.load().swa_group_set_option(self._h, key.encode(), None if value is None else str(value).encode()))
+
+    def search(self, query: np.ndarray, *, want_scores: bool = True):
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        c = _lib.Counters()
+        i = self.info()
+        scores = np.empty(i["seqcount"] * i["frames"], dtype=np.int64) if want_scores else None
+        _check(_lib.load().swa_group_search(self._h, q.ctypes.data, len(q), scores.ctypes.data if want_scores else None, C.byref(c)))
+        return scores, {f: getattr(c, f) for f, _ in c._fields_}
+
+    def search_topk(self, query: np.ndarray, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        c = _lib.Counters()
+        hits = (_lib.Hit * max(1, keep))()
+        n, tot, obv = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(_lib.load().swa_group_search_topk(self._h, q.ctypes.data, len(q), keep, minscore, maxscore, hits, C.byref(n),
+                                                 C.byref(tot), C.byref(obv), C.byref(c)))
+        return ([(hits[i].seqno, hits[i].score) for i in range(n.value)], tot.value, obv.value,
+                {f: getattr(c, f) for f, _ in c._fields_})
+
+    def search_pair_topk(self, query1, query2, keep=250, minscore=(1, 1), maxscore=((1 << 62), (1 << 62))):
+        q1 = np.ascontiguousarray(query1, dtype=np.uint8)
+        q2 = np.ascontiguousarray(query2, dtype=np.uint8)
+        two = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        k, lo, hi = two(keep), two(minscore), two(maxscore)
+        c = _lib.Counters()
+        h1, h2 = (_lib.Hit * max(1, k[0]))(), (_lib.Hit * max(1, k[1]))()
+        n1, t1, o1, n2, t2, o2 = (C.c_int64() for _ in range(6))
+        _check(_lib.load().swa_group_search_pair_topk(self._h, q1.ctypes.data, len(q1), q2.ctypes.data, len(q2), k[0], lo[0], hi[0],
+                                                      k[1], lo[1], hi[1], h1, C.byref(n1), C.byref(t1), C.byref(o1), h2,
+                                                      C.byref(n2), C.byref(t2), C.byref(o2), C.byref(c)))
+        return (([(h1[i].seqno, h1[i].score) for i in range(n1.value)], t1.value, o1.value),
+                ([(h2[i].seqno, h2[i].score) for i in range(n2.value)], t2.value, o2.value),
+                {f: getattr(c, f) for f, _ in c._fields_})
+
+    def search_frames_topk(self, queries, qtags=None, *, keep: int = 250, minscore: int = 1, maxscore: int = (1 << 62)):
+        L = _lib.load()
+        qs = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
+        ptr = (C.c_void_p * len(qs))(*[q.ctypes.data for q in qs])
+        lens = (C.c_int64 * len(qs))(*[len(q) for q in qs])
+        tags = (C.c_int32 * len(qs))(*(qtags if qtags is not None else range(len(qs))))
+        hits = (_lib.FrameHit * max(keep, 1))()
+        n, tot, obv = C.c_int64(), C.c_int64(), C.c_int64()
+        c = _lib.Counters()
+        _check(L.swa_group_search_frames_topk(self._h, len(qs), ptr, lens, tags, keep, minscore, maxscore, hits, C.byref(n),
+                                              C.byref(tot), C.byref(obv), C.byref(c)))
+        return ([(h.seqno, h.score, h.qstrand, h.qframe, h.dstrand, h.dframe) for h in hits[: n.value]], tot.value,
+                obv.value, {f: getattr(c, f) for f, _ in c._fields_})
+
+    def sequence(self, seqno: int, dstrand: int = 0, dframe: int = 0) -> np.ndarray:
+        L = _lib.load()
+        n = C.c_int64()
+        rc = L.swa_group_db_sequence(self._h, seqno, dstrand, dframe, None, 0, C.byref(n), None)
+        if rc not in (0, _lib.SWA_ERANGE):
+            _check(rc)
+        buf = np.empty(max(n.value, 1), dtype=np.uint8)
+        _check(L.swa_group_db_sequence(self._h, seqno, dstrand, dframe, buf.ctypes.data, n.value, C.byref(n), None))
+        return buf[: n.value]
+
+    def align(self, query: np.ndarray, seqnos, dstrands=None, dframes=None):
+        L = _lib.load()
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        ids = _i64(seqnos)
+        ds = None if dstrands is None else np.ascontiguousarray(dstrands, dtype=np.int32)
+        df = None if dframes is None else np.ascontiguousarray(dframes, dtype=np.int32)
+        out = (_lib.Alignment * max(len(ids), 1))()
+        cap = 1 << 16
+        while True:
+            text = C.create_string_buffer(cap)
+            used = C.c_int64()
+            rc = L.swa_group_align_hits(self._h, q.ctypes.data, len(q), ids.ctypes.data, None if ds is None else ds.ctypes.data,
+                                        None if df is None else df.ctypes.data, len(ids), out, text, cap, C.byref(used))
+            if rc == _lib.SWA_ERANGE:
+                cap = used.value
+                continue
+            _check(rc)
+            break
+        return [_alignment_dict(out[i], text.raw) for i in range(len(ids))]
+
+    def _unsupported(self, *a, **k):
+        raise SwaError("not a group operation: use a Database shard")
+
+    search_topk_array = search2 = search2_topk = search_endpoints = _unsupported
+
+    def close(self):
+        if self._h:
+            _lib.load().swa_group_close(self._h)
+            self._h = None
+
+
+def shard_bounds(offsets, nshards: int) -> np.ndarray:
+    """swa_shard_bounds: int64 [nshards + 1] cuts of residue-balanced contiguous shards (the C++ twin of parallel.shard_bounds)"""
+    off = _i64(offsets)
+    cuts = np.zeros(nshards + 1, dtype=np.int64)
+    _check(_lib.load().swa_shard_bounds(off.ctypes.data, len(off) - 1, nshards, cuts.ctypes.data))
+    return cuts
+
+
+def blastdb_shard_bounds(basename: str, nshards: int, *, symtype: int = 1) -> np.ndarray:
+    cuts = np.zeros(nshards + 1, dtype=np.int64)
+    _check(_lib.load().swa_blastdb_shard_bounds(os.fsencode(basename), symtype, nshards, cuts.ctypes.data))
+    return cuts
+
+
 def _alignment_dict(a, text: bytes) -> dict:
     d = {f: getattr(a, f) for f, _ in a._fields_ if not f.startswith("cigar_") and f != "reserved"}
     d["cigar"] = text[a.cigar_offset: a.cigar_offset + a.cigar_len].decode()

@@ -360,6 +360,34 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
   return SWA_OK;
 }
 
+// Sequence lengths alone, out of the index files (pass 1 of read_blast_db): offsets[s] = residues before sequence s.
+// What the multi-device group needs to cut a database into residue-balanced shards before any shard is read.
+int swa::read_blast_lengths(const char* basename, int symtype, std::vector<int64_t>& offsets)
+{
+  BlastDb bd;
+  const int rc_open = bd.open(basename, symtype, nullptr, false);
+  if (rc_open != SWA_OK) return rc_open;
+  offsets.assign(1, 0);
+  offsets.reserve(size_t(bd.nseq) + 1);
+  for (const Volume& v : bd.vols) {
+    for (int64_t s = 0; s < v.nseq; ++s) {
+      const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
+      if (o2 < o1 || o2 > v.seq.n) return fail(SWA_EIO, "corrupt sequence offsets in " + v.base);
+      int64_t len;
+      if (bd.protein) {
+        len = o2 > o1 ? int64_t(o2 - o1 - 1) : 0;
+      } else {
+        const uint64_t o3 = be32(v.amb_off + 4 * s);
+        if (o3 <= o1 || o3 > o2) return fail(SWA_EIO, "corrupt ambiguity offsets in " + v.base);
+        const size_t packed = size_t(o3 - o1);
+        len = int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3));
+      }
+      offsets.push_back(offsets.back() + len);
+    }
+  }
+  return SWA_OK;
+}
+
 // ---- definition lines -----------------------------------------------------------------------
 // BER walker for Blast-def-line-set (reference asnparse.cc:94-1095).  Every element of these headers is
 // context-tagged with indefinite length, primitives are short definite; the walker accepts both forms.

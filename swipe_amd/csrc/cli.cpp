@@ -1,5 +1,7 @@
-// swipe_amd: command-line driver with SWIPE's options on one MI355X: -p 0 blastn, 1 blastp, 2 blastx,
-// 3 tblastn, 4 tblastx (translated databases are translated once on the GPU when they are opened).
+// swipe_amd: command-line driver with SWIPE's options on the MI355Xs of one node: -p 0 blastn, 1 blastp, 2 blastx,
+// 3 tblastn, 4 tblastx (translated databases are translated once on the GPU when they are opened).  -a N = N devices:
+// the database is cut into N residue-balanced shards, one per device of the -g list, each served by a host thread of
+// its own (swa_group, the role of run_threads / worker, swipe.cc:1599-1699); -a 1 is one shard on the first device.
 //
 // Mirrors the control flow of the reference's main()/work() (swipe.cc:2436-2611): open the
 // database once, then for every query of the FASTA file: hits_init thresholds, search, hit list,
@@ -262,7 +264,7 @@ void usage(const char* prog)
   std::printf("  -k, --minevalue=REAL       minimum expect value of sequences to show (0.0)\n");
   std::printf("  -c, --min_score=NUM        minimum score of sequences to show (1)\n");
   std::printf("  -u, --max_score=NUM        maximum score of sequences to show (inf.)\n");
-  std::printf("  -a, --num_threads=NUM      accepted and ignored (one GPU)\n");
+  std::printf("  -a, --num_threads=NUM      devices to shard the database over, one host thread each (1)\n");
   std::printf("  -m, --outfmt=NUM           output format [0,7-9=plain,xml,tsv,tsv+] (0)\n");
   std::printf("  -p, --symtype=NAME/NUM     symbol type/translation [0-4] (1)\n");
   std::printf("  -I, --show_gis             show gi numbers in results (no)\n");
@@ -274,7 +276,7 @@ void usage(const char* prog)
   std::printf("  -S, --strand=NAME/NUM      query strands to search [1-3] (3)\n");
   std::printf("  -o, --out=FILE             output file (stdout)\n");
   std::printf("  -z, --dbsize=NUM           set effective database size (0)\n");
-  std::printf("  -g, --gpu=NUM              HIP device (0)\n");
+  std::printf("  -g, --gpu=LIST             HIP devices of the shards, e.g. 0,1,2,3 or 0,0 (all devices)\n");
 }
 }  // namespace
 
@@ -283,7 +285,8 @@ int main(int argc, char** argv)
   std::string dbname, queryname = "-", matrixname, outfile, taxidfile;
   bool show_gis = false, show_taxid = false;
   long gapopen = 0, gapextend = 0, minscore = 1, maxscore = LONG_MAX, maxmatches = 250, view = 0, symtype = 1;
-  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, device = 0, alignments = 100, query_gencode = 1, db_gencode = 1;
+  long match = 1, mismatch = -3, strands = 3, effdbsize = 0, alignments = 100, query_gencode = 1, db_gencode = 1;
+  std::string devlist;
   long threads = 1, dump = 0;
   double expect = 10.0, minexpect = 0.0;
   static const option longopts[] = {
@@ -307,7 +310,7 @@ int main(int argc, char** argv)
       case 'E': gapextend = std::atol(optarg); break;
       case 'v': maxmatches = std::atol(optarg); break;
       case 'b': alignments = std::atol(optarg); break;
-      case 'a': threads = std::atol(optarg); break;                   // shown, otherwise unused: one GPU does the work
+      case 'a': threads = std::atol(optarg); break;                   // shards = devices, one host thread each
       case 'e': expect = std::atof(optarg); break;
       case 'k': minexpect = std::atof(optarg); break;
       case 'c': minscore = std::atol(optarg); break;
@@ -315,7 +318,7 @@ int main(int argc, char** argv)
       case 'm': view = std::atol(optarg); break;
       case 'o': outfile = optarg; break;
       case 'z': effdbsize = std::atol(optarg); break;
-      case 'g': device = std::atol(optarg); break;
+      case 'g': devlist = optarg; break;
       case 'C':                                                        // swipe.cc:921-926
         if (strcasecmp(optarg, "F") != 0 && std::strcmp(optarg, "0") != 0) fatal("Composition-based score adjustments not supported.");
         break;
@@ -433,12 +436,30 @@ int main(int argc, char** argv)
   std::vector<uint8_t> qtable(4096);
   check(swa_translate_table(int(query_gencode), qtable.data()));
 
-  swa_db* db = nullptr;
-  if (symtype >= 3) check(swa_db_open_translated(dbname.c_str(), int(db_gencode), int(device), 0, -1, &db));
-  else check(swa_db_open(dbname.c_str(), db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN, int(device), 0, -1, &db));
+  // -a N shards over the devices of -g (default: every device of the node, in order); fewer devices than threads
+  // asked for = as many shards as devices (-g 0,0 puts two shards on device 0)
+  if (threads < 1 || threads > 256) fatal("Illegal number of threads specified");   // swipe.cc:1131, MAX_THREADS
+  std::vector<int> devices;
+  if (devlist.empty()) {
+    for (int d = 0; d < swa_device_count(); ++d) devices.push_back(d);
+    if (devices.empty()) fatal("swipe_amd: no HIP device (there is no CPU fallback)");
+  } else {
+    for (const char* p = devlist.c_str(); *p;) {
+      char* end = nullptr;
+      const long d = std::strtol(p, &end, 10);
+      if (end == p || d < 0) fatal("Illegal device list.");
+      devices.push_back(int(d));
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') fatal("Illegal device list.");
+    }
+  }
+  const int nshards = int(std::min<long>(threads, long(devices.size())));
+  swa_group* db = nullptr;
+  check(swa_group_open(dbname.c_str(), db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN, symtype >= 3 ? int(db_gencode) : 0,
+                       nshards, devices.data(), &db));
   swa_db_info_t info;
-  check(swa_db_info(db, &info));
-  check(swa_set_scoring(db, M, gapopen + gapextend, gapextend));
+  check(swa_group_info(db, &info, nullptr));
+  check(swa_group_set_scoring(db, M, gapopen + gapextend, gapextend));
   const int db_filetype = db_nt ? SWA_SYMTYPE_NUCLEOTIDE : SWA_SYMTYPE_PROTEIN;
   // definition lines, the alias's OID mask (applied by swa_db_open) and the -x taxid list (applied here):
   // db_check_inclusion, database.cc:1465-1481
@@ -447,7 +468,7 @@ int main(int argc, char** argv)
   if (!taxidfile.empty()) {
     std::vector<uint8_t> include(size_t(info.seqcount > 0 ? info.seqcount : 1));
     check(swa_headers_inclusion(headers, info.first_seqno, info.seqcount, include.data()));
-    check(swa_db_set_inclusion(db, include.data(), info.seqcount));
+    check(swa_group_set_inclusion(db, include.data(), info.seqcount));
   }
   char dbtitle[1024] = "", dbtime[256] = "";
   check(swa_headers_info(headers, nullptr, nullptr, nullptr, nullptr, nullptr, dbtitle, sizeof dbtitle));
@@ -535,7 +556,7 @@ int main(int argc, char** argv)
                              info.total_symcount, effdbsize, minscore, maxscore, minexpect, expect, &st2));
         std::vector<swa_hit_t> h1{size_t(keep)}, h2{size_t(keep)};
         int64_t n1 = 0, n2 = 0;
-        check(swa_search_pair_topk(db, q.seq.data(), qlen, qahead.seq.data(), qlen2, keep, st.scorethreshold,
+        check(swa_group_search_pair_topk(db, q.seq.data(), qlen, qahead.seq.data(), qlen2, keep, st.scorethreshold,
                                    st.upperscorethreshold, keep, st2.scorethreshold, st2.upperscorethreshold, h1.data(), &n1,
                                    &total, &obvious, h2.data(), &n2, &ahead_total, &ahead_obvious, &cnt));
         for (int64_t i = 0; i < n1; ++i) hits[size_t(i)] = swa_fhit_t{h1[size_t(i)].seqno, h1[size_t(i)].score, 0, 0, 0, 0};
@@ -557,7 +578,7 @@ int main(int argc, char** argv)
       std::vector<const uint8_t*> ptr;
       std::vector<int64_t> len;
       for (const auto& f : frames) { ptr.push_back(f.data()); len.push_back(int64_t(f.size())); }
-      check(swa_search_frames_topk(db, int(frames.size()), ptr.data(), len.data(), tags.data(), keep, st.scorethreshold,
+      check(swa_group_search_frames_topk(db, int(frames.size()), ptr.data(), len.data(), tags.data(), keep, st.scorethreshold,
                                    st.upperscorethreshold, hits.data(), &nhits, &total, &obvious, &cnt));
     }
     // the reverse-complemented nucleotide query enters its hits as (qstrand 0, dstrand 1), swipe.cc:1470-1471
@@ -604,11 +625,11 @@ int main(int argc, char** argv)
       std::vector<swa_alignment_t> al{size_t(n)};
       std::vector<char> text(1 << 16);
       int64_t used = 0;
-      int rc = swa_align_hits(db, qseq.data(), int64_t(qseq.size()), seqnos.data(), ds.data(), df.data(), n, al.data(),
+      int rc = swa_group_align_hits(db, qseq.data(), int64_t(qseq.size()), seqnos.data(), ds.data(), df.data(), n, al.data(),
                               text.data(), int64_t(text.size()), &used);
       if (rc == SWA_ERANGE) {
         text.resize(size_t(used));
-        rc = swa_align_hits(db, qseq.data(), int64_t(qseq.size()), seqnos.data(), ds.data(), df.data(), n, al.data(),
+        rc = swa_group_align_hits(db, qseq.data(), int64_t(qseq.size()), seqnos.data(), ds.data(), df.data(), n, al.data(),
                             text.data(), int64_t(text.size()), &used);
       }
       check(rc);
@@ -621,7 +642,7 @@ int main(int argc, char** argv)
         h.script.assign(text.data() + h.a.cigar_offset, size_t(h.a.cigar_len));
         h.dseq.resize(size_t(h.a.dlen > 0 ? h.a.dlen : 1));
         int64_t got = 0;
-        check(swa_db_sequence(db, h.a.seqno, h.a.dstrand, h.a.dframe, h.dseq.data(), h.a.dlen, &got, nullptr));
+        check(swa_group_db_sequence(db, h.a.seqno, h.a.dstrand, h.a.dframe, h.dseq.data(), h.a.dlen, &got, nullptr));
         display_positions(h, mode);
       }
     }
@@ -783,7 +804,7 @@ int main(int argc, char** argv)
   }
   if (qf != stdin) std::fclose(qf);
   swa_headers_close(headers);
-  swa_db_close(db);
+  swa_group_close(db);
   if (out != stdout) std::fclose(out);
   return 0;
 }

@@ -39,6 +39,8 @@ struct HostDb {
 // Mirrors db_open (alias + volumes, database.cc:775-925) and db_getsequence
 // (database.cc:1237-1401) for symtype 0 and 1.  Returns SWA_OK or records an error.
 int read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out);
+// prefix sums of the sequence lengths of the whole database, from the index files alone (nseq + 1 entries)
+int read_blast_lengths(const char* basename, int symtype, std::vector<int64_t>& offsets);
 // Definition lines ("lcl|id title" style, first defline of each entry) of the given sequences
 int read_blast_deflines(const char* basename, int symtype, const std::vector<int64_t>& seqnos,
                         std::vector<std::string>& deflines, std::vector<int64_t>& lengths);

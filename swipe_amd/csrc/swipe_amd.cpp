@@ -1735,10 +1735,6 @@ int search_all(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, s
   }
 }
 
-bool hit_before(const swa_hit_t& a, const swa_hit_t& b)   // hits.cc:188-190: score desc, then seqno desc
-{
-  return a.score > b.score || (a.score == b.score && a.seqno > b.seqno);
-}
 }  // namespace
 
 extern "C" const char* swa_last_error(void) { return swa::g_last_error.c_str(); }
@@ -2696,38 +2692,5 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   *text_used = int64_t(all.size());
   if (int64_t(all.size()) > text_cap) return fail(SWA_ERANGE, "text buffer too small for the edit scripts");
   std::memcpy(text, all.data(), all.size());
-  return SWA_OK;
-}
-
-// the same for frame-tagged hits: entries of one sequence all come from the shard that holds it, already in the
-// reference's order (query frame, then database frame), which a stable sort on (score, seqno) preserves
-extern "C" int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, int nlists, int64_t stride, int64_t keep,
-                               swa_fhit_t* out, int64_t* nout)
-{
-  if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
-  std::vector<swa_fhit_t> all;
-  for (int l = 0; l < nlists; ++l)
-    for (int64_t i = 0; i < counts[l]; ++i) all.push_back(lists[int64_t(l) * stride + i]);
-  std::stable_sort(all.begin(), all.end(), [](const swa_fhit_t& a, const swa_fhit_t& b) {
-    if (a.score != b.score) return a.score > b.score;
-    return a.seqno > b.seqno;
-  });
-  const size_t k = std::min<size_t>(size_t(keep), all.size());
-  for (size_t i = 0; i < k; ++i) out[i] = all[i];
-  *nout = int64_t(k);
-  return SWA_OK;
-}
-
-extern "C" int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
-                              int64_t keep, swa_hit_t* out, int64_t* nout)
-{
-  if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
-  std::vector<swa_hit_t> all;
-  for (int l = 0; l < nlists; ++l)
-    for (int64_t i = 0; i < counts[l]; ++i) all.push_back(lists[int64_t(l) * stride + i]);
-  std::stable_sort(all.begin(), all.end(), hit_before);
-  const size_t k = std::min<size_t>(size_t(keep), all.size());
-  for (size_t i = 0; i < k; ++i) out[i] = all[i];
-  *nout = int64_t(k);
   return SWA_OK;
 }

@@ -1,0 +1,194 @@
+"""GPU: the C++ multi-device layer (swa_group, swipe_amd_cli -a N -g LIST) - the reference's run_threads / worker
+(swipe.cc:1599-1699) and the MPI master's re-entry of reported hits (swipe.cc:1951-1974) with a device as the unit.
+
+The test box has ONE MI355X, so every shard lives on device 0 (`-g 0,0,0`: three handles, three host threads, three
+sets of streams): the orchestration, the routing of the alignment phase and the merge are exactly what N devices run.
+Everything must equal the single-shard result and the reference's golden CLI output byte for byte."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import swipe_amd
+from conftest import ROOT, case_matrix, load_golden
+from swipe_amd import blastdb
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+THREADS = os.cpu_count() or 1
+
+
+def shard_args(k):
+    return ["-a", str(k), "-g", ",".join("0" * k)]
+
+
+def write_case(tmp_path, name):
+    case, g = cases.get(name), load_golden(name)
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    alpha = blastdb.NCBI4NA if (case.sym in (0, 2, 4)) else blastdb.NCBISTDAA
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+    return case, g, base, qf
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("name", ["p1k", "multivol", "nt", "asym", "edges", "limit16"])
+def test_cli_sharded_over_devices_equals_reference_cli(tmp_path, name, shards):
+    """-a N: hit list, alignments (-m 7 / 8 / 0) of N shards = the reference's output for the whole database; the hits of
+    a list come from different shards and every alignment is made by the shard that owns the sequence."""
+    case, g, base, qf = write_case(tmp_path, name)
+    args = [EXE, "-d", base, "-i", qf, "-p", "1" if case.protein else "0", "-G", str(case.gapopen), "-E", str(case.gapextend),
+            "-v", str(case.keep), "-e", "10"] + shard_args(shards)
+    if case.protein:
+        mat = case.matrix
+        if mat == "@text":
+            mat = str(tmp_path / "matrix.txt")
+            open(mat, "w").write(case.matrix_text)
+        args += ["-M", mat]
+    else:
+        args += ["-r", str(case.match), "-q", str(case.mismatch)]
+    run = lambda extra, env=None: subprocess.run(args + extra, capture_output=True, text=True, check=True, env=env).stdout
+    assert run(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]
+    assert run(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
+    plain = run(["-m", "0", "-b", str(g["nalign"])])
+    assert plain[plain.index("Sequences producing"):] == g["plain_align"]
+    assert f"Threads:           {shards}" in plain
+    # and with the bound build of the first pass forced on every shard
+    assert run(["-m", "8", "-b", str(case.keep)], dict(os.environ, SWA_BOUND="1")) == g["tsv"]
+    # hit list without alignments
+    xml = run(["-m", "7", "-b", "0"])
+    strip = lambda t: re.sub(r"\s*<len>\d+</len>", "", t)
+    assert strip(xml) == strip(g["xml"])
+
+
+@pytest.mark.parametrize("name", [f.__name__[5:] for f in cases.TRANSLATED])
+def test_cli_translated_searches_sharded(tmp_path, name):
+    case, g, base, qf = write_case(tmp_path, name)
+    args = [EXE, "-d", base, "-i", qf, "-p", str(case.sym), "-G", str(case.gapopen), "-E", str(case.gapextend), "-v", str(case.keep),
+            "-e", "10", "-M", case.matrix, "-Q", str(case.query_gencode), "-D", str(case.db_gencode)] + shard_args(2)
+    run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
+    assert run(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]
+    assert run(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
+    plain = run(["-m", "0", "-b", str(g["nalign"])])
+    assert plain[plain.index("Sequences producing"):] == g["plain_align"]
+
+
+@pytest.mark.parametrize("variant", ["plain_gis_taxid", "masked", "masked_taxlist", "taxlist_gis_taxid"])
+def test_cli_masks_and_taxid_lists_sharded(tmp_path, variant):
+    """an OID-mask alias and a -x taxid list cut across shard boundaries: each shard applies its slice"""
+    from test_host_cpu import build_headers_db, HEADER_VARIANTS
+    case, vol, masked, tx = build_headers_db(tmp_path)
+    ref = load_golden("headers")["variants"][variant]
+    dbn, flags, taxlist = HEADER_VARIANTS[variant]
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(blastdb.NCBISTDAA[c] for c in case.query) + "\n")
+    args = [EXE, "-d", vol if dbn == "vol" else masked, "-i", qf, "-v", str(case.keep), "-e", "1e6"] + shard_args(3)
+    args += (["-I"] if flags & 1 else []) + (["-H"] if flags & 2 else []) + (["-x", tx] if taxlist else [])
+    run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
+    assert run(["-m", "7", "-b", "5"]) == ref["m7"]
+    assert run(["-m", "8", "-b", str(case.keep)]) == ref["m8"]
+    plain = run(["-m", "0", "-b", "5"])
+    assert plain[plain.index("Sequences producing"):] == ref["m0"]
+
+
+def test_cli_multi_query_file_sharded(tmp_path):
+    """queries of a file two per pass (swa_group_search_pair_topk) on every shard"""
+    g = load_golden("multiquery")
+    case = cases.get("edges")
+    base = str(tmp_path / "db")
+    blastdb.write_db(base, case.seqs, protein=True)
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(g["query_text"])
+    r = subprocess.run([EXE, "-d", base, "-i", qf, "-m", "8", "-b", "10", "-v", "12", "-e", "1000"] + shard_args(2), capture_output=True, text=True)
+    assert r.returncode == g["rc8"], r.stderr
+    assert r.stdout == g["m8"]
+
+
+def test_cli_thread_and_device_arguments(tmp_path):
+    case, g, base, qf = write_case(tmp_path, "p1k")
+    common = [EXE, "-d", base, "-i", qf, "-m", "8", "-b", "5"]
+    r = subprocess.run(common + ["-a", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Illegal number of threads specified" in r.stderr          # swipe.cc:1131
+    r = subprocess.run(common + ["-g", "7"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no such HIP device" in r.stderr
+    r = subprocess.run(common + ["-g", "0,x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Illegal device list" in r.stderr
+    # more threads than devices listed: as many shards as devices; more shards than sequences: the empty ones are dropped
+    one = subprocess.run(common, capture_output=True, text=True, check=True).stdout
+    assert subprocess.run(common + ["-a", "16"], capture_output=True, text=True, check=True).stdout == one
+    tiny = str(tmp_path / "tiny")
+    blastdb.write_db(tiny, case.seqs[:3], protein=True)
+    a = subprocess.run([EXE, "-d", tiny, "-i", qf, "-m", "8", "-b", "5", "-e", "1e9"], capture_output=True, text=True, check=True).stdout
+    b = subprocess.run([EXE, "-d", tiny, "-i", qf, "-m", "8", "-b", "5", "-e", "1e9"] + shard_args(8), capture_output=True, text=True, check=True).stdout
+    assert a == b and a
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_group_api_equals_one_shard(shards):
+    """swa_group_* through ctypes on 30 000 synthetic sequences with planted homologs: every score, the top-K with ties
+    cut by keep, counts, the two-queries-per-pass form and the alignments equal the single-handle calls."""
+    q = blastdb.encode_protein(swipe_amd.synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(7, 30000, query=q)
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    one = swipe_amd.Database.from_arrays(res, off, first_seqno=11)
+    grp = swipe_amd.Group.from_arrays(res, off, devices=(0,) * shards, first_seqno=11)
+    one.set_scoring(M, 11, 1)
+    grp.set_scoring(M, 11, 1)
+    gi, oi = grp.info(), one.info()
+    assert gi["nshards"] == shards and all(gi[k] == oi[k] for k in ("seqcount", "symcount", "longest", "first_seqno", "total_seqcount", "total_symcount"))
+    sizes = [grp.shard_info(k)["symcount"] for k in range(shards)]
+    assert max(sizes) - min(sizes) <= 2 * oi["longest"]                      # residue-balanced
+    s1, c1 = one.search(q)
+    s2, c2 = grp.search(q)
+    assert np.array_equal(s1, s2) and c1["cells"] == c2["cells"] and c2["narrow"] == 30000
+    for keep, lo, hi in ((250, 40, 1 << 62), (1, 1, 1 << 62), (37, 45, 300), (1000, 30, 1 << 62)):
+        assert one.search_topk(q, keep, lo, hi)[:3] == grp.search_topk(q, keep, lo, hi)[:3], (keep, lo, hi)
+    grp.set_option("bound", 1)
+    assert one.search_topk(q, 250, 80)[:3] == grp.search_topk(q, 250, 80)[:3]
+    grp.set_option("bound", None)
+    q2 = np.ascontiguousarray(q[20:340])
+    a, b, _ = one.search_pair_topk(q, q2, keep=(100, 50), minscore=(40, 35))
+    x, y, _ = grp.search_pair_topk(q, q2, keep=(100, 50), minscore=(40, 35))
+    assert a == x and b == y
+    hits = grp.search_topk(q, 60, 40)[0]
+    assert len({int(np.searchsorted([grp.shard_info(k)["first_seqno"] for k in range(shards)], h[0], side="right")) for h in hits}) > 1, \
+        "hits of one list should come from several shards"
+    ids = [h[0] for h in hits]
+    assert one.align(q, ids) == grp.align(q, ids)
+    for s in ids[:5]:
+        assert np.array_equal(one.sequence(s), grp.sequence(s))
+    with pytest.raises(swipe_amd.SwaError):
+        grp.sequence(10)
+    # an inclusion set that silences whole shards
+    inc = np.ones(30000, np.uint8)
+    inc[: 30000 * 3 // 5] = 0
+    one.set_inclusion(inc)
+    grp.set_inclusion(inc)
+    assert one.search_topk(q, 250, 40)[:3] == grp.search_topk(q, 250, 40)[:3]
+    assert np.array_equal(one.search(q)[0], grp.search(q)[0])
+    one.close()
+    grp.close()
+
+
+def test_group_of_a_translated_nucleotide_database():
+    case = cases.get("tblastn")
+    res, off = oracle.pack(case.seqs)
+    M = case_matrix(case, swipe_amd)
+    one = swipe_amd.Database.from_arrays(res, off, translate_gencode=case.db_gencode)
+    grp = swipe_amd.Group.from_arrays(res, off, devices=(0, 0, 0), translate_gencode=case.db_gencode)
+    one.set_scoring(M, case.gapopen, case.gapextend)
+    grp.set_scoring(M, case.gapopen, case.gapextend)
+    q = np.asarray(case.query, dtype=np.uint8)
+    assert np.array_equal(one.search(q)[0], grp.search(q)[0])
+    h1 = one.search_frames_topk([q], keep=case.keep, minscore=20)
+    h2 = grp.search_frames_topk([q], keep=case.keep, minscore=20)
+    assert h1[:3] == h2[:3] and h1[0]
+    ids, ds, df = [h[0] for h in h1[0]], [h[4] for h in h1[0]], [h[5] for h in h1[0]]
+    assert one.align(q, ids, ds, df) == grp.align(q, ids, ds, df)
+    one.close()
+    grp.close()

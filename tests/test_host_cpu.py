@@ -456,3 +456,58 @@ def test_synth_offsets_place_a_shard_of_one_database():
         assert np.array_equal(o, off[lo:hi + 1] - off[lo])
         parts.append(r)
     assert np.array_equal(np.concatenate(parts), res)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: swa_group
+def test_cpp_shard_bounds_equal_the_python_ones(tmp_path):
+    """swa_shard_bounds (what swa_group and the CLI's -a N cut shards with) == parallel.shard_bounds (what bench.py's ranks
+    cut them with), on ragged, empty and degenerate length tables; swa_blastdb_shard_bounds reads the same lengths from
+    the index files of multi-volume protein and nucleotide databases"""
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5, 1000):
+        lens = rng.integers(0, 500, n)
+        lens[rng.random(n) < 0.2] = 0
+        off = np.concatenate([[7], 7 + np.cumsum(lens)]).astype(np.int64)
+        for w in (1, 2, 3, 4, 8, 17):
+            cuts = swipe_amd.shard_bounds(off, w)
+            assert [(int(cuts[i]), int(cuts[i + 1])) for i in range(w)] == parallel.shard_bounds(off, w)
+    for name in ("multivol", "nt"):
+        case = cases.get(name)
+        base = str(tmp_path / name)
+        blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+        off = np.concatenate([[0], np.cumsum([len(s) for s in case.seqs])]).astype(np.int64)
+        for w in (1, 2, 5):
+            assert np.array_equal(swipe_amd.blastdb_shard_bounds(base, w, symtype=1 if case.protein else 0), swipe_amd.shard_bounds(off, w))
+    with pytest.raises(swipe_amd.SwaError):
+        swipe_amd.blastdb_shard_bounds(str(tmp_path / "nosuch"), 2)
+
+
+def test_group_has_no_cpu_path_either():
+    if _lib.load().swa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    res, off = oracle.pack([cases.Q375])
+    with pytest.raises(swipe_amd.SwaError) as e:
+        swipe_amd.Group.from_arrays(res, off, devices=(0, 0))
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_group_layer_is_thread_sanitizer_clean(tmp_path):
+    """swipe_amd/csrc/group.cpp - worker threads, job hand-over, routing of the alignment phase, error propagation, the
+    merges - compiled with -fsanitize=thread against stand-in shards (tests/stubs/fake_shard.cpp scores by hash, no
+    device, no alignment) and driven from six caller threads at once: groups of 1..13 shards over 0..2 500 sequences must
+    return what the one-shard group returns (keep = 0 / 1, ties across shard boundaries, shards contributing nothing, more
+    shards than sequences, a failing shard), and ThreadSanitizer must stay silent."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "group_check")
+    stubs = os.path.join(ROOT, "tests", "stubs")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe, os.path.join(stubs, "group_check.cpp"),
+                            os.path.join(stubs, "fake_shard.cpp"), os.path.join(ROOT, "swipe_amd", "csrc", "group.cpp"), "-lpthread"],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in build.stderr.lower():
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "group check ok" in r.stdout, r.stderr[-3000:]
