@@ -4,6 +4,7 @@ the oracle; synthetic generator C++ == numpy; hit merge; shard bounds."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -369,18 +370,18 @@ def test_integration_binding_compiles_against_the_reference(tmp_path):
     if not os.path.exists(ref) or not shutil.which("g++"):
         pytest.skip("needs /root/reference and g++")
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    blocks = re.findall(r"```cpp\n(.*?)```", doc, flags=re.S)
-    binding = next(b for b in blocks if b.startswith("#ifdef SWIPE_AMD"))
-    assert "swa_search(" in binding and "hits_enter(" in binding and "swa_set_scoring(" in binding
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import splice_binding
     src = open(ref).read()
-    start = src.index("void search_chunk(struct search_data * sdp)\n{")
-    end = src.index("void * worker(void *)")
-    patched = src[:start] + "#ifndef SWIPE_AMD\n" + src[start:end] + "#endif\n" + binding + "\n" + src[end:]
-    work = tmp_path / "swipe_patched.cc"
-    work.write_text(patched)
-    cmd = ["g++", "-fsyntax-only", "-w", "-DSWIPE_AMD", "-I", "/root/reference", "-I", os.path.join(ROOT, "include"), str(work)]
-    out = subprocess.run(cmd, capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[:3000]
+    for variant, guard in (("scores", "SWIPE_AMD_SCORES"), ("topk", "SWIPE_AMD_TOPK")):
+        binding = splice_binding.binding(doc, variant)
+        assert "hits_enter(" in binding and "swa_set_scoring(" in binding and "pthread_mutex_lock" in binding
+        assert ("swa_search(" in binding) == (variant == "scores") and ("swa_search_frames_topk(" in binding) == (variant == "topk")
+        work = tmp_path / f"swipe_patched_{variant}.cc"
+        work.write_text(splice_binding.splice(src, binding))
+        cmd = ["g++", "-fsyntax-only", "-w", "-DSWIPE_AMD", "-D" + guard, "-I", "/root/reference", "-I", os.path.join(ROOT, "include"), str(work)]
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[:3000]
     # the alignment-phase and multi-query snippets are statement fragments: check that the entry points they name exist
     for name in re.findall(r"\b(swa_[a-z0-9_]+)\s*\(", doc):
         assert name in _lib.EXPORTS, name
@@ -511,3 +512,25 @@ def test_group_layer_is_thread_sanitizer_clean(tmp_path):
     assert build.returncode == 0, build.stderr
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "group check ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_bound_reference_binaries_have_no_cpu_path(tmp_path):
+    """oracle/_ref/swipe_bound_* (the reference with INTEGRATION.md's binding spliced in, linked against libswipe_amd.so)
+    start, parse SWIPE's options, open the database with the reference's own db_open - and, without a device, stop in the
+    binding's amd_open with the library's error through SWIPE's fatal(): linked, called, and no fallback to search7."""
+    import subprocess
+    exes = [os.path.join(ROOT, "oracle", "_ref", "swipe_bound_" + v) for v in ("scores", "topk")]
+    if not all(os.path.exists(e) for e in exes):
+        pytest.skip("needs oracle/_ref (built where /root/reference is present)")
+    if _lib.load().swa_device_count() > 0:
+        pytest.skip("a GPU is present: tests/test_gpu_binding.py runs them for real")
+    case = cases.get("p1k")
+    base = str(tmp_path / "p1k")
+    blastdb.write_db(base, case.seqs, protein=True)
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">q\n" + "".join(blastdb.NCBISTDAA[c] for c in case.query) + "\n")
+    for exe in exes:
+        r = subprocess.run([exe, "-d", base, "-i", qf, "-m", "8"], capture_output=True, text=True)
+        assert r.returncode == 1 and "swipe_amd:" in r.stderr and "no CPU fallback" in r.stderr, r.stderr
+        r = subprocess.run([exe, "-d", str(tmp_path / "nosuch"), "-i", qf], capture_output=True, text=True)
+        assert r.returncode == 1 and "Unable to open" in r.stderr          # the reference's own db_open error
