@@ -773,52 +773,68 @@ int launch_mp_run(swa_db* db, const MpRun& r, int64_t qlen, hipStream_t st)
   while (nw < 8 && (waves_cu + nw - 1) / nw > by_lds) nw += 2;     // fewer, larger blocks when LDS is the limit
   const int threads = nw * 64;
   const int per_cu = std::max(1, std::min(by_lds, waves_cu / nw));
-  const int supers = (p.nbatches + nw - 1) / nw;
-  const int blocks = std::max(1, std::min(supers, db->cus * per_cu));
-  if (p.npass > 1 && p.nbatches > 0) {
-    // Bottom-row hand-over between passes: every resident wave owns (columns of its batch + 48) x 4 rows x (H, F).
-    // Sized by the longest sequence that would be chromosome-scale memory for a few batches of a genome database,
-    // so the budget is bounded and the batches that do not fit it run first, on as few waves as their size allows.
-    const size_t vbytes = r.mode == 3 ? 8 : 4;
-    const size_t per_col = 8 * vbytes;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = std::min<size_t>(size_t(4) << 30, (free_b + db->boundary.bytes()) / 4);
-    if (db->opt.boundary_mb >= 0) budget = size_t(db->opt.boundary_mb) << 20;     // tests
-    const int64_t need = int64_t(r.set->h_steps.empty() ? db->longest : r.set->h_steps[0]) + 48;
-    const int64_t cols_all = int64_t(budget / (size_t(blocks) * nw * per_col));
-    if (need <= cols_all) {
-      p.boundary_cols = int32_t(need);
-      HIP_TRY(db->boundary.reserve(size_t(blocks) * nw * size_t(need) * per_col));
-      p.boundary = db->boundary.p;
-    } else {
-      // batches [0, i0) are too long for the common allotment
+  // One launch over batches [lo, hi) of the set, whose steps are non-increasing there.  With several passes every resident
+  // wave owns a hand-over buffer of (columns of its batch + 48) x 4 rows x (H, F), sized by the range's longest batch; the
+  // total is bounded, so batches too long for the common allotment run first, on as few waves as their size allows.
+  auto launch_range = [&](int lo, int hi) -> int {
+    swa_mp_params q = p;
+    q.batches = r.set->batches.p + lo;
+    q.slots = r.set->slots.p + size_t(lo) * SWA_SLOTS;
+    q.nbatches = hi - lo;
+    if (q.nbatches <= 0) return SWA_OK;
+    const int supers = (q.nbatches + nw - 1) / nw;
+    const int blocks = std::max(1, std::min(supers, db->cus * per_cu));
+    if (q.npass > 1) {
+      const size_t vbytes = r.mode == 3 ? 8 : 4;
+      const size_t per_col = 8 * vbytes;
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      size_t budget = std::min<size_t>(size_t(4) << 30, (free_b + db->boundary.bytes()) / 4);
+      if (db->opt.boundary_mb >= 0) budget = size_t(db->opt.boundary_mb) << 20;     // tests
       const std::vector<int32_t>& hs = r.set->h_steps;
-      const int64_t fit = std::max<int64_t>(cols_all, 64);
-      const int i0 = int(std::partition_point(hs.begin(), hs.end(), [&](int32_t st) { return int64_t(st) + 48 > fit; }) - hs.begin());
-      const int supers_a = (i0 + nw - 1) / nw;
-      int blocks_a = int(std::max<int64_t>(1, std::min<int64_t>(supers_a, int64_t(budget / (size_t(nw) * size_t(need) * per_col)))));
-      const size_t bytes_a = size_t(blocks_a) * nw * size_t(need) * per_col;
-      const size_t bytes_b = size_t(blocks) * nw * size_t(fit) * per_col;
-      if (bytes_a > free_b + db->boundary.bytes())
-        return fail(SWA_ENOMEM, "a database sequence is too long for the multi-pass kernel's hand-over buffer; use a shorter query");
-      HIP_TRY(db->boundary.reserve(std::max(bytes_a, bytes_b)));
-      p.boundary = db->boundary.p;
-      swa_mp_params pa = p;
-      pa.nbatches = i0;
-      pa.boundary_cols = int32_t(need);
-      HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
-      HIP_TRY(swa_launch_mp(r.mode, K, &pa, blocks_a, threads, st));
-      p.batches = r.set->batches.p + i0;
-      p.slots = r.set->slots.p + size_t(i0) * SWA_SLOTS;
-      p.nbatches = r.set->nbatches - i0;
-      p.boundary_cols = int32_t(fit);
-      if (p.nbatches <= 0) return SWA_OK;
+      const int64_t need = int64_t(hs.empty() ? db->longest : hs[size_t(lo)]) + 48;
+      const int64_t cols_all = int64_t(budget / (size_t(blocks) * nw * per_col));
+      if (need <= cols_all) {
+        q.boundary_cols = int32_t(need);
+        HIP_TRY(db->boundary.reserve(size_t(blocks) * nw * size_t(need) * per_col));
+        q.boundary = db->boundary.p;
+      } else {
+        // batches [lo, lo + i0) are too long for the common allotment
+        const int64_t fit = std::max<int64_t>(cols_all, 64);
+        const int i0 = int(std::partition_point(hs.begin() + lo, hs.begin() + hi, [&](int32_t st) { return int64_t(st) + 48 > fit; }) - (hs.begin() + lo));
+        const int supers_a = (i0 + nw - 1) / nw;
+        int blocks_a = int(std::max<int64_t>(1, std::min<int64_t>(supers_a, int64_t(budget / (size_t(nw) * size_t(need) * per_col)))));
+        const size_t bytes_a = size_t(blocks_a) * nw * size_t(need) * per_col;
+        const size_t bytes_b = size_t(blocks) * nw * size_t(fit) * per_col;
+        if (bytes_a > free_b + db->boundary.bytes())
+          return fail(SWA_ENOMEM, "a database sequence is too long for the multi-pass kernel's hand-over buffer; use a shorter query");
+        HIP_TRY(db->boundary.reserve(std::max(bytes_a, bytes_b)));
+        q.boundary = db->boundary.p;
+        swa_mp_params qa = q;
+        qa.nbatches = i0;
+        qa.boundary_cols = int32_t(need);
+        HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
+        HIP_TRY(swa_launch_mp(r.mode, K, &qa, blocks_a, threads, st));
+        q.batches += i0;
+        q.slots += size_t(i0) * SWA_SLOTS;
+        q.nbatches -= i0;
+        q.boundary_cols = int32_t(fit);
+        if (q.nbatches <= 0) return SWA_OK;
+      }
     }
-  }
-  HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
-  HIP_TRY(swa_launch_mp(r.mode, K, &p, blocks, threads, st));
-  return SWA_OK;
+    HIP_TRY(hipMemsetAsync(db->ctl.p + 0, 0, sizeof(int32_t), st));
+    HIP_TRY(swa_launch_mp(r.mode, K, &q, blocks, threads, st));
+    return SWA_OK;
+  };
+  // A view (windows of long sequences, prepare_view) is TWO length-sorted regions - [windows and what shared their batches |
+  // the set's remaining batches] - and the second may hold longer batches than the first (windows are at most W + O long,
+  // unwindowed sequences up to Lmax): sized by h_steps[0] alone, the hand-over of a multi-pass launch would be overrun.
+  // Each region gets a launch of its own, sized by its own longest batch.
+  const int nb_all = r.set->nbatches;
+  const int split = p.npass > 1 && r.set->stream_base && r.set->nlong > 0 && r.set->nlong < nb_all ? r.set->nlong : nb_all;
+  int rc = launch_range(0, split);
+  if (rc == SWA_OK && split < nb_all) rc = launch_range(split, nb_all);
+  return rc;
 }
 
 // Runs of batches whose pass hand-over (8 bytes per stream element) fits the buffer budget; reserves db->boundary.

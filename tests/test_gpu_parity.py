@@ -1306,6 +1306,51 @@ def test_long_subject_is_searched_as_overlapping_windows():
     db.close()
 
 
+def test_multipass_kernel_over_a_view_whose_windows_are_shorter_than_its_other_batches():
+    """the block-synchronous multi-pass kernel sizes its per-wave pass hand-over by the longest batch of the set
+    it runs over.  Over a window view that is NOT batch 0: the view is [window batches | the set's remaining batches], and
+    with a large gap extension penalty the windows (W + O = 1 501 columns here) are far shorter than the longest sequences
+    left whole (4 500).  Eight long sequences = exactly one batch of the pair stream, so no ordinary sequence shares the
+    window batches either.  force_mp with 3 passes of a 600-row query; the query planted beyond column 1 600 of the
+    4 500-residue sequences, where an undersized hand-over used to be overrun: every score against the oracle."""
+    rng = np.random.default_rng(5)
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(23, 1, 600, rtab)
+    seqs = []
+    for k in range(8):                                             # windowed: longer than the threshold of 5 000
+        body = rtab[rng.integers(0, len(rtab), 6000 + 37 * k)].astype(np.uint8)
+        at = 700 + 450 * k                                         # straddling window starts (every 300 columns)
+        body[at:at + 300] = q[150:450]                             # about 1 550: inside the exact f16 range, so the kernel's own
+        seqs.append(body)
+    for k in range(40):                                            # left whole, longer than any window
+        body = rtab[rng.integers(0, len(rtab), 4500 - 30 * k)].astype(np.uint8)
+        at = 1600 + 10 * k                                         # result is what is checked, not a re-queued recomputation
+        body[at:at + 300 - 3 * k] = q[200: 500 - 3 * k]
+        seqs.append(body)
+    res, off = swipe_amd.synth_db(41, 600)
+    seqs += [res[off[i]:off[i + 1]] for i in range(600)]
+    r2, o2 = oracle.pack(seqs)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    want = oracle.search_all63(r2, o2, q, Mo, 16, 11, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 5, 11)
+    db.set_option("window", 5000)
+    db.set_option("window_step", 300)
+    db.set_option("force_mp", 1)
+    for boundary_mb in (None, 1):                                  # the common allotment, and one too small for the long batches
+        db.set_option("boundary_mb", boundary_mb)
+        got, c = db.search(q)
+        assert c["narrow_rows"] in range(9, 17) and np.array_equal(got, want), boundary_mb
+    assert 1200 < int(want[8]) < 1800 and 1200 < int(want[0]) < 1800 and c["wide"] == 0      # nothing was recomputed
+    # two queries (the dual policy of the same kernel) over the one-sequence-per-row view: 4 long sequences fill a batch there
+    q2 = q[::-1].copy()
+    want2 = oracle.search_all63(r2, o2, q2, Mo, 16, 11, threads=THREADS)
+    db.set_option("dual_mp", 1)
+    t1, t2, c2 = db.search2(q, q2)
+    assert np.array_equal(t1, want) and np.array_equal(t2, want2)
+    db.close()
+
+
 @pytest.mark.parametrize("step", [64, 333, 1000])
 def test_windows_are_exact_for_alignments_that_span_long_gaps(step):
     """the overlap is the longest span a positive-scoring alignment can have, qlen (1 + hi / R): planted alignments with
