@@ -130,7 +130,11 @@ SWA_API int swa_db_from_memory_translated(const uint8_t* nt_residues, const int6
    buffering) - and merges the per-part candidates, so hit lists, counts and scores are those of the resident shard.
    The handle answers swa_search, swa_search_topk, swa_search2_topk (nucleotide parts carry the 4-bit one-sequence-per-
    row tables their both-strand searches run over), swa_search_pair_topk, swa_set_scoring, swa_set_option, swa_db_info
-   and swa_db_close (other entry points return SWA_ESTATE).  hbm_budget_bytes <= 0 or large enough: an ordinary resident shard. */
+   and swa_db_close (other entry points return SWA_ESTATE).  hbm_budget_bytes <= 0 or large enough: an ordinary resident shard.
+   The budget covers what the default searches use: the two slots with their residues, tables and first-pass stream.  What a
+   part does not carry is built per part and search OUTSIDE it: the pair stream of a nucleotide part for a single-strand
+   search, the 16-bit stream for a matrix that scores the padding symbol, window views of very long sequences, 64-bit
+   score arrays.  Opening holds the database twice in host memory for a moment (the caller's arrays + the page-locked parts). */
 SWA_API int swa_db_from_memory_streamed(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int device,
                                 int64_t first_seqno, int64_t total_seqcount, int64_t total_symcount,
                                 int64_t hbm_budget_bytes, swa_db** out);

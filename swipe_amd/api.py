@@ -159,6 +159,8 @@ class Database:
         residues = np.ascontiguousarray(residues, dtype=np.uint8)
         offsets = _i64(offsets)
         h = C.c_void_p()
+        if hbm_budget > 0 and translate_gencode is not None:
+            raise SwaError("a streamed shard (hbm_budget) cannot be a translated one (translate_gencode): translated shards are resident")
         if hbm_budget > 0:
             _check(_lib.load().swa_db_from_memory_streamed(residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1, symtype,
                                                            device, first_seqno, total_seqcount, total_symcount, hbm_budget,

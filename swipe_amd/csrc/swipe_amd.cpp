@@ -266,13 +266,31 @@ struct swa_db {
   int32_t h_matrix[1024];
   int64_t goe = 0, ge = 0, hi = 0, lo = 0;
   Options opt;                             // swa_set_option
-  // (query length, threshold) pairs for which the bound build sent back more than 2 % of the shard under the current
-  // scoring system: those searches take the exact first pass at once; other queries still try the bound build
-  std::vector<std::pair<int64_t, int64_t>> bound_off;
+  // Queries for which the bound build sent back more than 2 % of the shard under the current scoring system (a family-rich
+  // query: its threshold sits inside the bulk of its scores): THAT query takes the exact first pass at once from then on.
+  // Keyed by the query itself (hash of its residues) so that one such query does not switch the build off for every later
+  // query of its length - results never depend on this, but throughput must not depend on the order of a query file
+  // either; the newest 64 are remembered.
+  struct BoundOff { uint64_t qhash; int64_t qlen, minscore; };
+  std::vector<BoundOff> bound_off;
+  uint64_t cur_qhash = 0;                  // hash of the query (pair) of the search in flight
+  static uint64_t hash_query(const uint8_t* q1, int64_t n1, const uint8_t* q2, int64_t n2)
+  {
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t i = 0; i < n1; ++i) h = (h ^ q1[i]) * 1099511628211ull;
+    h = (h ^ 0xff) * 1099511628211ull;
+    for (int64_t i = 0; q2 && i < n2; ++i) h = (h ^ q2[i]) * 1099511628211ull;
+    return h;
+  }
   bool bound_is_off(int64_t qlen, int64_t minscore) const
   {
-    for (const auto& b : bound_off) if (b.first == qlen && minscore <= b.second) return true;
+    for (const BoundOff& b : bound_off) if (b.qhash == cur_qhash && b.qlen == qlen && minscore <= b.minscore) return true;
     return false;
+  }
+  void note_bound_off(int64_t qlen, int64_t minscore)
+  {
+    if (bound_off.size() >= 64) bound_off.erase(bound_off.begin());
+    bound_off.push_back({cur_qhash, qlen, minscore});
   }
   // page-locked staging block for everything a search reads back (counters, tallies, the first candidates): one
   // asynchronous copy and ONE stream synchronisation per search
@@ -642,8 +660,14 @@ int prepare_view(swa_db* db, const BatchSet& set, int per_row, int64_t qlen, con
   const uintptr_t pa = reinterpret_cast<uintptr_t>(set.stream.p), pb = reinterpret_cast<uintptr_t>(v.stream.p);
   const uintptr_t base = std::min(pa, pb) & ~uintptr_t(127);
   const uint64_t da = (pa - base) / unit, dl = (pb - base) / unit;
-  if ((pa - base) % unit || (pb - base) % unit || da + uint64_t(set.chunks) > 0xffffffffull || dl + lchunks > 0xffffffffull)
-    return fail(SWA_ENOMEM, "window stream cannot be addressed from the set's base");
+  if ((pa - base) % unit || (pb - base) % unit || da + uint64_t(set.chunks) > 0xffffffffull || dl + lchunks > 0xffffffffull) {
+    // the two allocations lie more than 2^32 chunks apart (128 GiB for the 32-byte chunks of a nucleotide shard - hipMalloc
+    // promises nothing about distances): search without windows, which is always correct, only slower for the long sequences
+    db->nwin = 0;
+    db->nparents = 0;
+    db->view_of = nullptr;
+    return SWA_OK;                                         // *out still names the set itself
+  }
   for (swa_batch& b : batches) b.offset += uint32_t(dl);
   HIP_TRY(v.slots.reserve(size_t(nl + nm) * SWA_SLOTS));
   HIP_TRY(v.batches.reserve(size_t(nl + nm)));
@@ -1259,6 +1283,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   pd = Pending{};
   swa_counters_t& c = pd.c;
   c.cells = db->active_sym * qlen;
+  if (bound_min > 0) db->cur_qhash = swa_db::hash_query(query, qlen, nullptr, 0);
   rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 8192);
   if (rc != SWA_OK) return rc;
   if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, false, st);
@@ -1442,7 +1467,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       rc = read_requeue(db, 1, db->ovf_list.p, requeue, st);
       if (rc != SWA_OK) return rc;
       if (used_bound && int64_t(requeue.size()) * 50 > db->nseq && db->opt.bound != 1) {
-        db->bound_off.emplace_back(qlen, bound_min);   // threshold too close to the bulk of the scores
+        db->note_bound_off(qlen, bound_min);   // threshold too close to the bulk of the scores
         return run_search(db, query, qlen, 0, pd);
       }
     } else {
@@ -1473,6 +1498,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   pd.two = true;
   swa_counters_t& c = pd.c;
   c.cells = db->active_sym * (qa + qb);
+  if (bound_min > 0) db->cur_qhash = swa_db::hash_query(q1, qa, q2, qb);
   rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 8192);
   if (rc != SWA_OK) return rc;
   if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, true, st);
@@ -1663,7 +1689,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
       if (rc == SWA_OK) rc = read_requeue(db, 3, db->ovf_list2.p, rq2, st);
       if (rc != SWA_OK) return rc;
       if (used_bound && int64_t(rq1.size() + rq2.size()) * 50 > 2 * db->nseq && db->opt.bound != 1) {
-        db->bound_off.emplace_back(qlen, bound_min);
+        db->note_bound_off(qlen, bound_min);
         return run_search2(db, q1, q2, qlen, 0, pd, qlen_a, qlen_b);
       }
     } else {
@@ -1697,7 +1723,7 @@ int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2,
   if (pd.dev1 || pd.dev2) {
     const int64_t lists = pd.dev2 ? 2 : 1;
     if (pd.used_bound && (n1 + n2) * 50 > lists * db->nseq && db->opt.bound != 1) {
-      db->bound_off.emplace_back(qlen, bound_min);
+      db->note_bound_off(qlen, bound_min);
       *again = true;
       return SWA_OK;
     }

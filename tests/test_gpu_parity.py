@@ -394,6 +394,16 @@ def test_bound_build_is_dropped_when_too_much_comes_back(monkeypatch):
     db3.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=900)
     assert c["narrow_shifted"] == 8 and (hits, tot, obv) == _expected_topk(want3, 50, 900)
+    # round 3: the fallback is per QUERY, not per query length - another query of the same length, unrelated to the family,
+    # still gets the bound build, whichever of the two is searched first (throughput does not depend on query order)
+    other = synth._random_residues(99, 1, len(q), rtab)
+    wanto = oracle.search_all63(r3, o3, other, Mo, 12, 1, threads=THREADS)
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=80)
+    assert c["narrow_shifted"] == 2
+    hits, tot, obv, c = db3.search_topk(other, keep=50, minscore=80)
+    assert c["narrow_shifted"] == 8 and (hits, tot, obv) == _expected_topk(wanto, 50, 80)
+    hits, tot, obv, c = db3.search_topk(q, keep=50, minscore=80)
+    assert c["narrow_shifted"] == 2 and (hits, tot, obv) == _expected_topk(want3, 50, 80)
     db.close()
     db3.close()
 
