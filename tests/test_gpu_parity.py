@@ -1562,6 +1562,53 @@ def test_bench_shards_one_database_over_two_ranks():
     assert two["verified_vs_oracle"] >= 2000
 
 
+def test_bench_workload_protein100m_over_two_ranks():
+    """BASELINE.json configs[4] (`--workload protein100M`) through the N-rank code path at a size the test box takes: 400 000
+    sequences over two ranks (gloo, both on device 0) against the same workload on one rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--workload", "protein100M", "--nseq", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+            "--verify-sample", "2000"]
+    one = _bench_line({}, *args)
+    env = dict(os.environ, SWA_BENCH_DEVICE="0", SWA_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", *args],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["hits_sha1"] == one["hits_sha1"]
+    assert two["search"]["totalhits"] == one["search"]["totalhits"] and two["search"]["top_hit"] == one["search"]["top_hit"]
+    assert two["verified_vs_oracle"] >= 2000 and "roofline" in two
+
+
+def test_bench_default_line_carries_configs_3_and_4_as_secondary_sections():
+    """the default N = 1 run: headline + exact first pass + `secondary` = [nucleotide (configs[3]), the big protein database
+    on one GPU (configs[4]'s database), two queries per pass], each with its own roofline and oracle verification - here at
+    sizes the test box takes (the driver's run uses 50 M and 100 M sequences)"""
+    line = _bench_line({}, "--nseq", "300000", "--steps", "2", "--warmup", "1", "--no-cold", "--verify-sample", "1500",
+                       "--secondary-nt-nseq", "100000", "--secondary-protein-nseq", "500000")
+    assert line["metric"] == "GCUPS, 375-aa query vs 10M-seq protein db at 1/2/4/8 GPUs; bit-exact scores"      # BASELINE.json's string
+    assert "exact_first_pass.value" in line["config"]["workload"] and line["verified_vs_oracle"] >= 1500
+    nt, big, pair = line["secondary"]
+    assert "configs[3]" in nt["metric"] and nt["verified_vs_oracle"] >= 300 and nt["roofline"]["bound"] == "hbm" and nt["value"] > 0
+    assert nt["cpu_baseline"]["kind"] in ("reference", "port")
+    assert "configs[4]" in big["metric"] and big["verified_vs_oracle"] >= 375 and big["roofline"]["frac"] > 0 and big["value"] > 0
+    assert "500000 synthetic protein sequences" in big["config"]["workload"]
+    assert pair["hits_identical"] is True
+    assert line["cpu_baseline"]["value"] and line["roofline"]["achieved"] > 0
+
+
+def test_bench_predicts_the_scaling_curve_from_one_gpu():
+    """--predict-scaling: shards of N = 1, 2, 4, 8 timed one by one; merged lists identical at every N; efficiencies sane"""
+    r = _bench_line({}, "--predict-scaling", "--nseq", "400000", "--steps", "2")
+    rows = r["rows"]
+    assert [x["n_gpus"] for x in rows] == [1, 2, 4, 8] and r["merged_lists_identical"] is True
+    assert all(len(x["shard_ms"]) == x["n_gpus"] for x in rows)
+    assert rows[0]["predicted_efficiency"] == 1.0 and all(0.2 < x["predicted_efficiency"] <= 1.1 for x in rows)
+
+
 def test_windows_compose_with_subsets_translation_and_streaming():
     """long sequences cut into windows inside the other ways a shard can be held: with an inclusion subset (excluded long
     sequences are not windowed at all, included ones are), as six translated frames of a long nucleotide sequence
