@@ -212,6 +212,15 @@ SWA_API void swa_db_close(swa_db* db);
    never reads the environment.  Unknown keys and unparsable values return SWA_EINVAL. */
 SWA_API int swa_set_option(swa_db* db, const char* key, const char* value);
 
+/* Diagnostics of the kernel selection (host arithmetic, no device): the build of the one-query first pass a search of a
+   qlen-row query would run under a scoring system with highest matrix entry hi - G lanes per sequence pair, K rows per
+   lane, the bound build or the exact one - i.e. the argmax over the measured table of every build (swa_kernel_rate:
+   kernel GCUPS of build (bound, G, K) on MI355X, 0 = no such build; csrc/kernel_rates.inc).  G = 0: the
+   query takes the multi-pass path.  lanes as the option of that name (0 = free); mean_len <= 0 = 325. */
+SWA_API int swa_kernel_choice(int64_t qlen, int want_bound, int64_t hi, int64_t gapopenextend, int64_t gapextend, int64_t longest,
+                      double mean_len, int lanes, int32_t* G, int32_t* K, int32_t* bound, int32_t* predicted_gcups);
+SWA_API int swa_kernel_rate(int bound, int G, int K);
+
 /* ---- scoring ------------------------------------------------------------------------------ */
 /* matrix: 32*32 scores, index (db_symbol << 5) | query_symbol, as score_matrix_63
    (matrices.cc:583-590); gapopenextend = gapopen + gapextend (swipe.cc:1126). */

@@ -1,0 +1,111 @@
+// The kernel selection of the one-query first pass as ONE rule over ONE measured table.
+//
+// Round 2 chose (lanes per sequence pair G, rows per lane K) by nested conditions whose thresholds were tuned point by
+// point ("a 60-line thicket ... the 48 -> 50-row throughput cliff shows the thresholds are hand-tuned").
+// Now: kernel_rates.inc holds the MEASURED throughput of every build that exists - exact and bound, G = 1, 2, 4, 8, 16,
+// every K - at qlen = G x K (tools/probe.py rates on MI355X, profiles/r03_kernel_rates.txt), and a query of qlen rows
+// takes the build that maximises
+//     rate[G][K] x qlen / (G x K)            the padding rows of K = ceil(qlen / G) are computed but not wanted
+//                x (L + G0) / (L + G)        the skew of a chain (G steps) is drained once per batch of mean length L;
+//                                            the table was measured at L0 = 325 (factor 1 there)
+// among the builds the scoring system allows (exact f16 range for K rows, isolation of short chains).  Occupancy steps,
+// register-allocation potholes at single K, the one-lane kernels' lack of hand-overs: all of it is in the table, none of
+// it in code.  A new kernel or new hardware = a new sweep + tools/gen_kernel_table.py; tests/test_host_cpu.py walks
+// qlen = 1..1100 and checks the argmax property, coverage and that no query length falls off a cliff.
+#include "kernel_choice.h"
+#include "../../include/swipe_amd.h"
+
+#include <algorithm>
+
+#include "kernel_rates.inc"
+
+namespace swa {
+int lg(int G);
+int64_t f16_exact_limit(int64_t hi, int64_t ge, int K) { return 2048 - hi - int64_t(K + 1) * ge; }
+
+// Chains shorter than a DPP row isolate neighbouring sequences by multiplying what a chain's last lane sends by zero: a
+// state that overflowed to +-inf would turn that zero into NaN and poison the neighbour.  f16 reaches inf beyond 65504.
+bool chains_isolated(int64_t qlen, int64_t longest, int64_t hi, int64_t goe, int64_t ge)
+{
+  const int64_t reach = std::min<int64_t>(qlen, std::max<int64_t>(longest, 1)) * std::max<int64_t>(hi, 1);
+  return reach + 80 * ge + goe < 60000;
+}
+
+int lg(int G) { return G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : 4; }
+
+bool build_exists(bool bound, int G, int K)
+{
+  if (K < 1 || K > 63 || (G != 1 && G != 2 && G != 4 && G != 8 && G != 16)) return false;
+  return (bound ? kRateBound : kRateExact)[lg(G)][K] != 0;
+}
+
+static bool allowed(const ChoiceEnv& e, bool bound, int G, int K)
+{
+  if (!build_exists(bound, G, K)) return false;
+  if (bound && K > kExactRows && !e.long_lanes && G != 16) return false;
+  if (f16_exact_limit(e.hi, e.ge, bound ? K + e.bound_period : K) < 1024) return false;    // K x R eats the exact range
+  if (G > 1 && G < 16 && !chains_isolated(e.qlen, e.longest, e.hi, e.goe, e.ge)) return false;
+  return true;
+}
+
+static int predicted(const ChoiceEnv& e, bool bound, int G, int K)
+{
+  const double rate = (bound ? kRateBound : kRateExact)[lg(G)][K];
+  const double L = std::max(8.0, e.mean_len), L0 = 325.0;
+  const double skew = G == 1 ? 1.0 : ((L0 + G) / L0) * (L / (L + G));
+  return int(rate * double(e.qlen) / double(G * K) * skew);
+}
+
+KernelPick pick_first_pass(const ChoiceEnv& e)
+{
+  KernelPick best;
+  if (e.qlen < 1) return best;
+  auto consider = [&](bool bound, int G) {
+    const int64_t K64 = (e.qlen + G - 1) / G;
+    if (K64 > 63) return;
+    const int K = int(K64);
+    if (!allowed(e, bound, G, K)) return;
+    const int p = predicted(e, bound, G, K);
+    if (p > best.predicted_gcups) best = KernelPick{G, K, bound, p};
+  };
+  if (e.lanes > 0) {
+    // option "lanes": that chain length if the query fits one of its builds, else the next longer one that does
+    int G = e.lanes >= 16 ? 16 : e.lanes >= 8 ? 8 : e.lanes >= 4 ? 4 : e.lanes >= 2 ? 2 : 1;
+    for (; G <= 16 && best.G == 0; G *= 2) {
+      if (e.want_bound) consider(true, G);
+      if (best.G == 0) consider(false, G);
+    }
+    return best;
+  }
+  for (int G = 1; G <= 16; G *= 2) {
+    if (e.want_bound) consider(true, G);
+    consider(false, G);
+  }
+  return best;
+}
+}  // namespace swa
+
+// diagnostic entry point of the C ABI: the build a search of this query would run (no device needed)
+extern "C" int swa_kernel_choice(int64_t qlen, int want_bound, int64_t hi, int64_t gapopenextend, int64_t gapextend, int64_t longest,
+                                 double mean_len, int lanes, int32_t* G, int32_t* K, int32_t* bound, int32_t* predicted_gcups)
+{
+  swa::ChoiceEnv e;
+  e.qlen = qlen;
+  e.want_bound = want_bound != 0;
+  e.hi = hi; e.goe = gapopenextend; e.ge = gapextend;
+  e.longest = longest;
+  e.mean_len = mean_len > 0 ? mean_len : 325.0;
+  e.lanes = lanes;
+  const swa::KernelPick p = qlen <= 16 * swa::kExactRows16 ? swa::pick_first_pass(e) : swa::KernelPick{};
+  if (G) *G = p.G;
+  if (K) *K = p.K;
+  if (bound) *bound = p.bound ? 1 : 0;
+  if (predicted_gcups) *predicted_gcups = p.predicted_gcups;
+  return SWA_OK;
+}
+
+// the table itself (tests check the choice against it): measured GCUPS of the (G, K) build, 0 = no such build
+extern "C" int swa_kernel_rate(int bound, int G, int K)
+{
+  return swa::build_exists(bound != 0, G, K) ? int((bound ? kRateBound : kRateExact)[swa::lg(G)][K]) : 0;
+}

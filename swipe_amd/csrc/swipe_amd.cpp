@@ -11,6 +11,7 @@
 #include "host_util.h"
 #include "sw_device.h"
 #include "traceback.h"
+#include "kernel_choice.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1043,7 +1044,7 @@ constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] 
 constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
 constexpr int BOUND_LONG_ROWS = 62;         // longest lane of the bound build on 2-, 4- and 8-lane chains (sw_cb_long*.hip)
-constexpr int ONE_BOUND_ROWS = 60;          // longest query of the one-lane bound build (sw_one_e.hip; rowc[] ends at K + period + 2 <= 80)
+
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
 
@@ -1230,8 +1231,7 @@ bool f16_applicable(const swa_db* db)
 // min(qlen, longest) x hi + the row / column bias, so such searches take 16-lane chains (zero fill by DPP, no product).
 bool short_chains_safe(const swa_db* db, int64_t qlen)
 {
-  const int64_t reach = std::min<int64_t>(qlen, std::max<int64_t>(db->longest, 1)) * std::max<int64_t>(db->hi, 1);
-  return reach + 80 * db->ge + db->goe < 60000;
+  return swa::chains_isolated(qlen, db->longest, db->hi, db->goe, db->ge);
 }
 
 // What a search has enqueued and not yet seen on the host
@@ -1308,35 +1308,24 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   const bool force_mp = db->opt.force_mp == 1;
   const bool single_pass = qlen <= 16 * 58 && K > 0 && !force_mp;
   HIP_TRY(hipEventRecord(db->ev[1], st));
-  // G = 2 (up to 40 rows), 4 (up to 192), 8 (up to 384) or 16 (up to 928) lanes per sequence pair, K = ceil(qlen / G)
-  // rows per lane (option "lanes" = 2 / 4 / 8 / 16 picks the chain length if the query fits it: A/B runs and tests)
-  // (2 lanes: measured ahead of 4 up to 40 rows - 10 aa 4.5 -> 5.7, 30 aa 7.3 -> 7.9 TCUPS; level at 50..80 rows, and
-  // ahead again where 4 lanes would leave K at 21..24: 88 aa 8.61 -> 8.89, 96 aa 8.96 -> 9.34 TCUPS exact)
-  int G = qlen <= 40 || (qlen > 80 && qlen <= 2 * 48) ? 2 : qlen <= 4 * 48 ? 4 : qlen <= 8 * 48 ? 8 : 16;
-  // Bound build (top-K searches, see below): wanted when the threshold is far enough above its slack.  It keeps two
-  // values per row instead of three, and with them 2-lane chains stay ahead of 4 lanes up to 96 rows (+2..8 %)
+  // Lanes per sequence pair G and rows per lane K = ceil(qlen / G) of the single-pass build: the argmax over the measured
+  // table of every build that exists (kernel_choice.cpp; option "lanes" pins the chain length: A/B runs and tests).  One
+  // lane per pair for short queries, chains of 2 / 4 / 8 / 16 lanes beyond; the bound build of the same shape for top-K
+  // searches whose threshold clears its slack (6 instead of 7.5 instructions per cell pair, two state registers per row
+  // instead of three: its lanes reach 60..62 rows where the exact build stops at 48).
   const int Nb = swa_bound_period();
   const bool want_bound = bound_wanted(db, qlen, bound_min);
-  if (want_bound && qlen <= 2 * 48) G = 2;
-  // ONE lane per sequence pair (sw_one_kernel.inc) for queries of at most 48 rows, exact and bound build alike: no
-  // chain, hence no hand-overs and no skew
-  // (the bound build keeps 2 K state registers, not 3 K: its one-lane form reaches 60 rows at two waves per SIMD)
-  const bool one_bound_long = want_bound && qlen > 48 && qlen <= ONE_BOUND_ROWS && f16_limit(db, int(qlen) + Nb) >= 1024;
-  if (qlen <= 48 || one_bound_long) G = 1;
-  // ... and its chains reach 62 rows per lane (sw_cb_long2/4/8.hip): 97..124 rows on 2 lanes instead of 4, 193..248 on 4
-  // instead of 8, 385..496 on 8 instead of 16 - half the hand-overs per row and half the skew (option "long_lanes" = 0: off)
-  const int bound_rows = want_bound && db->opt.long_lanes != 0 && f16_limit(db, BOUND_LONG_ROWS + Nb) >= 1024 ? BOUND_LONG_ROWS : 48;
-  if (bound_rows > 48 && G > 1) {
-    for (int g = 2; g < G; g *= 2)
-      if (qlen > g * 48 && qlen <= int64_t(g) * bound_rows) { G = g; break; }
-  }
-  if (db->opt.lanes > 0) {
-    G = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
-    while (G < 16 && qlen > G * (G > 1 ? bound_rows : 48) && !(G == 1 && one_bound_long)) G *= 2;
-  }
-  if (G > 1 && G < 16 && !short_chains_safe(db, qlen) && qlen <= 16 * 58) G = 16;
-  const int Kg = G == 1 ? int(qlen) : G < 16 && qlen > G * 48 && qlen <= int64_t(G) * bound_rows ? int((qlen + G - 1) / G)
-                                    : swa_narrow_rows_split(int(std::min<int64_t>(qlen, 4096)), G);
+  swa::ChoiceEnv env;
+  env.qlen = qlen;
+  env.want_bound = want_bound;
+  env.hi = db->hi; env.goe = db->goe; env.ge = db->ge;
+  env.longest = db->longest;
+  env.mean_len = db->h_order.empty() ? 325.0 : double(db->active_sym) / double(db->h_order.size());
+  env.lanes = int(db->opt.lanes);
+  env.long_lanes = db->opt.long_lanes != 0;
+  env.bound_period = Nb;
+  const swa::KernelPick pick = single_pass ? swa::pick_first_pass(env) : swa::KernelPick{};
+  const int G = pick.G, Kg = pick.K;
   if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->opt.narrow_variant != 1) {
     const int K = Kg;
     swa_narrow_params p{};
@@ -1368,7 +1357,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // everything at or above bound_min is recomputed by the 32-bit kernel.  Used when the threshold is far enough above
     // that slack for the recomputed share to be negligible (option "bound" = 0 never, 1 whenever a build exists); if more
     // than 2 % of the sequences come back it is switched off for this (query length, threshold) and the exact kernel runs
-    used_bound = want_bound && (G == 1 || swa_bound_available(G, K)) && f16_limit(db, K + Nb) >= 1024;
+    used_bound = pick.bound;
     // The re-queue list is worked off beside this kernel by a follower on the second stream (sw_kernels.hip
     // swa_requeue_follow_kernel): the head of the list is preset to -1 ("not written yet"), the kernel's last block
     // raises ctl[7].  The follower is launched AFTER the producer, so however the runtime maps the two streams onto

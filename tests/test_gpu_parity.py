@@ -217,7 +217,7 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
 
 def test_one_lane_bound_build_is_the_default_up_to_60_rows():
     """top-K searches of 49..60-row queries take the one-lane bound build by themselves (no option set), 61 rows and
-    exact searches of the same queries go to chains; same hits either way"""
+    exact searches of the same queries go to 2-lane chains; same hits either way"""
     rtab = synth.residue_table_protein()
     full = synth._random_residues(5, 1, 80, rtab)
     res, off = swipe_amd.synth_db(8, 3000, query=full)
@@ -231,7 +231,7 @@ def test_one_lane_bound_build_is_the_default_up_to_60_rows():
         assert (c["narrow_shifted"], c["narrow_rows"]) == (form, rows), c
         assert (hits, tot, obv) == _expected_topk(want, 30, 70)
         scores, c = db.search(q)
-        assert c["narrow_shifted"] == 3 and np.array_equal(scores, want)
+        assert c["narrow_shifted"] == 7 and np.array_equal(scores, want)
     db.close()
 
 

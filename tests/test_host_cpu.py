@@ -534,3 +534,71 @@ def test_bound_reference_binaries_have_no_cpu_path(tmp_path):
         assert r.returncode == 1 and "swipe_amd:" in r.stderr and "no CPU fallback" in r.stderr, r.stderr
         r = subprocess.run([exe, "-d", str(tmp_path / "nosuch"), "-i", qf], capture_output=True, text=True)
         assert r.returncode == 1 and "Unable to open" in r.stderr          # the reference's own db_open error
+
+
+# ------------------------------------------------------------------------------------------------ round 3: kernel selection
+def _choice(qlen, bound=0, hi=11, goe=12, ge=1, longest=35000, mean_len=0.0, lanes=0):
+    L = _lib.load()
+    g, k, b, p = (ctypes.c_int32() for _ in range(4))
+    assert L.swa_kernel_choice(qlen, bound, hi, goe, ge, longest, mean_len, lanes, ctypes.byref(g), ctypes.byref(k), ctypes.byref(b),
+                               ctypes.byref(p)) == 0
+    return g.value, k.value, b.value, p.value
+
+
+def test_kernel_selection_is_the_argmax_of_the_measured_table():
+    """The first-pass build of a one-query search is chosen by ONE rule over ONE measured table (csrc/kernel_choice.cpp,
+    kernel_rates.inc generated from profiles/r03_kernel_rates.txt): walk qlen = 1..1100, exact and top-K, and check that
+    the pick covers the query with a build that exists, that no other build the table holds predicts more, that no query
+    length falls off a cliff (round 2: 9.2 -> 8.1 TCUPS from 48 to 50 rows), and that queries beyond the longest single
+    pass take the multi-pass path."""
+    L = _lib.load()
+    rate = lambda b, G, K: L.swa_kernel_rate(b, G, K) if 1 <= K <= 63 else 0
+    assert rate(0, 8, 47) > 8000 and rate(1, 8, 47) > rate(0, 8, 47) and rate(0, 2, 49) == 0 and rate(1, 2, 49) > 0 and rate(0, 3, 5) == 0
+    for bound in (0, 1):
+        prev = None
+        best_of_table = max(rate(bound, G, K) for G in (1, 2, 4, 8, 16) for K in range(1, 64))
+        for qlen in range(1, 1101):
+            G, K, b, p = _choice(qlen, bound)
+            if qlen > 928:
+                assert G == 0, qlen
+                continue
+            assert G in (1, 2, 4, 8, 16) and K == -(-qlen // G) and rate(b, G, K) > 0, (qlen, G, K, b)
+            assert b in (0, bound)
+            for G2 in (1, 2, 4, 8, 16):                     # nothing in the table predicts more
+                K2 = -(-qlen // G2)
+                for b2 in ((1, 0) if bound else (0,)):
+                    r2 = rate(b2, G2, K2)
+                    skew = 1.0 if G2 == 1 else ((325.0 + G2) / 325.0) * (325.0 / (325.0 + G2))
+                    assert p + 1 >= int(r2 * qlen / (G2 * K2) * skew), (qlen, (G, K, b, p), (G2, K2, b2, r2))
+            # (the one step that remains is structural: from 48 to 49 rows an exact search leaves the one-lane build - 3 K state
+            # registers, 48 rows at two waves per SIMD - for 2-lane chains, whose hand-overs cost 0.6 instructions per row: -7.6 %)
+            if qlen >= 24 and prev is not None:
+                assert p >= 0.92 * prev, f"cliff at {qlen - 1} -> {qlen} rows: {prev} -> {p} ({'bound' if bound else 'exact'})"
+            if qlen >= 48:
+                assert p >= 0.88 * best_of_table, (qlen, p, best_of_table)
+            prev = p
+    # exact searches of 49..64 rows run on 2-lane chains of 25..32 rows (measured 3..7 % ahead of 4 lanes of 13..16)
+    assert _choice(49)[:2] == (2, 25) and _choice(56)[:2] == (2, 28)
+    # the bench query: 8 lanes x 47 rows, bound build for the top-K search
+    assert _choice(375)[:3] == (8, 47, 0) and _choice(375, 1)[:3] == (8, 47, 1)
+    # top-K: one lane per pair up to 60 rows, long lanes (49..62 rows) on short chains beyond
+    assert _choice(60, 1)[:3] == (1, 60, 1) and _choice(124, 1)[:3] == (2, 62, 1) and _choice(248, 1)[:3] == (4, 62, 1)
+
+
+def test_kernel_selection_respects_the_scoring_system_and_the_knobs():
+    # K x R must leave 1024 of the exact f16 range (bound builds: K + period rows): gap extension 16 caps lanes at 46 bound / 62 exact rows
+    for qlen in (30, 47, 60, 200, 375, 700):
+        G, K, b, p = _choice(qlen, 1, hi=11, goe=20, ge=16)
+        assert G > 0 and 2048 - 11 - (K + (16 if b else 0) + 1) * 16 >= 1024, (qlen, G, K, b)
+    assert _choice(60, 1, ge=16, goe=20)[:3] != (1, 60, 1)
+    # a scoring system whose scores can overflow f16 to infinity: no chains shorter than a DPP row (0 x inf = NaN would reach the neighbour)
+    for qlen in (330, 375, 800):
+        assert _choice(qlen, 0, hi=200, goe=12, ge=1, longest=35000)[0] == 16
+    assert _choice(100, 0, hi=200, goe=12, ge=1, longest=35000)[0] == 4      # 100 rows x 200 stays finite
+    assert _choice(375, 0, hi=200, longest=100)[0] == 8          # short sequences bound the reach again
+    # option "lanes": that chain length if the query fits one of its builds, else the next longer one
+    assert _choice(100, 0, lanes=4)[:2] == (4, 25) and _choice(100, 0, lanes=16)[:2] == (16, 7) and _choice(40, 0, lanes=2)[:2] == (2, 20)
+    assert _choice(200, 0, lanes=2)[:2] == (8, 25)               # 2 x 48 and 4 x 48 rows do not hold it (exact build)
+    assert _choice(200, 1, lanes=2)[:3] == (4, 50, 1)            # the bound build's long lanes do on 4
+    # short database sequences (translated frames) make long chains pay their skew more often
+    assert _choice(90, 0, mean_len=40.0)[3] < _choice(90, 0, mean_len=325.0)[3]
