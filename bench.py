@@ -84,15 +84,14 @@ def roofline_blocks(nsym, nseq, cells, k_ms, form, rows, bytes_per_residue=1.0, 
 
 
 def committed_traffic(key, nseq):
-    """HBM bytes per launch from the committed PMC pass of this command (profiles/hbm_traffic.json): counters cannot be
-    collected inside a timed run, so the line says where the number comes from"""
+    """HBM bytes per launch from the committed PMC passes of the default bench command (profiles/hbm_traffic.json, written by
+    tools/summarise_profiles.py): counters cannot be collected inside a timed run, so the line says where the number comes
+    from.  Looked up by (workload, database size); None when this size was not profiled."""
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        rec = json.load(open(tf))
-        rec = rec.get(key, rec) if isinstance(rec.get(key, None), dict) else rec
-        if rec.get("nseq") == nseq:
-            return rec.get("bytes_per_launch"), rec.get("source", "profiles/hbm_traffic.json (rocprofv3 --pmc pass of this "
-                                                                  "command, committed; not re-measured in this run)")
+        for rec in json.load(open(tf)).get("records", []):
+            if rec.get("workload") == key and rec.get("nseq") == nseq:
+                return rec.get("bytes_per_launch"), rec.get("source")
     except Exception:
         pass
     return None, None
@@ -351,7 +350,8 @@ def protein100m_section(a, local, nseq=100_000_000, steps=3):
     el = time.perf_counter() - t0
     k_ms = float(np.mean(kms))
     cells = nsym * len(q)
-    roof, valu = roofline_blocks(nsym, nseq, cells, k_ms, c["narrow_shifted"], c["narrow_rows"])
+    traffic, tsrc = committed_traffic("protein", nseq)
+    roof, valu = roofline_blocks(nsym, nseq, cells, k_ms, c["narrow_shifted"], c["narrow_rows"], traffic=traffic, traffic_source=tsrc)
     info = db.info()
     out = {"metric": "GCUPS, 375-aa query vs 100M-seq protein db (BASELINE.json configs[4]'s database) on ONE MI355X",
            "value": round(cells * steps / el / 1e9, 1), "unit": "GCUPS", "n_gpus": 1, "steps": steps, "warmup": 1,
@@ -596,7 +596,8 @@ def main():
         same = bool(np.array_equal(hits_x, hits) and tot_x == tot)
         if not same:
             raise SystemExit("bench: the bound build and the exact first pass disagree on the hit list")
-        r_x, v_x = roofline_blocks(nsym, n_local, nsym * len(q), k_x, c_x["narrow_shifted"], c_x["narrow_rows"])
+        tr_x, ts_x = committed_traffic("exact", n_local)
+        r_x, v_x = roofline_blocks(nsym, n_local, nsym * len(q), k_x, c_x["narrow_shifted"], c_x["narrow_rows"], traffic=tr_x, traffic_source=ts_x)
         exact = {"value": round(tot_sym * len(q) * a.steps / el_x / 1e9, 1), "unit": "GCUPS", "steps": a.steps,
                  "ms_per_step": round(el_x / a.steps * 1e3, 3), "ms_median": round(med_x * 1e3, 3),
                  "overhead_ms": round(el_x / a.steps * 1e3 - k_x, 3), "hits_identical": same, "roofline": r_x, "valu_roofline": v_x,

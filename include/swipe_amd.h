@@ -220,6 +220,10 @@ SWA_API int swa_set_option(swa_db* db, const char* key, const char* value);
 SWA_API int swa_kernel_choice(int64_t qlen, int want_bound, int64_t hi, int64_t gapopenextend, int64_t gapextend, int64_t longest,
                       double mean_len, int lanes, int32_t* G, int32_t* K, int32_t* bound, int32_t* predicted_gcups);
 SWA_API int swa_kernel_rate(int bound, int G, int K);
+/* the same for the two-query kernels (swa_search2*, swa_search_pair_topk, frame pairs): nres = 16 nucleotide alphabet, 32 others */
+SWA_API int swa_kernel_choice2(int nres, int64_t qlen, int want_bound, int64_t hi, int64_t gapopenextend, int64_t gapextend,
+                       int64_t longest, double mean_len, int lanes, int32_t* G, int32_t* K, int32_t* bound, int32_t* predicted_gcups);
+SWA_API int swa_kernel_rate2(int nres, int bound, int G, int K);
 
 /* ---- scoring ------------------------------------------------------------------------------ */
 /* matrix: 32*32 scores, index (db_symbol << 5) | query_symbol, as score_matrix_63

@@ -61,7 +61,7 @@ EXPORTS = [
     "swa_shard_bounds", "swa_blastdb_shard_bounds", "swa_group_open", "swa_group_from_memory", "swa_group_close", "swa_group_info",
     "swa_group_shard", "swa_group_set_scoring", "swa_group_set_option", "swa_group_set_inclusion", "swa_group_search",
     "swa_group_search_topk", "swa_group_search_pair_topk", "swa_group_search_frames_topk", "swa_group_align_hits",
-    "swa_group_db_sequence", "swa_kernel_choice", "swa_kernel_rate",
+    "swa_group_db_sequence", "swa_kernel_choice", "swa_kernel_rate", "swa_kernel_choice2", "swa_kernel_rate2",
 ]
 
 _lib = None
@@ -158,5 +158,7 @@ def load():
     L.swa_group_db_sequence.argtypes = L.swa_db_sequence.argtypes
     L.swa_kernel_choice.argtypes = [i64, C.c_int, i64, i64, i64, i64, C.c_double, C.c_int] + [C.POINTER(C.c_int32)] * 4
     L.swa_kernel_rate.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.swa_kernel_choice2.argtypes = [C.c_int, i64, C.c_int, i64, i64, i64, i64, C.c_double, C.c_int] + [C.POINTER(C.c_int32)] * 4
+    L.swa_kernel_rate2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L

@@ -21,6 +21,7 @@
 
 namespace swa {
 int lg(int G);
+const unsigned short (*dual_table(bool bound, int nres))[64];
 int64_t f16_exact_limit(int64_t hi, int64_t ge, int K) { return 2048 - hi - int64_t(K + 1) * ge; }
 
 // Chains shorter than a DPP row isolate neighbouring sequences by multiplying what a chain's last lane sends by zero: a
@@ -83,6 +84,53 @@ KernelPick pick_first_pass(const ChoiceEnv& e)
   }
   return best;
 }
+
+// ---- two queries per pass ---------------------------------------------------------------------------------------------
+const unsigned short (*dual_table(bool bound, int nres))[64]
+{
+  return bound ? (nres == 32 ? kRateDualbound32 : nullptr) : nres == 16 ? kRateDual16 : kRateDual32;
+}
+
+bool dual_build_exists(bool bound, int nres, int G, int K)
+{
+  const unsigned short (*t)[64] = dual_table(bound, nres);
+  if (!t || K < 1 || K > 63 || (G != 1 && G != 2 && G != 4 && G != 8 && G != 16)) return false;
+  return t[lg(G)][K] != 0;
+}
+
+KernelPick pick_dual(const ChoiceEnv& e, int nres, int kmax)
+{
+  KernelPick best;
+  if (e.qlen < 1) return best;
+  auto consider = [&](bool bound, int G) {
+    const int64_t K64 = (e.qlen + G - 1) / G;
+    if (K64 > 63) return;
+    const int K = int(K64);
+    if (!dual_build_exists(bound, nres, G, K)) return;
+    if (kmax > 0 && K > kmax) return;
+    if (!e.long_lanes && K > 32 && G != 16) return;                       // option "long_lanes" = 0
+    if (f16_exact_limit(e.hi, e.ge, bound ? K + e.bound_period : K) < 1024) return;
+    if (G > 1 && G < 16 && !chains_isolated(e.qlen, e.longest, e.hi, e.goe, e.ge)) return;
+    const double rate = dual_table(bound, nres)[lg(G)][K];
+    const double L = std::max(8.0, e.mean_len), L0 = 325.0;
+    const double skew = G == 1 ? 1.0 : ((L0 + G) / L0) * (L / (L + G));
+    const int p = int(rate * double(e.qlen) / double(G * K) * skew);
+    if (p > best.predicted_gcups) best = KernelPick{G, K, bound, p};
+  };
+  if (e.lanes > 0) {
+    int G = e.lanes >= 16 ? 16 : e.lanes >= 8 ? 8 : e.lanes >= 4 ? 4 : e.lanes >= 2 ? 2 : 1;
+    for (; G <= 16 && best.G == 0; G *= 2) {
+      if (e.want_bound) consider(true, G);
+      if (best.G == 0) consider(false, G);
+    }
+    return best;
+  }
+  for (int G = 1; G <= 16; G *= 2) {
+    if (e.want_bound) consider(true, G);
+    consider(false, G);
+  }
+  return best;
+}
 }  // namespace swa
 
 // diagnostic entry point of the C ABI: the build a search of this query would run (no device needed)
@@ -108,4 +156,28 @@ extern "C" int swa_kernel_choice(int64_t qlen, int want_bound, int64_t hi, int64
 extern "C" int swa_kernel_rate(int bound, int G, int K)
 {
   return swa::build_exists(bound != 0, G, K) ? int((bound ? kRateBound : kRateExact)[swa::lg(G)][K]) : 0;
+}
+
+extern "C" int swa_kernel_choice2(int nres, int64_t qlen, int want_bound, int64_t hi, int64_t gapopenextend, int64_t gapextend,
+                                  int64_t longest, double mean_len, int lanes, int32_t* G, int32_t* K, int32_t* bound,
+                                  int32_t* predicted_gcups)
+{
+  swa::ChoiceEnv e;
+  e.qlen = qlen;
+  e.want_bound = want_bound != 0;
+  e.hi = hi; e.goe = gapopenextend; e.ge = gapextend;
+  e.longest = longest;
+  e.mean_len = mean_len > 0 ? mean_len : 325.0;
+  e.lanes = lanes;
+  const swa::KernelPick p = swa::pick_dual(e, nres == 16 ? 16 : 32, 0);
+  if (G) *G = p.G;
+  if (K) *K = p.K;
+  if (bound) *bound = p.bound ? 1 : 0;
+  if (predicted_gcups) *predicted_gcups = p.predicted_gcups;
+  return SWA_OK;
+}
+
+extern "C" int swa_kernel_rate2(int nres, int bound, int G, int K)
+{
+  return swa::dual_build_exists(bound != 0, nres == 16 ? 16 : 32, G, K) ? int(swa::dual_table(bound != 0, nres == 16 ? 16 : 32)[swa::lg(G)][K]) : 0;
 }

@@ -26,5 +26,9 @@ int64_t f16_exact_limit(int64_t hi, int64_t ge, int K);                 // score
 bool chains_isolated(int64_t qlen, int64_t longest, int64_t hi, int64_t goe, int64_t ge);   // see short_chains_safe
 bool build_exists(bool bound, int G, int K);
 KernelPick pick_first_pass(const ChoiceEnv& e);
+// the same rule for the two-query kernels (both strands of a nucleotide query, two protein queries or frames): nres = 16 for
+// the nucleotide alphabet, 32 otherwise; kmax > 0 caps the rows per lane (option "dual_kmax")
+bool dual_build_exists(bool bound, int nres, int G, int K);
+KernelPick pick_dual(const ChoiceEnv& e, int nres, int kmax);
 }  // namespace swa
 #endif

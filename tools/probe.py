@@ -8,6 +8,8 @@
     python tools/probe.py rates [--nseq N]
         kernel GCUPS of EVERY (G, K) build of the one-query first pass, exact and bound, at qlen = G x K: the measured
         table tools/gen_kernel_table.py turns into swipe_amd/csrc/kernel_rates.inc (the kernel selection is its argmax)
+    python tools/probe.py rates2 [--nseq N]
+        the same for the two-query kernels (nucleotide both strands; protein pairs exact and bound)
     python tools/probe.py table [--max 1100]
         the kernel-selection table as the library resolves it (no GPU needed): qlen -> (form, G, K) for exact / top-K
     python tools/probe.py longest [--nseq N] QLEN ...
@@ -116,6 +118,39 @@ def cmd_rates(a):
     db.close()
 
 
+def cmd_rates2(a):
+    """every build of the TWO-query first pass (both strands of a nucleotide query; two protein queries / frames) at
+    qlen = G x K: the second input of tools/gen_kernel_table.py"""
+    print(f"# two-query kernels: GCUPS (both queries counted) of every (G, K) build at qlen = G x K, {a.nseq} sequences, best of {a.reps}")
+    print("# mode G K qlen gcups form")
+    for nt in (True, False):
+        db, full, nsym = make_db(a.nseq, nt)
+        kone = 48 if nt else 32
+        for mode, topk in ((("dual16" if nt else "dual32"), 0),) + ((("dualbound32", 80),) if not nt else ()):
+            db.set_option("bound", 1 if topk else 0)
+            for G in (1, 2, 4, 8, 16):
+                db.set_option("lanes", G)
+                kmax = kone if G == 1 else 32 if (G == 2 or not nt) and not topk else 63 if G == 16 else 62 if topk else 60
+                for K in range(1, kmax + 1):
+                    qlen = G * K
+                    q = full[:qlen]
+                    q2 = blast_rc(q) if nt else np.ascontiguousarray(q[::-1])
+                    best, c = 1e9, None
+                    for _ in range(a.reps + 1):
+                        c = db.search2_topk(q, q2, keep=250, minscore=topk)[3] if topk else db.search2(q, q2, want_scores=False)[2]
+                        best = min(best, c["kernel_ms"])
+                    want = 10 if topk else (12 if G == 1 else 4)
+                    if c["narrow_shifted"] != want or c["narrow_rows"] != K:
+                        continue
+                    print("%s %2d %2d %4d %6.0f %2d" % (mode, G, K, qlen, c["cells"] / best / 1e6, c["narrow_shifted"]), flush=True)
+        db.close()
+
+
+def blast_rc(q):
+    from swipe_amd import blastdb
+    return blastdb.revcomp_nt16(q)
+
+
 def cmd_table(a):
     import ctypes as C
     from swipe_amd import _lib
@@ -153,6 +188,10 @@ def main():
     p.add_argument("--nseq", type=int, default=4_000_000)
     p.add_argument("--reps", type=int, default=2)
     p.set_defaults(fn=cmd_rates)
+    p = sub.add_parser("rates2")
+    p.add_argument("--nseq", type=int, default=4_000_000)
+    p.add_argument("--reps", type=int, default=2)
+    p.set_defaults(fn=cmd_rates2)
     p = sub.add_parser("table")
     p.add_argument("--max", type=int, default=1100)
     p.add_argument("--all", action="store_true")

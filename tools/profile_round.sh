@@ -1,24 +1,33 @@
 #!/bin/bash
-# Round profile on the GPU box (run through gpurun): bench line, rocprofv3 kernel stats, PMC passes.
-# FETCH_SIZE and WRITE_SIZE do not fit one pass (TCC has 4 slots, they cost 3 + 2).
-# Counters are collected in their own passes with --kernel-trace only (never with sys/hip/hsa traces).
-# Outputs land in gpurun_out/profile/; tools/summarize_profile.py turns them into profiles/<round>_*.
-set -u
-R=${1:-r01}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/profile
-mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
-python bench.py --steps 5 --warmup 1 > $OUT/bench_line.json 2> $OUT/bench.err
-export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1)
+# rocprofv3 evidence for profiles/ (round 3).  Run on the GPU box:  bash tools/profile_round.sh [--quick]
+#   1. kernel stats of the default bench command
+#   2. PMC passes, ONE counter group per pass, --kernel-trace only (never combined with other trace domains):
+#        VALU issue:  SQ_INSTS_VALU (instructions), SQ_ACTIVE_INST_VALU (quad-cycles the VALU works: = instructions when every
+#                     instruction takes one 4-cycle window, which is the packed-f16 recurrence), SQ_ACTIVE_INST_VALU2
+#                     (quad-cycles in which TWO 2-cycle-class instructions issued), GRBM_GUI_ACTIVE
+#        occupancy / stalls: SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES
+#        LDS / scalar / memory instructions, then the three TCC passes (HBM traffic)
+#   3. FETCH_SIZE / WRITE_SIZE calibration on known byte counts at the access widths the kernels use (tools/ubench/fetch_calib.hip)
+# tools/summarise_profiles.py turns the output into profiles/r03_*.csv and profiles/hbm_traffic.json.
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof_r03
+rm -rf $O; mkdir -p $O
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-cold $1"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/bench_under_stats.json 2> $O/stats.err
 i=0
-for G in "FETCH_SIZE" "WRITE_SIZE" "GRBM_COUNT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
-         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
-         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
+for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_WAVES GRBM_GUI_ACTIVE" \
+           "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/pmc$i -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $OUT/pmc$i.log 2>&1)
+  timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc$i -- $CMD > $O/bench_under_pmc$i.json 2> $O/pmc$i.err
+  echo "pass $i ($grp) rc=$?"
 done
-python tools/summarize_profile.py $OUT $R > $OUT/summary.log 2>&1
-cat $OUT/bench_line.json; tail -5 $OUT/summary.log
+for grp in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/calib$i -- ./tools/ubench/fetch_calib.bin > $O/calib$i.txt 2> $O/calib$i.err
+  echo "calibration pass $i ($grp) rc=$?"
+done
+find $O -name "*.csv" | wc -l
+du -sh $O

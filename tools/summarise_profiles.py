@@ -1,70 +1,151 @@
-"""gpurun_out/prof_r02 (tools/gpu_profile.sh) -> profiles/r02_kernel_stats_bench.csv, profiles/r02_pmc_bench.csv,
-profiles/hbm_traffic.json.  Run in the build container after the GPU call merged its output back."""
+"""gpurun_out/prof_r03 (tools/profile_round.sh) -> profiles/r03_kernel_stats_bench.csv, profiles/r03_pmc_bench.csv,
+profiles/r03_fetch_calibration.txt, profiles/hbm_traffic.json.  Run in the build container after the GPU call merged its
+output back.  Launches of one kernel over databases of different size (the 10 M-sequence headline and the 100 M-sequence
+secondary section run the same build) are told apart by the counter's magnitude."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r02")
+src = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "prof_r03")
 out = os.path.join(ROOT, "profiles")
+CMD = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-cold"
+NSIMD = 1024
+
 
 def short(name):
     return re.sub(r"\(.*", "", name).replace("void ", "").strip()
 
+
 # --- kernel stats
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
-rows = []
 if stats:
-    for r in csv.DictReader(open(stats[0])):
-        rows.append(r)
-    with open(os.path.join(out, "r02_kernel_stats_bench.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-cold\n")
-        f.write("# (protein headline 1 + 3 steps, exact first pass 1 + 3 steps, nucleotide secondary 1 + 3 steps, pair section: two 375-aa queries\n")
-        f.write("# per pass = swa_dual_bound_kernel 1 + 3 steps, then each of the two alone through swa_narrow_bound_kernel; durations in ns)\n")
-        f.write("# Calls = 1 untimed warm-up + 3 timed steps: bench.py reports the mean of the timed ones (AverageNs within 0.3 % of it).\n")
-        f.write("# swa_requeue_follow_kernel runs BESIDE the first-pass kernel on a second stream (DESIGN.md 4.10): its duration is its\n")
-        f.write("# lifetime = the producer's, not work; swa_requeue_wave_kernel is the finishing kernel after it.\n")
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, "r03_kernel_stats_bench.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {CMD}\n")
+        f.write("# sections of the default run: protein headline (10 M sequences, bound first pass, 1 + 1 + 2 launches), the same with the exact\n")
+        f.write("# first pass (swa_narrow_split_kernel), nucleotide secondary (50 M sequences, swa_dual_kernel), 100 M proteins on one GPU (the\n")
+        f.write("# same swa_narrow_bound_kernel build as the headline: its AverageNs mixes 105 ms and 1 048 ms launches - the per-size means\n")
+        f.write("# are in r03_pmc_bench.csv), pair section (swa_dual_bound_kernel).  Durations in ns.\n")
         cols = list(rows[0].keys())
         f.write(",".join(cols) + "\n")
-        for r in rows[:14]:
+        for r in rows[:16]:
             f.write(",".join('"%s"' % r[c] if c == "Name" else r[c] for c in cols) + "\n")
     print("kernel stats:", len(rows), "kernels")
-    for r in rows[:6]:
-        print("  %-70s calls %4s avg %12s ns" % (short(r["Name"])[:70], r["Calls"], r.get("AverageNs", r.get("Average", "?"))))
 
-# --- PMC: mean per launch per kernel
-pmc = defaultdict(lambda: defaultdict(list))
+# --- per-launch durations by kernel from the kernel trace of the stats run (to split by size)
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+
+# --- PMC: per kernel and size class, mean per launch
+raw = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-want = ("swa_narrow_bound_kernel", "swa_narrow_split_kernel", "swa_dual_kernel")
+        raw[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+want = ("swa_narrow_bound_kernel", "swa_narrow_split_kernel", "swa_dual_kernel", "swa_dual_bound_kernel")
+
+
+def classes(values):
+    """split a list of per-launch values into size classes (a factor of 3 apart)"""
+    lo = min(v for v in values if v > 0) if any(v > 0 for v in values) else 0
+    small = [v for v in values if v <= 3 * lo] if lo else values
+    big = [v for v in values if lo and v > 3 * lo]
+    return small, big
+
+
 lines = []
-traffic = {}
-for k in sorted(pmc):
+for k in sorted(raw):
     if not k.startswith(want):
         continue
-    c = {n: sum(v) / len(v) for n, v in pmc[k].items()}
-    n_launch = max(len(v) for v in pmc[k].values())
-    lines.append((k, n_launch, c))
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        traffic[k] = {"fetch_size_kb_raw": c["FETCH_SIZE"], "write_size_kb_raw": c["WRITE_SIZE"],
-                      "bytes_per_launch": int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)}
-with open(os.path.join(out, "r02_pmc_bench.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-cold\n")
-    f.write("# mean per launch; 10 M sequences (protein: 3 237 270 683 residues, 375-aa query; nucleotide: 3 237 408 910 bases, 1 kb query, both strands)\n")
-    f.write("kernel,launches,counter,value_per_launch\n")
-    for k, n, c in lines:
+    per = {"": {}, "big": {}}
+    for name, vals in raw[k].items():
+        ref = raw[k].get("SQ_INSTS_VALU") or raw[k].get("FETCH_SIZE") or vals
+        small, big = classes(vals) if name not in ("SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_VALU2") else (vals, [])
+        if name in ("SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_VALU2") and len(classes(ref)[1]):
+            nsmall = len(classes(ref)[0])
+            small, big = vals[:nsmall], vals[nsmall:]
+        per[""][name] = (sum(small) / len(small), len(small))
+        if big:
+            per["big"][name] = (sum(big) / len(big), len(big))
+    for cls in ("", "big"):
+        if per[cls]:
+            lines.append((k, cls, per[cls]))
+
+
+def label(k, cls):
+    if k.startswith("swa_dual_kernel"):
+        return "nucleotide 50 M sequences (16 187 M bases), 1 kb query, both strands"
+    if k.startswith("swa_dual_bound_kernel"):
+        return "protein 10 M sequences, two 375-aa queries per pass"
+    return "protein 100 M sequences (32 377 M residues), 375-aa query" if cls == "big" else "protein 10 M sequences (3 237 M residues), 375-aa query"
+
+
+traffic = []
+with open(os.path.join(out, "r03_pmc_bench.csv"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --pmc <group> (one group per pass, 6 passes) -- {CMD}\n")
+    f.write("# mean per launch.  SQ_* values are sums over all 1 024 SIMDs (GRBM_GUI_ACTIVE over the 8 XCDs); SQ_ACTIVE_INST_*, SQ_BUSY_CU_CYCLES,\n")
+    f.write("# SQ_WAVE_CYCLES and SQ_WAIT_* are in QUAD-cycles (rocprofv3 -L), which is why SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU to the last\n")
+    f.write("# digit here: every VALU instruction of these kernels is of the 4-cycle class and occupies exactly one quad-cycle (round 2's\n")
+    f.write("# verdict asked which of the two was mislabelled: neither).  SQ_ACTIVE_INST_VALU2 = quad-cycles in which TWO 2-cycle-class\n")
+    f.write("# instructions issued.  Derived rows: valu_busy_pct = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES (VALU quad-cycles per SIMD-busy\n")
+    f.write("# quad-cycle), wave_* = share of SQ_WAVE_CYCLES a resident wave spends executing / waiting for issue / parked on s_waitcnt.\n")
+    f.write("kernel,workload,launches,counter,value_per_launch\n")
+    for k, cls, c in lines:
+        lab = label(k, cls)
+        n = max(v[1] for v in c.values())
         for name in sorted(c):
-            f.write('"%s",%d,%s,%.1f\n' % (k, n, name, c[name]))
-    f.write("# HBM bytes = FETCH_SIZE KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB x 1024\n")
-    for k, t in traffic.items():
-        f.write("# %s: %.3e bytes per launch\n" % (k, t["bytes_per_launch"]))
-rec = {}
-for k, t in traffic.items():
-    key = "protein" if k.startswith("swa_narrow_bound") else "exact" if k.startswith("swa_narrow_split") else "nucleotide"
-    rec[key] = dict(t, nseq=10_000_000, kernel=k, correction="FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
-                    source="profiles/r02_pmc_bench.csv (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)")
-if rec:
-    json.dump(rec, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
-print(json.dumps(rec, indent=1))
-for k, n, c in lines:
-    print(k, n, {a: "%.4g" % b for a, b in c.items()})
+            f.write('"%s","%s",%d,%s,%.1f\n' % (k, lab, c[name][1], name, c[name][0]))
+        g = lambda n_: c[n_][0] if n_ in c else None
+        if g("SQ_ACTIVE_INST_VALU") and g("SQ_BUSY_CU_CYCLES"):
+            f.write('"%s","%s",%d,%s,%.2f\n' % (k, lab, n, "derived:valu_busy_pct", 100 * g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CU_CYCLES")))
+            f.write('"%s","%s",%d,%s,%.3f\n' % (k, lab, n, "derived:dual_issue_pct_of_valu", 100 * g("SQ_ACTIVE_INST_VALU2") / g("SQ_ACTIVE_INST_VALU")))
+        if g("SQ_WAVE_CYCLES"):
+            for nm, key in (("wave_executing_pct", "SQ_ACTIVE_INST_ANY"), ("wave_waiting_for_issue_pct", "SQ_WAIT_INST_ANY"), ("wave_parked_pct", "SQ_WAIT_ANY")):
+                f.write('"%s","%s",%d,%s,%.2f\n' % (k, lab, n, "derived:" + nm, 100 * g(key) / g("SQ_WAVE_CYCLES")))
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            b = int(g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE") * 1024)
+            f.write('"%s","%s",%d,%s,%d\n' % (k, lab, n, "derived:hbm_bytes", b))
+            wl = "nucleotide" if k.startswith("swa_dual_kernel") else "pair" if k.startswith("swa_dual_bound") else \
+                 "exact" if k.startswith("swa_narrow_split") else "protein"
+            nseq = 50_000_000 if wl == "nucleotide" else 100_000_000 if cls == "big" else 10_000_000
+            traffic.append({"workload": wl, "nseq": nseq, "kernel": k, "fetch_size_kb_raw": g("FETCH_SIZE"), "write_size_kb_raw": g("WRITE_SIZE"),
+                            "bytes_per_launch": b,
+                            "correction": "FETCH_SIZE x 2 (calibrated on this kernel's 2-byte-per-lane coalesced loads: factor 2.000, "
+                                          "profiles/r03_fetch_calibration.txt); WRITE_SIZE as reported (a scattered 4-byte store counts 32 B)",
+                            "source": "profiles/r03_pmc_bench.csv (rocprofv3 --pmc passes of the default bench command, committed; not "
+                                      "re-measured in this run)"})
+if traffic:
+    json.dump({"records": traffic}, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+
+# --- calibration
+cal = defaultdict(dict)
+for f in glob.glob(os.path.join(src, "calib*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        cal[short(r["Kernel_Name"])].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if cal:
+    GIB = 1 << 30
+    with open(os.path.join(out, "r03_fetch_calibration.txt"), "w") as f:
+        f.write("# tools/ubench/fetch_calib.hip under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_*: every kernel moves a KNOWN number of bytes\n")
+        f.write("# (1 GiB, beyond the 256 MiB Infinity Cache); factor = bytes moved / (counter in KB x 1024)\n")
+        for k in sorted(cal):
+            if not k.startswith("calib_"):
+                continue
+            known = GIB
+            for name, vals in sorted(cal[k].items()):
+                v = sum(vals) / len(vals)
+                line = "%-34s %-22s %16.1f" % (k, name, v)
+                if name == "FETCH_SIZE" and "read" in k and v > 0:
+                    line += "   KB -> factor %.4f" % (known / (v * 1024))
+                if name == "WRITE_SIZE" and "write" in k and v > 0:
+                    stores = GIB // 64
+                    line += ("   KB -> factor %.4f" % (known / (v * 1024))) if "4c" in k else ("   KB = %.1f B per scattered 4-byte store" % (v * 1024 / stores))
+                if name.startswith("TCC_EA0_RDREQ") and "read" in k and v > 0:
+                    line += "   requests -> %.1f B each" % (known / v)
+                f.write(line + "\n")
+        f.write("# => FETCH_SIZE reports half the bytes at 16, 4 AND 2 bytes per lane (coalesced): the x 2 correction holds for the residue stream's\n")
+        f.write("#    128-byte-per-wave loads; TCC_EA0_RDREQ counts 128-byte requests.  WRITE_SIZE is exact for coalesced stores and counts 32 B for\n")
+        f.write("#    every scattered 4-byte store (one 32-byte masked write request) - the scores of a 10 M-sequence search show as 0.32 GB.\n")
+print(open(os.path.join(out, "r03_fetch_calibration.txt")).read() if cal else "no calibration data")
+for k, cls, c in lines:
+    print(k, cls or "10M", {a: "%.4g" % b[0] for a, b in c.items() if a in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")})
