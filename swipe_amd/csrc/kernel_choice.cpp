@@ -5,7 +5,7 @@
 // Now: kernel_rates.inc holds the MEASURED throughput of every build that exists - exact and bound, G = 1, 2, 4, 8, 16,
 // every K - at qlen = G x K (tools/probe.py rates on MI355X, profiles/r03_kernel_rates.txt), and a query of qlen rows
 // takes the build that maximises
-//     rate[G][K] x qlen / (G x K)            the padding rows of K = ceil(qlen / G) are computed but not wanted
+//     rate[G][K] x qlen / (G x K)            the padding rows of K >= ceil(qlen / G) are computed but not wanted
 //                x (L + G0) / (L + G)        the skew of a chain (G steps) is drained once per batch of mean length L;
 //                                            the table was measured at L0 = 325 (factor 1 there)
 // among the builds the scoring system allows (exact f16 range for K rows, isolation of short chains).  Occupancy steps,
@@ -61,13 +61,18 @@ KernelPick pick_first_pass(const ChoiceEnv& e)
 {
   KernelPick best;
   if (e.qlen < 1) return best;
+  // K = ceil(qlen / G) rows per lane - or up to three more where the table says the build of exactly K rows sits in a
+  // pothole (an occupancy step, a register-allocation accident: 2 x 33 exact rows run at 8.7 TCUPS, 2 x 35 at 9.5): the
+  // extra rows are padding like the G K - qlen there always are (profile rows past the query score -1).  A pinned chain
+  // length (option "lanes") takes exactly ceil(qlen / G): that is how the tests reach every instantiation.
   auto consider = [&](bool bound, int G) {
-    const int64_t K64 = (e.qlen + G - 1) / G;
-    if (K64 > 63) return;
-    const int K = int(K64);
-    if (!allowed(e, bound, G, K)) return;
-    const int p = predicted(e, bound, G, K);
-    if (p > best.predicted_gcups) best = KernelPick{G, K, bound, p};
+    const int64_t K0 = (e.qlen + G - 1) / G;
+    for (int64_t K64 = K0; K64 <= K0 + (e.lanes > 0 ? 0 : 3) && K64 <= 63; ++K64) {
+      const int K = int(K64);
+      if (!allowed(e, bound, G, K)) continue;
+      const int p = predicted(e, bound, G, K);
+      if (p > best.predicted_gcups) best = KernelPick{G, K, bound, p};
+    }
   };
   if (e.lanes > 0) {
     // option "lanes": that chain length if the query fits one of its builds, else the next longer one that does
@@ -103,19 +108,20 @@ KernelPick pick_dual(const ChoiceEnv& e, int nres, int kmax)
   KernelPick best;
   if (e.qlen < 1) return best;
   auto consider = [&](bool bound, int G) {
-    const int64_t K64 = (e.qlen + G - 1) / G;
-    if (K64 > 63) return;
-    const int K = int(K64);
-    if (!dual_build_exists(bound, nres, G, K)) return;
-    if (kmax > 0 && K > kmax) return;
-    if (!e.long_lanes && K > 32 && G != 16) return;                       // option "long_lanes" = 0
-    if (f16_exact_limit(e.hi, e.ge, bound ? K + e.bound_period : K) < 1024) return;
-    if (G > 1 && G < 16 && !chains_isolated(e.qlen, e.longest, e.hi, e.goe, e.ge)) return;
-    const double rate = dual_table(bound, nres)[lg(G)][K];
-    const double L = std::max(8.0, e.mean_len), L0 = 325.0;
-    const double skew = G == 1 ? 1.0 : ((L0 + G) / L0) * (L / (L + G));
-    const int p = int(rate * double(e.qlen) / double(G * K) * skew);
-    if (p > best.predicted_gcups) best = KernelPick{G, K, bound, p};
+    const int64_t K0 = (e.qlen + G - 1) / G;
+    for (int64_t K64 = K0; K64 <= K0 + (e.lanes > 0 ? 0 : 3) && K64 <= 63; ++K64) {     // see pick_first_pass
+      const int K = int(K64);
+      if (!dual_build_exists(bound, nres, G, K)) continue;
+      if (kmax > 0 && K > kmax) continue;
+      if (!e.long_lanes && K > 32 && G != 16) continue;                       // option "long_lanes" = 0
+      if (f16_exact_limit(e.hi, e.ge, bound ? K + e.bound_period : K) < 1024) continue;
+      if (G > 1 && G < 16 && !chains_isolated(e.qlen, e.longest, e.hi, e.goe, e.ge)) continue;
+      const double rate = dual_table(bound, nres)[lg(G)][K];
+      const double L = std::max(8.0, e.mean_len), L0 = 325.0;
+      const double skew = G == 1 ? 1.0 : ((L0 + G) / L0) * (L / (L + G));
+      const int p = int(rate * double(e.qlen) / double(G * K) * skew);
+      if (p > best.predicted_gcups) best = KernelPick{G, K, bound, p};
+    }
   };
   if (e.lanes > 0) {
     int G = e.lanes >= 16 ? 16 : e.lanes >= 8 ? 8 : e.lanes >= 4 ? 4 : e.lanes >= 2 ? 2 : 1;

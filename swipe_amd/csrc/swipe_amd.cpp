@@ -28,7 +28,6 @@
 
 extern "C" {
 int swa_narrow_rows_for(int qlen);
-int swa_narrow_rows_split(int qlen, int G);
 hipError_t swa_launch_narrow_split(int G, int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_one_a(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_one_b(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -38,7 +37,6 @@ hipError_t swa_launch_one_bound_e(int K, const swa_narrow_params* p, int blocks,
 hipError_t swa_launch_narrow_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_dual_pass(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_dual_bound(int G, int K, const swa_mp_params* p, int cus, hipStream_t st);
-int swa_dual_bound_available(int G, int K, int nres);
 hipError_t swa_launch_narrow_bound_pass(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g2(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g4(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
@@ -48,7 +46,6 @@ hipError_t swa_launch_narrow_bound_long4(int K, const swa_narrow_params* p, int 
 hipError_t swa_launch_narrow_bound_long8(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 hipError_t swa_launch_narrow_bound_g16(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_bound_period(void);
-int swa_bound_available(int G, int K);
 hipError_t swa_launch_gather(const swa_seqs* sq, const int* ids, const int64_t* out_off, int n, uint8_t* out, hipStream_t st);
 hipError_t swa_launch_narrow(int K, const swa_narrow_params* p, int blocks, hipStream_t st);
 int swa_mp_waves(int mode, int K);
@@ -63,10 +60,8 @@ hipError_t swa_launch_endpoints_wave(const swa_seqs* sq, const int32_t* ids,
 hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
 hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
-int swa_dual_rows_for(int qlen, int nres, int G);
 hipError_t swa_launch_dual(int K, int nres, int G, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_dual_one(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
-int swa_dual_one_rows(int nres);
 hipError_t swa_launch_mp(int mode, int K, const swa_mp_params* p, int blocks, int threads, hipStream_t st);
 hipError_t swa_launch_format(const swa_seqs* sq, const int32_t* slots, const swa_batch* batches, int nbatches, void* stream,
                              int nibbles, hipStream_t st);
@@ -1043,7 +1038,6 @@ int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, h
 constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] blocks finished | [32] done flag (polled)
 constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
-constexpr int BOUND_LONG_ROWS = 62;         // longest lane of the bound build on 2-, 4- and 8-lane chains (sw_cb_long*.hip)
 
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
@@ -1225,15 +1219,6 @@ bool f16_applicable(const swa_db* db)
   return db->hi >= 0 && db->hi < 512 && db->lo > -1024 && db->goe >= db->ge && db->goe <= 1024 && db->ge >= 0 &&
          db->ge <= 16;
 }
-// Chains shorter than a DPP row isolate neighbouring sequences by multiplying what a chain's last lane sends by zero
-// (v_pk_fma_f16): a state that overflowed to +-inf would turn that zero into NaN and poison the NEIGHBOUR, whose score
-// would then read 0 and never be re-queued.  f16 reaches inf beyond 65504; every value is bounded by
-// min(qlen, longest) x hi + the row / column bias, so such searches take 16-lane chains (zero fill by DPP, no product).
-bool short_chains_safe(const swa_db* db, int64_t qlen)
-{
-  return swa::chains_isolated(qlen, db->longest, db->hi, db->goe, db->ge);
-}
-
 // What a search has enqueued and not yet seen on the host
 struct Pending {
   swa_counters_t c{};
@@ -1513,30 +1498,23 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   // option "dual_mp" = 1 forces the multi-pass kernel (A/B, tests)
   const int nres = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 16 : 32;
   const bool dual_mp = db->opt.dual_mp == 1;
-  // chains of 4 / 8 lanes (several sequences per DPP row, from the pair stream) for short queries, as in run_search
-  // ... and ONE lane per sequence (sw_one_dual.hip) for queries of at most 48 nucleotide / 32 other rows: no chain at all
-  const int64_t one_rows = swa_dual_one_rows(nres);
-  // (nucleotide: 4- and 8-lane chains carry up to 60 rows per lane, sw_dual_long4/8.hip - the registers and the 16-symbol
-  // table that give the 16-lane build its 63 - so 129..240 rows run on 4 lanes and 257..480 on 8; "long_lanes" = 0: 32)
-  const int lane_rows = nres == 16 && db->opt.long_lanes != 0 ? 60 : 32;
-  int Gd = qlen <= one_rows ? 1 : qlen <= 2 * 32 ? 2 : qlen <= 4 * lane_rows ? 4 : qlen <= 8 * lane_rows ? 8 : 16;
-  if (db->opt.lanes > 0) {
-    Gd = db->opt.lanes >= 16 ? 16 : db->opt.lanes >= 8 ? 8 : db->opt.lanes >= 4 ? 4 : db->opt.lanes >= 2 ? 2 : 1;
-    if (Gd == 1 && qlen > one_rows) Gd = 2;
-    while (Gd > 1 && Gd < 16 && qlen > Gd * (Gd >= 4 ? lane_rows : 32)) Gd *= 2;
-  }
-  if (Gd > 1 && Gd < 16 && !short_chains_safe(db, qlen)) Gd = 16;
-  int Kd = dual_mp ? 0 : Gd == 1 ? int(qlen) : swa_dual_rows_for(int(std::min<int64_t>(qlen, 4096)), nres, Gd);
-  // Pairs whose search takes the bound build (sw_cb_dual_*.hip, two state registers per row) run on chains of up to 62
-  // rows per lane: 129..248 rows on 4 lanes instead of 8, 257..496 on 8 instead of 16 - half the hand-overs per row and
-  // half the skew.  (The exact two-query kernel stops at 32 rows - three state registers per row - so whatever switches
-  // the bound build off falls back to the shorter lanes; option "long_lanes" = 0 does.)
-  if (!dual_mp && nres == 32 && Gd >= 8 && db->opt.long_lanes != 0 && (db->opt.lanes == 0 || db->opt.lanes == Gd / 2) &&
-      db->opt.dual_kmax == 0 && bound_wanted(db, qlen, bound_min) && short_chains_safe(db, qlen)) {
-    const int g = qlen <= 4 * BOUND_LONG_ROWS ? 4 : 8;
-    const int Kl = int((qlen + g - 1) / g);
-    if (g < Gd && qlen > g * 32 && swa_dual_bound_available(g, Kl, nres) && f16_limit(db, Kl + swa_bound_period()) >= 1024) { Gd = g; Kd = Kl; }
-  }
+  // Lanes per sequence Gd and rows per lane Kd of the single-pass two-query build: as in run_search the argmax over the
+  // measured table of every build that exists (kernel_choice.cpp pick_dual; profiles/r03_kernel_rates_dual.txt) - ONE lane
+  // per sequence up to 48 nucleotide / 32 other rows (sw_one_dual.hip), chains of 2 / 4 / 8 / 16 lanes beyond (nucleotide:
+  // up to 60..63 rows per lane; others 32), and for pairs of protein queries / frames in a top-K search the bound build
+  // (sw_cb_dual_*.hip: 17..62 rows on 4 and 8 lanes, 17..32 on 16).  No single-pass build: passes of the 16-lane kernel.
+  const int Nb = swa_bound_period();
+  swa::ChoiceEnv env;
+  env.qlen = qlen;
+  env.want_bound = bound_wanted(db, qlen, bound_min);
+  env.hi = db->hi; env.goe = db->goe; env.ge = db->ge;
+  env.longest = db->longest;
+  env.mean_len = db->h_order.empty() ? 325.0 : double(db->active_sym) / double(db->h_order.size());
+  env.lanes = int(db->opt.lanes);
+  env.long_lanes = db->opt.long_lanes != 0;
+  env.bound_period = Nb;
+  const swa::KernelPick pick = dual_mp ? swa::KernelPick{} : swa::pick_dual(env, nres, int(db->opt.dual_kmax));
+  const int Gd = pick.G ? pick.G : 16, Kd = pick.K;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
     rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
     if (rc != SWA_OK) return rc;
@@ -1574,8 +1552,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     p.negKR = f16_pair(-float(int64_t(Kd) * db->ge));
     for (int i = 0; i <= Kd + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
     // bound build (sw_cb_dual.hip) under the same rule as in run_search
-    const int Nb = swa_bound_period();
-    used_bound = Gd > 1 && bound_wanted(db, qlen, bound_min) && swa_dual_bound_available(Gd, Kd, nres) && f16_limit(db, Kd + Nb) >= 1024;
+    used_bound = pick.bound;
     // the re-queue follower beside the kernel, as in run_search: one grid, odd blocks on the second query's list
     // ... where the kernel leaves register room for its waves: the bound build (2 K + 40 registers) and exact builds of at most
     // 32 rows per lane.  Beside the 63-row nucleotide kernel (two waves x 256 registers) a follower that lands on a SIMD first
