@@ -15,6 +15,25 @@
     python tools/probe.py longest [--nseq N] QLEN ...
         where the time goes for short queries: kernel time with windows auto / off / forced small
 
+    python tools/probe.py streamed [args]
+        Database larger than its HBM budget: throughput of the streamed shard (two device slots, PCIe double buffering) vs the
+    python tools/probe.py pair [args]
+        Two different 375-aa queries per pass (swa_search_pair_topk) vs one query per pass, bench database and thresholds:
+    python tools/probe.py translated [args]
+        tblastn probe: 375-aa query against a synthetic nucleotide db held as its six translations.
+    python tools/probe.py cli [args]
+        End-to-end CLI on a query file: wall time per query against the search kernel's own time.
+    python tools/probe.py align [args]
+        How long does the alignment phase take?  250 hits of the 375-aa bench query, and a long-query / long-sequence
+    python tools/probe.py cold [args]
+        Cold path: BLAST v4 volumes on local disk -> swa_db_open (read + PCIe + format) -> first search.
+    python tools/probe.py follow [args]
+        A/B of the re-queue follower (second stream, beside the first pass): blocks of the follower vs first-pass kernel time
+    python tools/probe.py boundcheck [args]
+        At scale: top-250 hit lists of the bound build vs the exact first pass on the 10 M-sequence database, for queries of
+    python tools/probe.py diag [args]
+        stage-by-stage smoke with a watchdog: prints where a hang sits (faulthandler dumps the Python stack after 60 s)
+
 Prints plain text; run on the box through gpurun and redirect into gpurun_out/."""
 import argparse
 import os
@@ -167,6 +186,360 @@ def cmd_table(a):
                 last = cur
 
 
+# ---- specialised probes, folded in from the one-off scripts of rounds 1 and 2 (their positional arguments follow the sub-command) ----
+def cmd_streamed(a):
+    """Database larger than its HBM budget: throughput of the streamed shard (two device slots, PCIe double buffering) vs the
+resident one, bench query and thresholds."""
+    argv = ["probe.py streamed"] + list(a.args)
+
+    import sys, time, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 10_000_000
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    nsym = int(off[-1])
+    st = swipe_amd.stats_init(qlen=len(q), db_seqcount=nseq, db_symcount=nsym)
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+    out = {}
+    db = swipe_amd.Database.from_arrays(res, off)
+    full = db.info()["hbm_bytes"]
+    for label, budget in (("resident", 0), ("half", full // 2), ("quarter", full // 4), ("tenth", full // 10)):
+        if budget:
+            t = time.time()
+            db = swipe_amd.Database.from_arrays(res, off, hbm_budget=budget)
+            t_open = time.time() - t
+        else:
+            t_open = 0.0
+        db.set_scoring(M, 11, 1)
+        for mode in ("topk", "topk-exact"):
+            db.set_option("bound", None if mode == "topk" else 0)
+            hits = db.search_topk(q, keep=250, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
+            t = time.perf_counter()
+            for _ in range(4):
+                hits = db.search_topk(q, keep=250, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
+            dt = (time.perf_counter() - t) / 4
+            out.setdefault(mode, hits[:3])
+            print("%-9s %-10s budget %6.2f GB (device %5.2f GB, open %.1f s): %7.1f ms per search = %6.0f GCUPS, kernels %.1f ms, same hits %s" % (
+                label, mode, budget / 1e9, db.info()["hbm_bytes"] / 1e9, t_open, dt * 1e3, nsym * len(q) / dt / 1e9, hits[3]["kernel_ms"],
+                hits[:3] == out[mode]), flush=True)
+        db.close()
+
+
+def cmd_pair(a):
+    """Two different 375-aa queries per pass (swa_search_pair_topk) vs one query per pass, bench database and thresholds:
+aggregate GCUPS of a multi-query file."""
+    argv = ["probe.py pair"] + list(a.args)
+
+    import sys, time, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 10_000_000
+    q1 = blastdb.encode_protein(synth.QUERY_P07327)
+    rtab = synth.residue_table_protein()
+    q2 = synth._random_residues(4242, 1, 375, rtab)
+    q3 = synth._random_residues(4243, 1, 330, rtab)
+    res, off = swipe_amd.synth_db(1, nseq, query=q1)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    nsym = int(off[-1])
+    def thr(q):
+        st = swipe_amd.stats_init(qlen=len(q), db_seqcount=nseq, db_symcount=nsym)
+        return st.scorethreshold, st.upperscorethreshold
+    for a, b in ((q1, q2), (q1, q3)):
+        (la, ha), (lb, hb) = thr(a), thr(b)
+        singles = [db.search_topk(a, keep=250, minscore=la, maxscore=ha), db.search_topk(b, keep=250, minscore=lb, maxscore=hb)]
+        t = time.perf_counter()
+        for _ in range(3):
+            db.search_topk(a, keep=250, minscore=la, maxscore=ha)
+            db.search_topk(b, keep=250, minscore=lb, maxscore=hb)
+        t_single = (time.perf_counter() - t) / 3
+        r = db.search_pair_topk(a, b, keep=250, minscore=(la, lb), maxscore=(ha, hb))
+        t = time.perf_counter()
+        for _ in range(3):
+            r = db.search_pair_topk(a, b, keep=250, minscore=(la, lb), maxscore=(ha, hb))
+        t_pair = (time.perf_counter() - t) / 3
+        same = r[0][0] == singles[0][0] and r[1][0] == singles[1][0] and r[0][1] == singles[0][1] and r[1][1] == singles[1][1]
+        cells = nsym * (len(a) + len(b))
+        print("queries %d + %d aa: one per pass %.1f ms = %.0f GCUPS; paired %.1f ms = %.0f GCUPS (kernel %.1f ms, form %d, K %d); same hits %s" % (
+            len(a), len(b), t_single * 1e3, cells / t_single / 1e9, t_pair * 1e3, cells / t_pair / 1e9, r[2]["kernel_ms"],
+            r[2]["narrow_shifted"], r[2]["narrow_rows"], same), flush=True)
+
+
+def cmd_translated(a):
+    """tblastn probe: 375-aa query against a synthetic nucleotide db held as its six translations.
+Reports the one-time GPU translation pre-pass (HBM-bound) and the search rate, and checks a sample of
+(sequence, frame) scores against the oracle."""
+    argv = ["probe.py translated"] + list(a.args)
+
+    import os, sys, time, numpy as np
+    import swipe_amd, oracle
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 2_000_000
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(3, nseq, protein=False)
+    t = time.time()
+    db = swipe_amd.Database.from_arrays(res, off, translate_gencode=1)
+    load = time.time() - t
+    info = db.info()
+    print("translate+format %.3f s for %.3f G bases (%d sequences x 6 frames), hbm %.2f GB" % (load, info["symcount"] / 1e9, nseq, info["hbm_bytes"] / 1e9))
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    scores, c = db.search(q)
+    tab = oracle.translate_table(1)
+    pick = np.random.default_rng(2).integers(0, nseq, 300)
+    M = oracle.matrix_builtin("BLOSUM62")
+    fr = [oracle.translate(res[off[i]:off[i + 1]], t // 3, t % 3, tab) for i in pick for t in range(6)]
+    r2, o2 = oracle.pack(fr)
+    want = oracle.search_all63(r2, o2, q, M, 12, 1, threads=os.cpu_count())
+    got = np.concatenate([scores[6 * i: 6 * i + 6] for i in pick])
+    print("parity on %d (sequence, frame) pairs:" % len(want), np.array_equal(got, want))
+    for _ in range(3):
+        _, c = db.search(q, want_scores=False)
+        print("tblastn: %.0f GCUPS kernel (%.2f ms), total %.0f GCUPS, cells %.3e" % (c['cells'] / c['kernel_ms'] / 1e6, c['kernel_ms'], c['cells'] / c['total_ms'] / 1e6, c['cells']))
+    hits, tot, obv, c = db.search_frames_topk([q], keep=250, minscore=40)
+    print("top hit", hits[:3], "totalhits", tot)
+    for minscore in (60, 80):
+        best = None
+        for _ in range(3):
+            hits, tot, obv, c = db.search_frames_topk([q], keep=250, minscore=minscore)
+            if best is None or c["kernel_ms"] < best["kernel_ms"]: best = c
+        print("tblastn top-250, minscore %d: form %d K=%d kernel %.0f GCUPS, search %.0f GCUPS, totalhits %d" % (
+            minscore, best["narrow_shifted"], best["narrow_rows"], best["cells"] / best["kernel_ms"] / 1e6, best["cells"] / best["total_ms"] / 1e6, tot))
+
+
+def cmd_cli(a):
+    """End-to-end CLI on a query file: wall time per query against the search kernel's own time.
+Writes a synthetic BLAST v4 protein database to local disk, runs swipe_amd_cli on 1 and then N queries
+(-m 8 tabular and -m 0 with alignments) and reports (T_N - T_1) / (N - 1) = steady-state seconds per query."""
+    argv = ["probe.py cli"] + list(a.args)
+
+    import os, sys, time, tempfile, subprocess, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 10_000_000
+    nq = int(argv[2]) if len(argv) > 2 else 16
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    d = tempfile.mkdtemp(prefix="cli_", dir="/tmp")
+    nvol = max(1, int(np.ceil((off[-1] + nseq) / 3.5e9)))
+    names = []
+    for v in range(nvol):
+        lo, hi = nseq * v // nvol, nseq * (v + 1) // nvol
+        name = os.path.join(d, "db.%02d" % v)
+        blastdb.write_protein_volume_arrays(name, res, off[lo:hi + 1], first_id=lo)
+        names.append(name)
+    blastdb.write_alias(os.path.join(d, "db"), names, protein=True)
+    # queries: database sequences of about the bench query's length (so every one has real hits)
+    lens = np.diff(off)
+    pick = np.nonzero((lens > 330) & (lens < 420))[0][:: max(1, nseq // 200)][:nq]
+    sym = "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ"
+    def fasta(ids, path):
+        with open(path, "w") as f:
+            for i in ids:
+                f.write(">q%d\n%s\n" % (i, "".join(sym[c] for c in res[off[i]:off[i + 1]])))
+    fasta(pick[:1], os.path.join(d, "q1.fa"))
+    fasta(pick, os.path.join(d, "qn.fa"))
+    cli = os.path.join(os.path.dirname(swipe_amd.__file__), "swipe_amd_cli")
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    kms = []
+    for i in pick:
+        db.search_topk(res[off[i]:off[i + 1]], keep=250, minscore=80)
+        kms.append(db.search_topk(res[off[i]:off[i + 1]], keep=250, minscore=80)[3]["total_ms"])
+    db.close()
+    print("library search step (device time, top-250): mean %.1f ms per query over %d queries" % (np.mean(kms), len(pick)))
+    for mode, extra in (("-m 8", ["-m", "8"]), ("-m 0 (250 alignments)", ["-m", "0"]), ("-m 7 xml", ["-m", "7"])):
+        ts = []
+        for qf in ("q1.fa", "qn.fa"):
+            best = 1e9
+            for _ in range(2):
+                t = time.time()
+                r = subprocess.run([cli, "-d", os.path.join(d, "db"), "-i", os.path.join(d, qf), "-o", os.path.join(d, "out.txt")] + extra,
+                                   capture_output=True, text=True)
+                best = min(best, time.time() - t)
+                if r.returncode:
+                    print(r.stderr[-500:]); sys.exit(1)
+            ts.append(best)
+        per = (ts[1] - ts[0]) / (len(pick) - 1)
+        print("%-24s 1 query %.2f s, %d queries %.2f s -> %.1f ms per query in steady state (search step alone %.1f ms: %.0f %% of it)" % (
+            mode, ts[0], len(pick), ts[1], per * 1e3, np.mean(kms), 100 * np.mean(kms) / (per * 1e3)))
+    subprocess.run(["rm", "-rf", d])
+
+
+def cmd_align(a):
+    """How long does the alignment phase take?  250 hits of the 375-aa bench query, and a long-query / long-sequence
+worst case, through swa_align_hits (GPU end points + host traceback)."""
+    argv = ["probe.py align"] + list(a.args)
+
+    import sys, time, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    nseq = int(argv[1]) if len(argv) > 1 else 1_000_000
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    hits, tot, obv, c = db.search_topk(q, keep=250, minscore=35)
+    ids = [h[0] for h in hits]
+    lens = np.diff(off)[ids]
+    for rep in range(2):
+        t = time.time(); e = db.search_endpoints(q, ids); t1 = time.time() - t
+        t = time.time(); al = db.align(q, ids); t2 = time.time() - t
+        print("250 hits (mean len %.0f, max %d): end points %.1f ms, whole alignment phase %.1f ms" % (lens.mean(), lens.max(), t1 * 1e3, t2 * 1e3))
+    # worst case: the 100 longest sequences, and a 3000-aa query
+    order = np.argsort(np.diff(off))[::-1][:100]
+    rtab = synth.residue_table_protein()
+    ql = synth._random_residues(5, 1, 3000, rtab)
+    for name, qq in (("375-aa", q), ("3000-aa", ql)):
+        t = time.time(); e = db.search_endpoints(qq, order); t1 = time.time() - t
+        print("%s query vs the 100 longest sequences (%d..%d aa): end points %.1f ms" % (name, np.diff(off)[order].min(), np.diff(off)[order].max(), t1 * 1e3))
+
+
+def cmd_cold(a):
+    """Cold path: BLAST v4 volumes on local disk -> swa_db_open (read + PCIe + format) -> first search."""
+    argv = ["probe.py cold"] + list(a.args)
+
+    import os, sys, time, tempfile, subprocess, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 10_000_000
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    d = tempfile.mkdtemp(prefix="cold_", dir="/tmp")
+    nvol = max(1, int(np.ceil((off[-1] + nseq) / 3.5e9)))
+    t = time.time()
+    names = []
+    for v in range(nvol):
+        lo, hi = nseq * v // nvol, nseq * (v + 1) // nvol
+        name = os.path.join(d, "db.%02d" % v)
+        blastdb.write_protein_volume_arrays(name, res, off[lo:hi + 1], first_id=lo)
+        names.append(name)
+    blastdb.write_alias(os.path.join(d, "db"), names, protein=True)
+    print("wrote %d volumes, %.2f GB in %.1f s" % (nvol, (off[-1] + nseq) / 1e9, time.time() - t))
+    os.sync()
+    try:
+        open("/proc/sys/vm/drop_caches", "w").write("3\n")
+        dropped = True
+    except Exception:
+        dropped = False
+    for rep in range(2):
+        t = time.time()
+        db = swipe_amd.Database.open(os.path.join(d, "db"))
+        t_open = time.time() - t
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+        t = time.time()
+        hits, tot, obv, c = db.search_topk(q, keep=250, minscore=40)
+        t_search = time.time() - t
+        print("%s open (disk -> HBM, formatted): %.2f s; first search %.3f s; top hit %s" % ("cold" if rep == 0 and dropped else "warm page cache", t_open, t_search, hits[0]))
+        db.close()
+    subprocess.run(["rm", "-rf", d])
+
+
+def cmd_follow(a):
+    """A/B of the re-queue follower (second stream, beside the first pass): blocks of the follower vs first-pass kernel time
+and whole-step wall time, bench query on a shard of the bench database."""
+    argv = ["probe.py follow"] + list(a.args)
+
+    import os, sys, time, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 1_250_000
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    db = swipe_amd.Database.from_arrays(res, off, total_seqcount=10_000_000, total_symcount=3_237_270_683)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    st = swipe_amd.stats_init(qlen=len(q), db_seqcount=10_000_000, db_symcount=3_237_270_683)
+    ref = None
+    for rnd in range(2):
+        for follow in (0, 1, 32, 128, 256, 1024, 2048):
+            db.set_option("requeue_follow", follow)
+            db.search_topk_array(q, keep=250, minscore=st.scorethreshold)
+            t = time.perf_counter(); k = []
+            for _ in range(10):
+                hits, tot, obv, c = db.search_topk_array(q, keep=250, minscore=st.scorethreshold)
+                k.append(c["kernel_ms"])
+            wall = (time.perf_counter() - t) / 10 * 1e3
+            ref = hits if ref is None else ref
+            print("follow %5d: kernel %.3f ms  step %.3f ms  overhead %.3f  same hits %s  requeued %d" % (
+                follow, np.mean(k), wall, wall - np.mean(k), np.array_equal(hits, ref), c["wide"]), flush=True)
+
+
+def cmd_boundcheck(a):
+    """At scale: top-250 hit lists of the bound build vs the exact first pass on the 10 M-sequence database, for queries of
+many lengths (random ones and database sequences, which have real hits), E <= 10 thresholds from the statistics."""
+    argv = ["probe.py boundcheck"] + list(a.args)
+
+    import os, sys, time, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq = int(argv[1]) if len(argv) > 1 else 10_000_000
+    q0 = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q0)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    rtab = synth.residue_table_protein()
+    rng = np.random.default_rng(17)
+    lens = np.diff(off)
+    queries = [q0]
+    for L in (30, 45, 60, 90, 120, 180, 250, 330, 400, 520, 700, 900, 1100, 1700, 2600):
+        queries.append(synth._random_residues(1000 + L, 1, L, rtab))
+        cand = np.nonzero((lens > 0.9 * L) & (lens < 1.1 * L))[0]
+        i = int(cand[rng.integers(0, len(cand))])
+        queries.append(res[off[i]:off[i + 1]].copy())
+    bad = 0
+    for q in queries:
+        st = swipe_amd.stats_init(qlen=len(q), db_seqcount=nseq, db_symcount=int(off[-1]))
+        out = {}
+        for mode in ("0", None):
+            if mode: db.set_option("bound", mode)
+            else: db.set_option("bound", None)
+            t = time.time()
+            hits, tot, obv, c = db.search_topk(q, keep=250, minscore=st.scorethreshold, maxscore=st.upperscorethreshold)
+            out[mode] = (hits, tot, obv, c, time.time() - t)
+        same = out["0"][:3] == out[None][:3]
+        bad += not same
+        c = out[None][3]
+        print("qlen %4d threshold %3d: form %d K=%2d requeued %5d totalhits %5d  %.1f ms vs exact %.1f ms  %s" % (
+            len(q), st.scorethreshold, c["narrow_shifted"], c["narrow_rows"], c["wide"], out[None][1], c["total_ms"], out["0"][3]["total_ms"],
+            "same" if same else "DIFFERENT"), flush=True)
+    print("scale check done:", len(queries), "queries,", bad, "different")
+
+
+def cmd_diag(a):
+    """stage-by-stage smoke with a watchdog: prints where a hang sits (faulthandler dumps the Python stack after 60 s)"""
+    argv = ["probe.py diag"] + list(a.args)
+
+    import faulthandler, os, sys, time
+    faulthandler.dump_traceback_later(60, exit=True)
+    import numpy as np
+    def say(*a): print(time.strftime("%H:%M:%S"), *a, flush=True)
+    say("import")
+    import swipe_amd
+    from swipe_amd import blastdb, synth
+    say("devices", swipe_amd._lib.load().swa_device_count())
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, 4000, query=q)
+    say("synth")
+    db = swipe_amd.Database.from_arrays(res, off, device=0)
+    say("opened")
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    say("scoring")
+    for host, follow in ((1, 0), (0, 0), (0, 1)):
+        db.set_option("requeue_host", host)
+        db.set_option("requeue_follow", follow)
+        say("requeue_host", host, "follow", follow)
+        scores, c = db.search(q)
+        say("search", c)
+        hits, total, obvious, c = db.search_topk(q, keep=10, minscore=40)
+        say("topk", hits[:3], total, c)
+        db.set_option("bound", 1)
+        hits, total, obvious, c = db.search_topk(q, keep=10, minscore=40)
+        say("topk bound", hits[:3], total, c)
+        db.set_option("bound", None)
+    db.close()
+    say("done")
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -196,6 +569,33 @@ def main():
     p.add_argument("--max", type=int, default=1100)
     p.add_argument("--all", action="store_true")
     p.set_defaults(fn=cmd_table)
+    p = sub.add_parser("streamed")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_streamed)
+    p = sub.add_parser("pair")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_pair)
+    p = sub.add_parser("translated")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_translated)
+    p = sub.add_parser("cli")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_cli)
+    p = sub.add_parser("align")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_align)
+    p = sub.add_parser("cold")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_cold)
+    p = sub.add_parser("follow")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_follow)
+    p = sub.add_parser("boundcheck")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_boundcheck)
+    p = sub.add_parser("diag")
+    p.add_argument("args", nargs="*")
+    p.set_defaults(fn=cmd_diag)
     a = ap.parse_args()
     a.fn(a)
 
