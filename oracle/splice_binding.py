@@ -4,7 +4,7 @@ the binding of INTEGRATION.md section 2 - the prelude block plus binding A ("sco
 document, so the document IS the code that runs.  The patched text only ever exists in the pipe to the compiler
 (oracle/Makefile); no copy of a reference source is written anywhere.
 
-usage: splice_binding.py /root/reference/swipe.cc INTEGRATION.md scores|topk"""
+usage: splice_binding.py /root/reference/swipe.cc INTEGRATION.md scores|topk|group   (group = topk, built with -DSWIPE_AMD_GROUP)"""
 import re
 import sys
 
@@ -14,7 +14,7 @@ def blocks(doc):
 
 
 def binding(doc, variant):
-    guard = {"scores": "#ifdef SWIPE_AMD_SCORES", "topk": "#ifdef SWIPE_AMD_TOPK"}[variant]
+    guard = {"scores": "#ifdef SWIPE_AMD_SCORES", "topk": "#ifdef SWIPE_AMD_TOPK", "group": "#ifdef SWIPE_AMD_TOPK"}[variant]
     b = blocks(doc)
     prelude = next(x for x in b if x.startswith("#ifdef SWIPE_AMD\n"))
     body = next(x for x in b if x.startswith(guard))

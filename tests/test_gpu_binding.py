@@ -3,7 +3,7 @@ program - its own main(), option parsing, database reader, hits_init / hits_ente
 compiled from /root/reference by oracle/Makefile - with the body of search_chunk() (swipe.cc:1365-1596) replaced by the
 binding of INTEGRATION.md section 2 (cut out of the document at build time) and linked against libswipe_amd.so.  Their
 output must equal the golden output of the unmodified reference byte for byte: with one worker thread and with eight
-(chunks arriving concurrently), for protein / nucleotide / multi-volume / custom-matrix / 64-bit-score / translated
+(chunks arriving concurrently; swipe_bound_group = binding B over swa_group: -a N is then N shards, here all on device 0), for protein / nucleotide / multi-volume / custom-matrix / 64-bit-score / translated
 databases, OID masks and taxid lists, several queries per file."""
 import os
 import re
@@ -16,7 +16,7 @@ from conftest import ROOT, load_golden
 from swipe_amd import blastdb
 
 pytestmark = pytest.mark.gpu
-BOUND = {v: os.path.join(ROOT, "oracle", "_ref", "swipe_bound_" + v) for v in ("scores", "topk")}
+BOUND = {v: os.path.join(ROOT, "oracle", "_ref", "swipe_bound_" + v) for v in ("scores", "topk", "group")}
 
 
 def need(variant):
@@ -47,7 +47,7 @@ def case_args(tmp_path, name):
 
 
 @pytest.mark.parametrize("threads", [1, 8])
-@pytest.mark.parametrize("variant", ["scores", "topk"])
+@pytest.mark.parametrize("variant", ["scores", "topk", "group"])
 @pytest.mark.parametrize("name", ["p1k", "nt", "multivol", "asym", "edges", "limit16", "blastx", "tblastn", "tblastx"])
 def test_reference_bound_to_the_library_prints_the_reference_output(tmp_path, name, variant, threads):
     exe = need(variant)
@@ -63,7 +63,7 @@ def test_reference_bound_to_the_library_prints_the_reference_output(tmp_path, na
     assert t9[0] == want[0] and t9[1].startswith("# Database: ") and t9[2:] == want[2:]      # the database path differs
 
 
-@pytest.mark.parametrize("variant", ["scores", "topk"])
+@pytest.mark.parametrize("variant", ["scores", "topk", "group"])
 @pytest.mark.parametrize("hv", ["plain_gis_taxid", "masked", "masked_gis_taxid", "taxlist", "masked_taxlist"])
 def test_bound_reference_with_masks_and_taxid_lists(tmp_path, hv, variant):
     from test_host_cpu import build_headers_db, HEADER_VARIANTS
@@ -73,7 +73,7 @@ def test_bound_reference_with_masks_and_taxid_lists(tmp_path, hv, variant):
     dbn, flags, taxlist = HEADER_VARIANTS[hv]
     qf = str(tmp_path / "q.fa")
     open(qf, "w").write(">query test\n" + "".join(blastdb.NCBISTDAA[c] for c in case.query) + "\n")
-    args = [exe, "-d", vol if dbn == "vol" else masked, "-i", qf, "-v", str(case.keep), "-e", "1e6"]
+    args = [exe, "-d", vol if dbn == "vol" else masked, "-i", qf, "-v", str(case.keep), "-e", "1e6", "-a", "3"]      # group: 3 shards on device 0
     args += (["-I"] if flags & 1 else []) + (["-H"] if flags & 2 else []) + (["-x", tx] if taxlist else [])
     run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
     assert run(["-m", "7", "-b", "5"]) == ref["m7"]
@@ -82,7 +82,7 @@ def test_bound_reference_with_masks_and_taxid_lists(tmp_path, hv, variant):
     assert plain[plain.index("Sequences producing"):] == ref["m0"]
 
 
-@pytest.mark.parametrize("variant", ["scores", "topk"])
+@pytest.mark.parametrize("variant", ["scores", "topk", "group"])
 def test_bound_reference_with_a_query_file(tmp_path, variant):
     """the per-query reset (amd_queryno) over a file of several queries, an empty one among them"""
     exe = need(variant)

@@ -373,13 +373,13 @@ def test_integration_binding_compiles_against_the_reference(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import splice_binding
     src = open(ref).read()
-    for variant, guard in (("scores", "SWIPE_AMD_SCORES"), ("topk", "SWIPE_AMD_TOPK")):
+    for variant, guard in (("scores", "SWIPE_AMD_SCORES"), ("topk", "SWIPE_AMD_TOPK"), ("group", "SWIPE_AMD_TOPK -DSWIPE_AMD_GROUP")):
         binding = splice_binding.binding(doc, variant)
-        assert "hits_enter(" in binding and "swa_set_scoring(" in binding and "pthread_mutex_lock" in binding
-        assert ("swa_search(" in binding) == (variant == "scores") and ("swa_search_frames_topk(" in binding) == (variant == "topk")
+        assert "hits_enter(" in binding and "amd_set_scoring(" in binding and "pthread_mutex_lock" in binding
+        assert ("swa_search(" in binding) == (variant == "scores") and ("amd_search_frames_topk(" in binding) == (variant != "scores")
         work = tmp_path / f"swipe_patched_{variant}.cc"
         work.write_text(splice_binding.splice(src, binding))
-        cmd = ["g++", "-fsyntax-only", "-w", "-DSWIPE_AMD", "-D" + guard, "-I", "/root/reference", "-I", os.path.join(ROOT, "include"), str(work)]
+        cmd = ["g++", "-fsyntax-only", "-w", "-DSWIPE_AMD"] + ["-D" + guard.split()[0]] + guard.split()[1:] + ["-I", "/root/reference", "-I", os.path.join(ROOT, "include"), str(work)]
         out = subprocess.run(cmd, capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[:3000]
     # the alignment-phase and multi-query snippets are statement fragments: check that the entry points they name exist
@@ -519,7 +519,7 @@ def test_bound_reference_binaries_have_no_cpu_path(tmp_path):
     start, parse SWIPE's options, open the database with the reference's own db_open - and, without a device, stop in the
     binding's amd_open with the library's error through SWIPE's fatal(): linked, called, and no fallback to search7."""
     import subprocess
-    exes = [os.path.join(ROOT, "oracle", "_ref", "swipe_bound_" + v) for v in ("scores", "topk")]
+    exes = [os.path.join(ROOT, "oracle", "_ref", "swipe_bound_" + v) for v in ("scores", "topk", "group")]
     if not all(os.path.exists(e) for e in exes):
         pytest.skip("needs oracle/_ref (built where /root/reference is present)")
     if _lib.load().swa_device_count() > 0:
