@@ -33,6 +33,8 @@
         At scale: top-250 hit lists of the bound build vs the exact first pass on the 10 M-sequence database, for queries of
     python tools/probe.py diag [args]
         stage-by-stage smoke with a watchdog: prints where a hang sits (faulthandler dumps the Python stack after 60 s)
+    python tools/probe.py group [--nseq N]
+        what the swa_group layer costs on one GPU: plain handle vs groups of 1 / 2 / 4 / 8 shards on device 0
 
 Prints plain text; run on the box through gpurun and redirect into gpurun_out/."""
 import argparse
@@ -540,6 +542,41 @@ def cmd_diag(a):
     say("done")
 
 
+def cmd_group(a):
+    """swa_group on ONE GPU: what the layer itself costs.  The bench step (top-250, thresholds of the database) through a plain
+    handle, through a group of one shard (worker-thread hand-over + merge on top), and through groups of 2 / 4 / 8 shards that
+    all live on device 0 (N handles, N host threads, N stream sets time-sharing one GPU: the kernels of the shards overlap, so
+    the wall time shows what N-fold smaller kernels and their tails cost, not a speed-up)."""
+    import time
+    import swipe_amd
+    from swipe_amd import blastdb, synth
+    nseq = a.nseq
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    nsym = int(off[-1])
+    st = swipe_amd.stats_init(qlen=len(q), db_seqcount=nseq, db_symcount=nsym)
+    M = swipe_amd.matrix_builtin("BLOSUM62")
+
+    def timed(db):
+        db.set_scoring(M, 11, 1)
+        for _ in range(3):
+            r = db.search_topk(q, 250, st.scorethreshold, st.upperscorethreshold)
+        t = time.perf_counter()
+        for _ in range(a.reps):
+            r = db.search_topk(q, 250, st.scorethreshold, st.upperscorethreshold)
+        return (time.perf_counter() - t) / a.reps * 1e3, r
+    one = swipe_amd.Database.from_arrays(res, off)
+    ms, ref = timed(one)
+    one.close()
+    print(f"# {nseq} sequences, {a.reps} searches each; wall time per search (Python call included)")
+    print("plain handle          %8.3f ms  %7.0f GCUPS" % (ms, nsym * len(q) / ms / 1e6))
+    for shards in (1, 2, 4, 8):
+        g = swipe_amd.Group.from_arrays(res, off, devices=(0,) * shards)
+        gms, r = timed(g)
+        g.close()
+        print("group of %d on dev 0   %8.3f ms  %7.0f GCUPS   same hits %s   (+%.3f ms)" % (shards, gms, nsym * len(q) / gms / 1e6, r[:3] == ref[:3], gms - ms))
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -596,6 +633,10 @@ def main():
     p = sub.add_parser("diag")
     p.add_argument("args", nargs="*")
     p.set_defaults(fn=cmd_diag)
+    p = sub.add_parser("group")
+    p.add_argument("--nseq", type=int, default=10_000_000)
+    p.add_argument("--reps", type=int, default=10)
+    p.set_defaults(fn=cmd_group)
     a = ap.parse_args()
     a.fn(a)
 
