@@ -96,3 +96,26 @@ def test_bound_reference_with_a_query_file(tmp_path, variant):
         r = subprocess.run([exe, "-d", base, "-i", qf, "-m", "8", "-b", "10", "-v", "12", "-e", "1000", "-a", threads], capture_output=True, text=True)
         assert r.returncode == g["rc8"], r.stderr
         assert r.stdout == g["m8"]
+
+
+def _option_runs():
+    g = load_golden("options")
+    return [(name, i) for name in g for i in range(len(g[name]["runs"]))]
+
+
+@pytest.mark.parametrize("name,i", _option_runs())
+def test_bound_reference_under_threshold_and_strand_options(tmp_path, name, i):
+    """the options of tests/golden/options.json through the reference bound to the library: hits_init computes the
+    thresholds (reference code), binding B hands them to the device-side acceptance test, binding A feeds hits_enter"""
+    g = load_golden("options")[name]
+    case = cases.get(name)
+    rec = g["runs"][i]
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    alpha = blastdb.NCBI4NA if case.query_is_nt else blastdb.NCBISTDAA
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+    args = ["-d", base, "-i", qf, "-p", str(case.sym)] + (["-Q", str(case.query_gencode), "-D", str(case.db_gencode)] if case.sym >= 2 else [])
+    for variant, tail, key in (("topk", ["-m", "8", "-a", "2"], "m8"), ("topk", ["-m", "7", "-b", "0"], "m7"), ("scores", ["-m", "8"], "m8")):
+        r = subprocess.run([need(variant)] + args + rec["options"] + tail, capture_output=True, text=True)
+        assert r.returncode == rec[key + "_rc"] and r.stdout == rec[key], (variant, rec["options"], r.stderr)

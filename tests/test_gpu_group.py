@@ -192,3 +192,36 @@ def test_group_of_a_translated_nucleotide_database():
     assert one.align(q, ids, ds, df) == grp.align(q, ids, ds, df)
     one.close()
     grp.close()
+
+
+def _option_runs():
+    g = load_golden("options")
+    return [(name, i) for name in g for i in range(len(g[name]["runs"]))]
+
+
+@pytest.mark.parametrize("name,i", _option_runs())
+def test_cli_options_that_move_thresholds_and_strands_equal_reference_cli(tmp_path, name, i):
+    """tests/golden/options.json: the reference CLI under -c / -u (score window), -e / -k (E-value window), -z (effective
+    database size), -v / -b (list lengths), -S (query strands, also of translated queries), nucleotide rewards, other
+    matrices and gap systems with and without Karlin-Altschul parameters - hits_init's thresholds (hits.cc:283-511) and
+    search_chunk's strand loops (swipe.cc:277-337) end to end.  swipe_amd_cli on one shard and on two must print the same
+    bytes."""
+    g = load_golden("options")[name]
+    case = cases.get(name)
+    assert g["checksum"] == case.checksum()
+    rec = g["runs"][i]
+    base = str(tmp_path / name)
+    blastdb.write_db(base, case.seqs, protein=case.protein, volumes=case.volumes)
+    alpha = blastdb.NCBI4NA if case.query_is_nt else blastdb.NCBISTDAA
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(alpha[c] for c in case.query) + "\n")
+    args = [EXE, "-d", base, "-i", qf, "-p", str(case.sym)]
+    if case.sym >= 2:
+        args += ["-Q", str(case.query_gencode), "-D", str(case.db_gencode)]
+    args += rec["options"]
+    strip = lambda t: re.sub(r"\s*<len>\d+</len>", "", t)
+    for shards in ([], shard_args(2)):
+        r = subprocess.run(args + shards + ["-m", "8"], capture_output=True, text=True)
+        assert r.returncode == rec["m8_rc"] and r.stdout == rec["m8"], (rec["options"], shards, r.stderr)
+    r = subprocess.run(args + ["-m", "7", "-b", "0"], capture_output=True, text=True)
+    assert r.returncode == rec["m7_rc"] and strip(r.stdout) == strip(rec["m7"]), (rec["options"], r.stderr)
