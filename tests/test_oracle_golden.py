@@ -188,3 +188,57 @@ def test_translated_hit_list_matches_cli(name):
     assert h.c.stats_available
     assert ["%.2g" % h.expect(x[1]) for x in got] == cli["evalue"]
     assert ["%.1f" % h.bits(x[1]) for x in got] == cli["bits"]
+
+
+def _option_runs():
+    g = load_golden("options")
+    return [(name, i) for name in ("p1k", "nt") for i in range(len(g[name]["runs"]))]
+
+
+@pytest.mark.parametrize("name,i", _option_runs())
+def test_oracle_hits_init_under_the_reference_s_options(name, i):
+    """tests/golden/options.json (the reference CLI under -c -u -e -k -z -v -b -S, other rewards / matrices / gap systems):
+    the oracle's scalar scores + hits_init / hits_enter restatement reproduce the reference's hit list (sequence numbers
+    and scores of the -m 7 view) and the E-value / bit-score columns of its -m 8 view."""
+    import re
+    from swipe_amd import blastdb
+    g = load_golden("options")[name]
+    case = cases.get(name)
+    assert g["checksum"] == case.checksum()
+    rec = g["runs"][i]
+    opt = dict(zip(rec["options"][::2], rec["options"][1::2]))
+    protein = case.protein
+    matrix = opt.get("-M", "BLOSUM62")
+    match, mismatch = int(opt.get("-r", 1)), int(opt.get("-q", -3))
+    go = int(opt.get("-G", 11 if protein else 5))
+    ge = int(opt.get("-E", 1 if protein else 2))
+    strands = {"plus": 1, "minus": 2, "both": 3}.get(opt.get("-S", "3"), None) or int(opt.get("-S", 3))
+    M = oracle.matrix_builtin(matrix) if protein else oracle.matrix_nucleotide(match, mismatch)
+    res, off = oracle.pack(case.seqs)
+    q = np.asarray(case.query, dtype=np.uint8)
+    queries = [(q, 0)] if protein else [(x, s) for x, s in ((q, 0), (blastdb.revcomp_nt16(q), 1)) if (s + 1) & strands]
+    kw = dict(descriptions=int(opt.get("-v", 250)), alignments=0, minscore=int(opt.get("-c", 1)), maxscore=int(opt.get("-u", 1 << 62)),
+              minexpect=float(opt.get("-k", 0.0)), expect=float(opt.get("-e", 10.0)), symtype=1 if protein else 0, querystrands=strands,
+              matrix=matrix, match=match, mismatch=mismatch, gapopen=go, gapextend=ge, qlen=len(q), dbseqs=len(case.seqs),
+              dbsyms=int(off[-1]), effdbsize=int(opt.get("-z", 0)))
+    h = oracle.HitList(**kw)
+    for x, s in queries:
+        scores = oracle.search_all63(res, off, x, M, go + ge, ge, threads=2)
+        for seqno, sc in enumerate(scores):
+            h.enter(seqno, int(sc), 0, 0, s, 0)
+    got = h.hits()
+    assert [x[0] for x in got] == list(map(int, re.findall(r"<track>(\d+)</track>", rec["m7"])))
+    assert [x[1] for x in got] == list(map(int, re.findall(r"<score>(-?\d+)</score>", rec["m7"])))
+    # -m 8 (its own list: alignments = -b default 100, descriptions -v): E-value and bit score columns of the rows it prints
+    rows = [l.split("\t") for l in rec["m8"].splitlines()]
+    h8 = oracle.HitList(**dict(kw, alignments=int(opt.get("-b", 100))))
+    for x, s in queries:
+        scores = oracle.search_all63(res, off, x, M, go + ge, ge, threads=2)
+        for seqno, sc in enumerate(scores):
+            h8.enter(seqno, int(sc), 0, 0, s, 0)
+    top = h8.hits()[: len(rows)]
+    if h8.c.stats_available:
+        assert [r[10] for r in rows] == ["%.2g" % h8.expect(x[1]) for x in top]
+        assert [r[11] for r in rows] == ["%.1f" % h8.bits(x[1]) for x in top]
+    else:
+        assert [r[10] for r in rows] == [str(x[1]) for x in top]
