@@ -225,3 +225,20 @@ def test_cli_options_that_move_thresholds_and_strands_equal_reference_cli(tmp_pa
         assert r.returncode == rec["m8_rc"] and r.stdout == rec["m8"], (rec["options"], shards, r.stderr)
     r = subprocess.run(args + ["-m", "7", "-b", "0"], capture_output=True, text=True)
     assert r.returncode == rec["m7_rc"] and strip(r.stdout) == strip(rec["m7"]), (rec["options"], r.stderr)
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_cli_nucleotide_database_in_three_volumes_behind_an_alias(tmp_path, shards):
+    """.nal alias over three .nin/.nsq volumes (ambiguity tables per volume): the reference prints for it what it prints for
+    the single volume (checked on the CPU in test_oracle_vs_reference), and so must swipe_amd_cli - also when the shard
+    boundaries of -a 3 fall inside volumes"""
+    case, g = cases.get("nt"), load_golden("nt")
+    base = str(tmp_path / "ntv")
+    blastdb.write_db(base, case.seqs, protein=False, volumes=3)
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(blastdb.NCBI4NA[c] for c in case.query) + "\n")
+    args = [EXE, "-d", base, "-i", qf, "-p", "0", "-G", str(case.gapopen), "-E", str(case.gapextend), "-v", str(case.keep), "-e", "10",
+            "-r", str(case.match), "-q", str(case.mismatch)] + shard_args(shards)
+    run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True).stdout
+    assert run(["-m", "8", "-b", str(case.keep)]) == g["tsv"]
+    assert run(["-m", "7", "-b", str(g["nalign"])]) == g["xml_align"]

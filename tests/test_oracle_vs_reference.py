@@ -129,3 +129,21 @@ def test_translated_lanes_match_compiled_reference(tmp_path, symtype, qgc, dgc, 
         assert oracle.search7_lane(d, qf[qtag], M, 12, 1) == s7a == s7b
         assert oracle.fullsw(d, qf[qtag], M, 12, 1) == s63
         assert oracle.search16s_lane(d, qf[qtag], M, 12, 1) == (s16s, bp16s, bq16s)
+
+
+def test_reference_prints_the_same_for_a_nucleotide_database_cut_into_volumes(tmp_path):
+    """the fixture the GPU test test_cli_nucleotide_database_in_three_volumes_behind_an_alias rests on: the compiled
+    reference on the `nt` sequences written as three .nin/.nsq volumes behind a .nal alias prints the golden -m 8 text of
+    the single-volume database"""
+    import cases
+    from conftest import load_golden
+    exe = os.path.join(ROOT, "oracle", "_ref", "swipe")
+    case, g = cases.get("nt"), load_golden("nt")
+    base = str(tmp_path / "ntv")
+    blastdb.write_db(base, case.seqs, protein=False, volumes=3)
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(blastdb.NCBI4NA[c] for c in case.query) + "\n")
+    r = subprocess.run([exe, "-d", base, "-i", qf, "-p", "0", "-G", str(case.gapopen), "-E", str(case.gapextend), "-v", str(case.keep),
+                        "-e", "10", "-r", str(case.match), "-q", str(case.mismatch), "-m", "8", "-b", str(case.keep)],
+                       capture_output=True, text=True, check=True)
+    assert r.stdout == g["tsv"]
