@@ -410,6 +410,33 @@ void order_by_length(const LenOf& len_of, const int32_t* ids, int64_t n, std::ve
   }
 }
 
+// OR over a byte range on a few host threads (residue-code validation of a shard: 3 GB in 0.1 s instead of 1.5)
+uint8_t or_of_bytes(const uint8_t* data, int64_t n)
+{
+  const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, n >> 24}));
+  std::vector<uint8_t> acc(size_t(nthreads), 0);
+  auto scan = [&](int64_t t) {
+    const uint8_t* p = data + n * t / nthreads;
+    const uint8_t* e = data + n * (t + 1) / nthreads;
+    uint64_t a8 = 0;
+    uint8_t a = 0;
+    for (; p < e && (reinterpret_cast<uintptr_t>(p) & 7); ++p) a |= *p;
+    for (; p + 8 <= e; p += 8) { uint64_t v; std::memcpy(&v, p, 8); a8 |= v; }
+    for (; p < e; ++p) a |= *p;
+    for (int k = 0; k < 8; ++k) a |= uint8_t(a8 >> (8 * k));
+    acc[size_t(t)] = a;
+  };
+  if (nthreads == 1) scan(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(scan, t);
+    for (std::thread& t : pool) t.join();
+  }
+  uint8_t any = 0;
+  for (uint8_t a : acc) any |= a;
+  return any;
+}
+
 // residues == nullptr: db->residues already holds them on the device (translated shards)
 int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t nseq)
 {
@@ -430,27 +457,7 @@ int ingest(swa_db* db, const uint8_t* residues, const int64_t* offsets, int64_t 
   // corrupt .psq, a caller's array - would read out of bounds and score silently wrong.  One OR over all bytes.
   if (residues && db->nsym) {
     const uint8_t bad_bits = db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? 0xF0 : 0xE0;
-    const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, db->nsym >> 24}));
-    std::vector<uint8_t> acc(size_t(nthreads), 0);
-    auto scan = [&](int64_t t) {
-      const uint8_t* p = residues + base + db->nsym * t / nthreads;
-      const uint8_t* e = residues + base + db->nsym * (t + 1) / nthreads;
-      uint64_t a8 = 0;
-      uint8_t a = 0;
-      for (; p < e && (reinterpret_cast<uintptr_t>(p) & 7); ++p) a |= *p;
-      for (; p + 8 <= e; p += 8) { uint64_t v; std::memcpy(&v, p, 8); a8 |= v; }
-      for (; p < e; ++p) a |= *p;
-      for (int k = 0; k < 8; ++k) a |= uint8_t(a8 >> (8 * k));
-      acc[size_t(t)] = a;
-    };
-    if (nthreads == 1) scan(0);
-    else {
-      std::vector<std::thread> pool;
-      for (int64_t t = 0; t < nthreads; ++t) pool.emplace_back(scan, t);
-      for (std::thread& t : pool) t.join();
-    }
-    uint8_t any = 0;
-    for (uint8_t a : acc) any |= a;
+    const uint8_t any = or_of_bytes(residues + base, db->nsym);
     if (any & bad_bits)
       return fail(SWA_EINVAL, db->symtype == SWA_SYMTYPE_NUCLEOTIDE ? "database residue code out of range (nucleotide codes are 4-bit masks, < 16)"
                                                                    : "database residue code out of range (must be < 32)");
