@@ -12,9 +12,11 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_r03
-rm -rf $O; mkdir -p $O
+if [ "$2" = "stats-only" ]; then rm -rf $O/stats; else rm -rf $O; fi; mkdir -p $O
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-cold $1"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/bench_under_stats.json 2> $O/stats.err
+# kernel stats: the command the driver runs, unabridged (the PMC passes below use fewer steps and skip the host-side sections)
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --gpus 1 --steps 20 --warmup 5 $1 > $O/bench_under_stats.json 2> $O/stats.err
+if [ "$2" = "stats-only" ]; then find $O -name "*.csv" | wc -l; exit 0; fi
 i=0
 for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_WAVES GRBM_GUI_ACTIVE" \
            "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES" \

@@ -16,20 +16,33 @@ def short(name):
     return re.sub(r"\(.*", "", name).replace("void ", "").strip()
 
 
-# --- kernel stats
+# --- kernel stats (+ the launches of one kernel split by database size, from the kernel trace of the same run)
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+trace = defaultdict(list)
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        trace[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out, "r03_kernel_stats_bench.csv"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats -- {CMD}\n")
-        f.write("# sections of the default run: protein headline (10 M sequences, bound first pass, 1 + 1 + 2 launches), the same with the exact\n")
-        f.write("# first pass (swa_narrow_split_kernel), nucleotide secondary (50 M sequences, swa_dual_kernel), 100 M proteins on one GPU (the\n")
-        f.write("# same swa_narrow_bound_kernel build as the headline: its AverageNs mixes 105 ms and 1 048 ms launches - the per-size means\n")
-        f.write("# are in r03_pmc_bench.csv), pair section (swa_dual_bound_kernel).  Durations in ns.\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5     (the driver's command, unabridged)\n")
+        f.write("# sections of the default run: protein headline (10 M sequences, bound first pass: 5 warm-up + 20 timed launches), the same with\n")
+        f.write("# the exact first pass (swa_narrow_split_kernel, 1 + 20), oracle verification (exact pass, 1), pair section (swa_dual_bound_kernel),\n")
+        f.write("# cold open, nucleotide secondary (50 M sequences, swa_dual_kernel, 1 + 3 + 1), 100 M proteins on one GPU (1 + 3 + 1).  The 100 M\n")
+        f.write("# section runs the SAME swa_narrow_bound_kernel build as the headline, so that kernel's AverageNs below mixes 105 ms and 1 048 ms\n")
+        f.write("# launches: the rows marked [split] at the end give the mean per database size, from the kernel trace of this very run - the\n")
+        f.write("# 10 M-sequence mean is what bench.py reports as roofline.kernel_ms.  Durations in ns.\n")
         cols = list(rows[0].keys())
         f.write(",".join(cols) + "\n")
         for r in rows[:16]:
             f.write(",".join('"%s"' % r[c] if c == "Name" else r[c] for c in cols) + "\n")
+        for name, ds in trace.items():
+            if not short(name).startswith(("swa_narrow_bound_kernel", "swa_narrow_split_kernel", "swa_dual_kernel", "swa_dual_bound_kernel")):
+                continue
+            lo = min(ds)
+            for label, sel in (("smaller database", [d for d in ds if d <= 3 * lo]), ("larger database", [d for d in ds if d > 3 * lo])):
+                if sel and len(sel) != len(ds):
+                    f.write('"[split] %s: %s",%d,%d,%.1f,,%d,%d,\n' % (short(name), label, len(sel), sum(sel), sum(sel) / len(sel), min(sel), max(sel)))
     print("kernel stats:", len(rows), "kernels")
 
 # --- per-launch durations by kernel from the kernel trace of the stats run (to split by size)
