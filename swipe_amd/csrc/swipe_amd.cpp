@@ -561,25 +561,44 @@ int ensure_main(swa_db* db)
 // batches | the set's remaining batches, offsets rebased], two stream regions under one base pointer; nothing is copied
 // but 12 bytes per batch.  Rebuilt when the query changes O; shards without long sequences never build one.
 struct WindowPlan { bool on = false; int64_t O = 0, W = 0, Lmax = 0; };
-WindowPlan plan_windows(const swa_db* db, int64_t qlen)
+// slots_per_cu = database sequences one CU works on at a time under the kernel that will run: 4 SIMDs x resident waves x
+// chains per wave x sequences per chain.  Round 2 assumed 64 (16-lane chains of sequence pairs, two waves) for every
+// kernel; the one-lane kernels of short queries hold 3 072 - with them a shard is spread 48 times thinner, and a
+// 35 000-residue protein (5 ms on one lane, alone) outlasts a 10-residue search of ten million sequences (3.7 ms).
+WindowPlan plan_windows(const swa_db* db, int64_t qlen, int slots_per_cu)
 {
   WindowPlan w;
   if (db->opt.window == 0 || db->ge <= 0 || db->h_order.empty()) return w;
   w.O = db->hi > 0 ? qlen + qlen * db->hi / db->ge + 1 : qlen + 1;
-  const int64_t wlen = std::max<int64_t>(w.O + w.O / 4, 4096);
+  // columns one slot works through if the shard is spread evenly; half of that is what a sequence may have without outlasting
+  // the rest, and windows are cut about that long (at least 512 columns, at most 4 096, never less than 1.25 overlaps)
+  const int64_t avg = db->active_sym / std::max<int64_t>(1, int64_t(db->cus) * std::max(1, slots_per_cu));
+  const int64_t wlen = std::max<int64_t>(w.O + w.O / 4, std::min<int64_t>(4096, std::max<int64_t>(512, avg / 2)));
   w.W = db->opt.window_step > 0 ? db->opt.window_step : wlen - w.O;
-  const int64_t share = db->active_sym / std::max<int64_t>(1, int64_t(db->cus) * 64) / 2;
-  w.Lmax = db->opt.window > 0 ? db->opt.window : std::max<int64_t>(3 * (w.W + w.O) / 2, share);
+  // ... and nothing shorter than four mean lengths is cut: on a small shard avg is tiny, and windowing the ordinary tail of the
+  // length distribution would recompute overlaps for nothing
+  const int64_t mean4 = 4 * db->active_sym / std::max<int64_t>(1, int64_t(db->h_order.size()));
+  w.Lmax = db->opt.window > 0 ? db->opt.window : std::max<int64_t>({3 * (w.W + w.O) / 2, avg / 2, mean4});
   if (w.W + w.O >= (int64_t(1) << 30)) return w;         // window lengths are 32 bit
   w.on = db->len_of(db->h_order[0]) > w.Lmax;            // h_order: longest first
   return w;
 }
+// resident waves per SIMD of a build with K rows per lane (launch bounds of the kernels: split_waves_for / cb_waves_for)
+int waves_for_rows(int K, bool bound)
+{
+  return bound ? (K <= 5 ? 8 : K <= 10 ? 6 : K <= 20 ? 4 : K <= 29 ? 3 : 2) : (K <= 8 ? 8 : K <= 12 ? 6 : K <= 20 ? 4 : K <= 31 ? 3 : 2);
+}
+int slots_per_cu(int G, int K, bool bound, int seqs_per_chain)
+{
+  if (G <= 0 || K <= 0) return 64;
+  return 4 * waves_for_rows(K, bound) * (64 / G) * seqs_per_chain;
+}
 
 // the set to launch over: `set` itself, or the view that replaces its long sequences by windows
-int prepare_view(swa_db* db, const BatchSet& set, int per_row, int64_t qlen, const BatchSet** out)
+int prepare_view(swa_db* db, const BatchSet& set, int per_row, int64_t qlen, const BatchSet** out, int nslots = 64)
 {
   *out = &set;
-  const WindowPlan wp = plan_windows(db, qlen);
+  const WindowPlan wp = plan_windows(db, qlen, nslots);
   if (!wp.on) { db->nwin = 0; db->view_of = nullptr; return SWA_OK; }
   if (db->view_of == &set && db->view.built && db->view_O == wp.O && db->view_W == wp.W && db->view_Lmax == wp.Lmax) {
     *out = &db->view;
@@ -1286,20 +1305,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   HIP_TRY(hipMemsetAsync(db->ctl.p, 0, CTL_INTS * sizeof(int32_t), st));
   rc = ensure_main(db);                                  // nucleotide shards build their pair stream on first use
   if (rc != SWA_OK) return rc;
-  const BatchSet* bsp = &db->main;                       // ... or the view that cuts long sequences into windows
-  rc = prepare_view(db, db->main, 2, qlen, &bsp);
-  if (rc != SWA_OK) return rc;
-  const BatchSet& bs = *bsp;
-  const swa_seqs sq = db->seqs();
-  const int64_t nids = db->nseq + (bsp != &db->main ? db->nwin : 0);
-
   std::vector<int32_t> requeue;
   bool used_bound = false, follow = false;
   const bool f16 = f16_applicable(db);
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = db->opt.force_mp == 1;
   const bool single_pass = qlen <= 16 * 58 && K > 0 && !force_mp;
-  HIP_TRY(hipEventRecord(db->ev[1], st));
   // Lanes per sequence pair G and rows per lane K = ceil(qlen / G) of the single-pass build: the argmax over the measured
   // table of every build that exists (kernel_choice.cpp; option "lanes" pins the chain length: A/B runs and tests).  One
   // lane per pair for short queries, chains of 2 / 4 / 8 / 16 lanes beyond; the bound build of the same shape for top-K
@@ -1318,6 +1329,13 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   env.bound_period = Nb;
   const swa::KernelPick pick = single_pass ? swa::pick_first_pass(env) : swa::KernelPick{};
   const int G = pick.G, Kg = pick.K;
+  const BatchSet* bsp = &db->main;                       // ... or the view that cuts long sequences into windows
+  rc = prepare_view(db, db->main, 2, qlen, &bsp, slots_per_cu(G, Kg, pick.bound, 2));
+  if (rc != SWA_OK) return rc;
+  const BatchSet& bs = *bsp;
+  const swa_seqs sq = db->seqs();
+  const int64_t nids = db->nseq + (bsp != &db->main ? db->nwin : 0);
+  HIP_TRY(hipEventRecord(db->ev[1], st));
   if (f16 && single_pass && Kg > 0 && f16_limit(db, Kg) >= 1024 && db->opt.narrow_variant != 1) {
     const int K = Kg;
     swa_narrow_params p{};
@@ -1526,7 +1544,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
     if (rc != SWA_OK) return rc;
     const BatchSet& whole = Gd < 16 ? db->main : nib ? db->single4 : db->single;
-    rc = prepare_view(db, whole, Gd < 16 ? 2 : 1, qlen, &bsp);
+    rc = prepare_view(db, whole, Gd < 16 ? 2 : 1, qlen, &bsp, slots_per_cu(Gd, Kd, pick.bound, 1));
     if (rc == SWA_OK) rc = reserve2(bsp != &whole);
     if (rc != SWA_OK) return rc;
     const BatchSet& set = *bsp;

@@ -1361,6 +1361,48 @@ def test_multipass_kernel_over_a_view_whose_windows_are_shorter_than_its_other_b
     db.close()
 
 
+def test_short_queries_window_a_titin_sized_subject_by_themselves():
+    """round 3: whether a long sequence is cut into windows depends on how many sequences the chosen kernel keeps in flight.  A
+    30-residue query runs one lane per sequence pair - 1 536 pairs per CU instead of the 64 of the 16-lane chains - so a
+    35 000-residue protein, 5 ms on its one lane, would outlast the search of 300 000 ordinary sequences several times over
+    (round 2's rule, tuned for 16-lane chains, left it whole).  Automatic windows: every score equal to the oracle's (exact and
+    top-K with the bound build), and the first pass at least 1.5 x faster than with windows off."""
+    rng = np.random.default_rng(21)
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(77, 1, 30, rtab)
+    res, off = swipe_amd.synth_db(19, 300_000)
+    body = rtab[rng.integers(0, len(rtab), 35_000)].astype(np.uint8)
+    for at in (5, 17_000, 34_960):
+        body[at:at + 30] = q                                      # copies at both ends and across a window start
+    res = np.concatenate([res, body])
+    off = np.concatenate([off, [off[-1] + len(body)]]).astype(np.int64)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    pick = np.unique(np.concatenate([rng.integers(0, 300_000, 3000), [300_000]]))
+    sub = [res[off[i]:off[i + 1]] for i in pick]
+    r2, o2 = oracle.pack(sub)
+    want = oracle.search_all63(r2, o2, q, Mo, 12, 1, threads=THREADS)
+    times = {}
+    for mode in (None, 0):
+        db.set_option("window", mode)
+        best = 1e9
+        for _ in range(3):
+            scores, c = db.search(q)
+            best = min(best, c["kernel_ms"])
+        times[mode] = best
+        assert c["narrow_shifted"] == 11 and np.array_equal(scores[pick], want), mode
+    assert int(want[-1]) == int(oracle.search_all63(*oracle.pack([q]), q, Mo, 12, 1)[0])          # the long one carries the query whole
+    assert times[None] * 1.5 < times[0], times
+    db.set_option("window", None)
+    full, _ = db.search(q)
+    for bound in (0, 1):
+        db.set_option("bound", bound)
+        hits, tot, obv, c = db.search_topk(q, keep=40, minscore=70)
+        assert (hits, tot, obv) == _expected_topk(full, 40, 70), bound
+    db.close()
+
+
 @pytest.mark.parametrize("step", [64, 333, 1000])
 def test_windows_are_exact_for_alignments_that_span_long_gaps(step):
     """the overlap is the longest span a positive-scoring alignment can have, qlen (1 + hi / R): planted alignments with

@@ -99,19 +99,31 @@ def cmd_qlen(a):
 
 
 def cmd_longest(a):
+    """short queries against a database that holds a very long sequence (--long N residues, e.g. titin's 35 000): the one
+    chain that walks it column by column outlasts the search of everything else unless it is cut into windows"""
     import swipe_amd
-    db, full, nsym = make_db(a.nseq)
+    from swipe_amd import synth
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(7, 1, 6000, rtab)
+    res, off = swipe_amd.synth_db(1, a.nseq, query=full[:375])
+    if a.long:
+        rng = np.random.default_rng(5)
+        extra = [rtab[rng.integers(0, len(rtab), n)].astype(np.uint8) for n in a.long]
+        res = np.concatenate([res] + extra)
+        off = np.concatenate([off, off[-1] + np.cumsum([len(x) for x in extra])]).astype(np.int64)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     info = db.info()
-    print(f"# {a.nseq} sequences, longest {info['longest']}")
+    print(f"# {info['seqcount']} sequences, longest {info['longest']}; kernel time, best of {a.reps}")
     for qlen in a.qlens:
         q = full[:qlen]
         out = []
-        for name, opts in (("auto", {}), ("off", {"window": 0}), ("win>1000 step 512", {"window": 1000, "window_step": 512}),
-                           ("win>600 step 384", {"window": 600, "window_step": 384})):
-            for k in ("window", "window_step"):
-                db.set_option(k, opts.get(k))
-            ms, c = run_one(db, q, False, 0, a.reps)
-            out.append("%s %.3f ms %.0f GCUPS" % (name, ms, c["cells"] / ms / 1e6))
+        for topk in (0, 80):
+            for name, opts in (("windows auto", {}), ("windows off", {"window": 0})):
+                for k in ("window", "window_step"):
+                    db.set_option(k, opts.get(k))
+                ms, c = run_one(db, q, False, topk, a.reps)
+                out.append("%s %s %.3f ms %.0f GCUPS" % ("top-250" if topk else "exact", name, ms, c["cells"] / ms / 1e6))
         print("qlen %4d  " % qlen + " | ".join(out), flush=True)
     db.close()
 
@@ -591,6 +603,7 @@ def main():
     p.set_defaults(fn=cmd_qlen)
     p = sub.add_parser("longest")
     p.add_argument("qlens", type=int, nargs="+")
+    p.add_argument("--long", type=int, action="append", help="add a sequence of this many residues (repeatable)")
     p.add_argument("--nseq", type=int, default=2_000_000)
     p.add_argument("--reps", type=int, default=4)
     p.set_defaults(fn=cmd_longest)
