@@ -345,7 +345,9 @@ Writes a synthetic BLAST v4 protein database to local disk, runs swipe_amd_cli o
     blastdb.write_alias(os.path.join(d, "db"), names, protein=True)
     # queries: database sequences of about the bench query's length (so every one has real hits)
     lens = np.diff(off)
-    pick = np.nonzero((lens > 330) & (lens < 420))[0][:: max(1, nseq // 200)][:nq]
+    qlo, qhi = (int(argv[3]), int(argv[4])) if len(argv) > 4 else (330, 420)        # query lengths (database sequences of that length)
+    cand = np.nonzero((lens > qlo) & (lens < qhi))[0]
+    pick = cand[:: max(1, len(cand) // nq)][:nq]
     sym = "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ"
     def fasta(ids, path):
         with open(path, "w") as f:
