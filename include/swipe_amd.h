@@ -48,7 +48,8 @@ extern "C" {
 #define SWA_OK          0
 #define SWA_EINVAL     -1   /* bad argument */
 #define SWA_ENODEV     -2   /* no HIP device / HIP runtime error */
-#define SWA_ENOMEM     -3
+#define SWA_ENOMEM     -3   /* device or host memory; no C++ exception leaves the library (a failed host allocation is this
+                               status where the reference's xmalloc ends the process, swipe.cc:158-182) */
 #define SWA_EIO        -4   /* database files unreadable or malformed */
 #define SWA_ESTATE     -5   /* call order (e.g. search before set_scoring) */
 #define SWA_ERANGE     -6   /* caller's buffer too small; the needed size is reported */

@@ -632,7 +632,7 @@ struct swa_headers {
 };
 
 extern "C" int swa_headers_open(const char* basename, int symtype, const char* taxidfile, swa_headers** out)
-{
+try {
   if (!out) return swa::fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   swa_headers* h = new (std::nothrow) swa_headers;
@@ -641,7 +641,7 @@ extern "C" int swa_headers_open(const char* basename, int symtype, const char* t
   if (rc != SWA_OK) { delete h; return rc; }
   *out = h;
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" void swa_headers_close(swa_headers* h) { delete h; }
 
@@ -654,7 +654,7 @@ extern "C" int swa_headers_time(const swa_headers* h, char* buf, int64_t cap)   
 
 extern "C" int swa_headers_info(const swa_headers* h, int64_t* seqcount, int64_t* symcount, int64_t* masked_seqcount,
                                 int64_t* masked_symcount, int64_t* longest, char* title, int64_t title_cap)
-{
+try {
   if (!h) return swa::fail(SWA_EINVAL, "null handle");
   if (seqcount) *seqcount = h->db.nseq;
   if (symcount) *symcount = h->db.nsym;
@@ -663,7 +663,7 @@ extern "C" int swa_headers_info(const swa_headers* h, int64_t* seqcount, int64_t
   if (longest) *longest = h->db.longest;
   if (title && title_cap > 0) std::snprintf(title, size_t(title_cap), "%s", h->db.title.c_str());
   return SWA_OK;
-}
+} SWA_CATCH
 
 namespace {
 int header_bytes(const swa_headers* h, int64_t seqno, const uint8_t** p, size_t* n, size_t* vol, int64_t* local)
@@ -679,7 +679,7 @@ int header_bytes(const swa_headers* h, int64_t seqno, const uint8_t** p, size_t*
 }  // namespace
 
 extern "C" int swa_headers_get(const swa_headers* h, int64_t seqno, int flags, char* buf, int64_t buflen, int64_t* needed)
-{
+try {
   if (!h || buflen < 0 || (buflen > 0 && !buf) || !needed) return swa::fail(SWA_EINVAL, "bad argument");
   const uint8_t* p; size_t n, vol; int64_t local;
   const int rc = header_bytes(h, seqno, &p, &n, &vol, &local);
@@ -694,11 +694,11 @@ extern "C" int swa_headers_get(const swa_headers* h, int64_t seqno, int flags, c
   if (*needed > buflen) return swa::fail(SWA_ERANGE, "defline buffer too small");
   std::memcpy(buf, d.c_str(), d.size() + 1);
   return SWA_OK;
-}
+} SWA_CATCH
 
 // db_check_inclusion (database.cc:1465-1481) for the sequences [first_seqno, first_seqno + n)
 extern "C" int swa_headers_inclusion(const swa_headers* h, int64_t first_seqno, int64_t n, uint8_t* include)
-{
+try {
   if (!h || n < 0 || (n > 0 && !include)) return swa::fail(SWA_EINVAL, "bad argument");
   DeflineFilter f;
   f.memb = (unsigned long)h->db.memb_bit;
@@ -716,7 +716,7 @@ extern "C" int swa_headers_inclusion(const swa_headers* h, int64_t first_seqno, 
     include[i] = ok ? 1 : 0;
   }
   return SWA_OK;
-}
+} SWA_CATCH
 
 int swa::read_blast_deflines(const char* basename, int symtype, const std::vector<int64_t>& seqnos,
                              std::vector<std::string>& deflines, std::vector<int64_t>& lengths)
@@ -772,7 +772,7 @@ inline void ber_string(std::vector<uint8_t>& v, const std::string& s)
 
 extern "C" int swa_blastdb_write(const char* basename, int symtype, const uint8_t* residues, const int64_t* offsets,
                                  int64_t nseq, int64_t first_id, const char* title)
-{
+try {
   if (!basename || !offsets || nseq < 0 || (nseq > 0 && !residues)) return swa::fail(SWA_EINVAL, "bad argument");
   if (symtype != SWA_SYMTYPE_PROTEIN && symtype != SWA_SYMTYPE_NUCLEOTIDE) return swa::fail(SWA_EINVAL, "symtype must be 0 or 1");
   const bool protein = symtype == SWA_SYMTYPE_PROTEIN;
@@ -858,4 +858,4 @@ extern "C" int swa_blastdb_write(const char* basename, int symtype, const uint8_
   const bool ok = std::fwrite(pin.data(), 1, pin.size(), fin) == pin.size();
   std::fclose(fin);
   return ok ? SWA_OK : swa::fail(SWA_EIO, "write failed");
-}
+} SWA_CATCH

@@ -54,7 +54,9 @@ struct Worker {
       std::function<int()> f = std::move(job);
       has_job = false;
       l.unlock();
-      const int r = f();
+      int r;
+      try { r = f(); }                                     // the C ABI does not throw; a stand-in shard of the tests may
+      catch (const std::exception& x) { r = fail(SWA_ENOMEM, std::string("exception on a shard's thread: ") + x.what()); }
       std::string e = r == SWA_OK ? std::string() : std::string(swa_last_error());   // thread-local on THIS thread
       l.lock();
       rc = r;
@@ -180,7 +182,7 @@ int make_group(const std::vector<int64_t>& cuts, const int* devices, int64_t bas
 }  // namespace
 
 extern "C" int swa_shard_bounds(const int64_t* offsets, int64_t nseq, int nshards, int64_t* cuts)
-{
+try {
   if (!offsets || nseq < 0 || nshards < 1 || !cuts) return fail(SWA_EINVAL, "bad argument");
   const int64_t total = offsets[nseq] - offsets[0];
   cuts[0] = 0;
@@ -193,19 +195,19 @@ extern "C" int swa_shard_bounds(const int64_t* offsets, int64_t nseq, int nshard
   }
   cuts[nshards] = nseq;
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_blastdb_shard_bounds(const char* basename, int symtype, int nshards, int64_t* cuts)
-{
+try {
   if (nshards < 1 || !cuts) return fail(SWA_EINVAL, "bad argument");
   std::vector<int64_t> off;
   const int rc = swa::read_blast_lengths(basename, symtype, off);
   if (rc != SWA_OK) return rc;
   return swa_shard_bounds(off.data(), int64_t(off.size()) - 1, nshards, cuts);
-}
+} SWA_CATCH
 
 extern "C" int swa_group_open(const char* basename, int symtype, int db_gencode, int nshards, const int* devices, swa_group** out)
-{
+try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   if (!basename) return fail(SWA_EINVAL, "null database name");
@@ -225,12 +227,12 @@ extern "C" int swa_group_open(const char* basename, int symtype, int db_gencode,
     return db_gencode ? swa_db_open_translated(base.c_str(), db_gencode, dev, lo, hi - 1, db)
                       : swa_db_open(base.c_str(), symtype, dev, lo, hi - 1, db);
   }, out);
-}
+} SWA_CATCH
 
 extern "C" int swa_group_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int db_gencode,
                                      int nshards, const int* devices, int64_t first_seqno, int64_t total_seqcount,
                                      int64_t total_symcount, swa_group** out)
-{
+try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   if (nseq < 0 || !offsets) return fail(SWA_EINVAL, "bad database arrays");
@@ -245,7 +247,7 @@ extern "C" int swa_group_from_memory(const uint8_t* residues, const int64_t* off
     return db_gencode ? swa_db_from_memory_translated(residues, offsets + lo, hi - lo, db_gencode, dev, first_seqno + lo, tseq, tsym, db)
                       : swa_db_from_memory(residues, offsets + lo, hi - lo, symtype, dev, first_seqno + lo, tseq, tsym, db);
   }, out);
-}
+} SWA_CATCH
 
 extern "C" void swa_group_close(swa_group* g)
 {
@@ -260,7 +262,7 @@ extern "C" void swa_group_close(swa_group* g)
 }
 
 extern "C" int swa_group_info(const swa_group* g, swa_db_info_t* info, int* nshards)
-{
+try {
   if (!g || !info) return fail(SWA_EINVAL, "null argument");
   *info = swa_db_info_t{};
   for (size_t i = 0; i < g->shard.size(); ++i) {
@@ -275,29 +277,29 @@ extern "C" int swa_group_info(const swa_group* g, swa_db_info_t* info, int* nsha
   }
   if (nshards) *nshards = int(g->shard.size());
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_shard(const swa_group* g, int i, swa_db** db)
-{
+try {
   if (!g || !db || i < 0 || i >= int(g->shard.size())) return fail(SWA_EINVAL, "no such shard");
   *db = g->shard[size_t(i)];
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_set_scoring(swa_group* g, const int64_t* matrix, int64_t gapopenextend, int64_t gapextend)
-{
+try {
   if (!g || !matrix) return fail(SWA_EINVAL, "null argument");
   return g->run_all([&](int i) { return swa_set_scoring(g->shard[size_t(i)], matrix, gapopenextend, gapextend); });
-}
+} SWA_CATCH
 
 extern "C" int swa_group_set_option(swa_group* g, const char* key, const char* value)
-{
+try {
   if (!g || !key) return fail(SWA_EINVAL, "null argument");
   return g->run_all([&](int i) { return swa_set_option(g->shard[size_t(i)], key, value); });
-}
+} SWA_CATCH
 
 extern "C" int swa_group_set_inclusion(swa_group* g, const uint8_t* include, int64_t n)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   int64_t total = 0;
   for (int64_t c : g->count) total += c;
@@ -306,10 +308,10 @@ extern "C" int swa_group_set_inclusion(swa_group* g, const uint8_t* include, int
     const int64_t lo = g->first[size_t(i)] - g->first[0];
     return swa_db_set_inclusion(g->shard[size_t(i)], include ? include + lo : nullptr, g->count[size_t(i)]);
   });
-}
+} SWA_CATCH
 
 extern "C" int swa_group_search(swa_group* g, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   std::vector<swa_counters_t> c(g->shard.size());
   const int rc = g->run_all([&](int i) {
@@ -318,12 +320,12 @@ extern "C" int swa_group_search(swa_group* g, const uint8_t* query, int64_t qlen
   });
   if (rc == SWA_OK) sum_counters(c, counters);
   return rc;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_search_topk(swa_group* g, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore,
                                      int64_t maxscore, swa_hit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                                      swa_counters_t* counters)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   *nhits = 0;
@@ -344,14 +346,14 @@ extern "C" int swa_group_search_topk(swa_group* g, const uint8_t* query, int64_t
   if (obvious) *obvious = o;
   sum_counters(c, counters);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_search_pair_topk(swa_group* g, const uint8_t* query1, int64_t qlen1, const uint8_t* query2, int64_t qlen2,
                                           int64_t keep1, int64_t minscore1, int64_t maxscore1, int64_t keep2, int64_t minscore2,
                                           int64_t maxscore2, swa_hit_t* hits1, int64_t* nhits1, int64_t* totalhits1,
                                           int64_t* obvious1, swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2,
                                           int64_t* obvious2, swa_counters_t* counters)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   if (keep1 < 0 || keep2 < 0 || (keep1 > 0 && !hits1) || (keep2 > 0 && !hits2) || !nhits1 || !nhits2)
     return fail(SWA_EINVAL, "bad hit buffer");
@@ -377,13 +379,13 @@ extern "C" int swa_group_search_pair_topk(swa_group* g, const uint8_t* query1, i
   if (obvious2) *obvious2 = y;
   sum_counters(c, counters);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_search_frames_topk(swa_group* g, int nq, const uint8_t* const* queries, const int64_t* qlens,
                                             const int32_t* qtags, int64_t keep, int64_t minscore, int64_t maxscore,
                                             swa_fhit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                                             swa_counters_t* counters)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   *nhits = 0;
@@ -405,12 +407,12 @@ extern "C" int swa_group_search_frames_topk(swa_group* g, int nq, const uint8_t*
   if (obvious) *obvious = o;
   sum_counters(c, counters);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_align_hits(swa_group* g, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
                                     const int32_t* dstrands, const int32_t* dframes, int64_t n, swa_alignment_t* out, char* text,
                                     int64_t text_cap, int64_t* text_used)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   if (n < 0 || text_cap < 0 || !text_used || (n > 0 && (!seqnos || !out)) || (text_cap > 0 && !text))
     return fail(SWA_EINVAL, "bad argument");
@@ -472,23 +474,23 @@ extern "C" int swa_group_align_hits(swa_group* g, const uint8_t* query, int64_t 
   *text_used = need;
   if (need > text_cap) return fail(SWA_ERANGE, "text buffer too small for the edit scripts");
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_group_db_sequence(swa_group* g, int64_t seqno, int dstrand, int dframe, uint8_t* buf, int64_t cap,
                                      int64_t* len, int64_t* ntlen)
-{
+try {
   if (!g) return fail(SWA_EINVAL, "null group handle");
   const int o = g->owner(seqno);
   if (o < 0) return fail(SWA_EINVAL, "sequence number outside the group's shards");
   return g->run_one(o, [&] { return swa_db_sequence(g->shard[size_t(o)], seqno, dstrand, dframe, buf, cap, len, ntlen); });
-}
+} SWA_CATCH
 
 // ---- merging per-shard lists (tag_search_report re-entered through hits_enter, swipe.cc:1951-1974) -----------------
 // the same for frame-tagged hits: entries of one sequence all come from the shard that holds it, already in the
 // reference's order (query frame, then database frame), which a stable sort on (score, seqno) preserves
 extern "C" int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, int nlists, int64_t stride, int64_t keep,
                                swa_fhit_t* out, int64_t* nout)
-{
+try {
   if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
   std::vector<swa_fhit_t> all;
   for (int l = 0; l < nlists; ++l)
@@ -501,11 +503,11 @@ extern "C" int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, i
   for (size_t i = 0; i < k; ++i) out[i] = all[i];
   *nout = int64_t(k);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
                               int64_t keep, swa_hit_t* out, int64_t* nout)
-{
+try {
   if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
   std::vector<swa_hit_t> all;
   for (int l = 0; l < nlists; ++l)
@@ -515,4 +517,4 @@ extern "C" int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int
   for (size_t i = 0; i < k; ++i) out[i] = all[i];
   *nout = int64_t(k);
   return SWA_OK;
-}
+} SWA_CATCH

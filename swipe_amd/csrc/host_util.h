@@ -3,12 +3,22 @@
 #define SWA_HOST_UTIL_H
 #include <cstdint>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 namespace swa {
 // records the message returned by swa_last_error() on this thread and returns `code`
 int fail(int code, const std::string& msg);
+
+// No exception leaves the C ABI: every entry point that returns a status is a function-try-block closed by this.  The
+// reference ends the process when an allocation fails (xmalloc -> fatal, swipe.cc:158-182); a library hands the
+// decision to its caller.
+#define SWA_CATCH                                                                                               \
+  catch (const std::bad_alloc&) { return swa::fail(SWA_ENOMEM, "out of host memory"); }                         \
+  catch (const std::length_error& e) { return swa::fail(SWA_ENOMEM, std::string("size out of range: ") + e.what()); } \
+  catch (const std::exception& e) { return swa::fail(SWA_EINVAL, std::string("unexpected: ") + e.what()); }
 
 // A database (or a range of one) read from BLAST v4 files into host memory:
 // sequence s = residues[offsets[s] .. offsets[s+1]) in reference symbol codes.

@@ -101,7 +101,7 @@ int length_adjustment(double K, double logK, double a_over_l, double beta, int q
 }  // namespace
 
 extern "C" int swa_matrix_builtin(const char* name, int64_t* matrix)
-{
+try {
   if (!name || !matrix) return swa::fail(SWA_EINVAL, "swa_matrix_builtin: null argument");
   for (int k = 0; k < REFDATA_NMATRICES; ++k)
     if (strcasecmp(name, refdata_matrix_names[k]) == 0) {
@@ -111,19 +111,19 @@ extern "C" int swa_matrix_builtin(const char* name, int64_t* matrix)
       return SWA_OK;
     }
   return swa::fail(SWA_EINVAL, "unknown score matrix name");
-}
+} SWA_CATCH
 
 extern "C" int swa_matrix_nucleotide(int64_t match, int64_t mismatch, int64_t* matrix)
-{
+try {
   if (!matrix) return swa::fail(SWA_EINVAL, "swa_matrix_nucleotide: null argument");
   fill_default(matrix);
   for (int d = 1; d < 16; ++d)                                 // matrices.cc:533-538: exact equality of base masks
     for (int q = 1; q < 16; ++q) matrix[(d << 5) | q] = d == q ? match : mismatch;
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_matrix_parse(const char* text, int64_t* matrix)
-{
+try {
   // matrices.cc:352-430: '#'/blank lines skipped, a line starting with blank or tab names the
   // columns, any other line is "<row letter> score score ..." -> [(row << 5) | column]
   if (!text || !matrix) return swa::fail(SWA_EINVAL, "swa_matrix_parse: null argument");
@@ -158,10 +158,10 @@ extern "C" int swa_matrix_parse(const char* text, int64_t* matrix)
     p += len + (e ? 1 : 0);
   }
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_default_gaps(const char* matrixname, int64_t* gapopen, int64_t* gapextend)
-{
+try {
   if (!matrixname || !gapopen || !gapextend) return swa::fail(SWA_EINVAL, "swa_default_gaps: null argument");
   for (int t = 0; t < REFDATA_NKA; ++t)
     if (strcasecmp(matrixname, refdata_ka_tables[t].name) == 0)
@@ -172,14 +172,14 @@ extern "C" int swa_default_gaps(const char* matrixname, int64_t* gapopen, int64_
           return SWA_OK;
         }
   return swa::fail(SWA_EINVAL, "no default gap penalties for this matrix");
-}
+} SWA_CATCH
 
 extern "C" int swa_stats_init(int symtype, const char* matrixname, int64_t match, int64_t mismatch,
                               int64_t gapopen, int64_t gapextend, int64_t qlen,
                               int64_t db_seqcount, int64_t db_symcount, int64_t effdbsize,
                               int64_t minscore, int64_t maxscore, double minexpect, double expect,
                               swa_stats_t* out)
-{
+try {
   if (!out) return swa::fail(SWA_EINVAL, "swa_stats_init: null output");
   std::memset(out, 0, sizeof *out);
   out->scorethreshold = minscore;                                                         // hits.cc:486-487
@@ -213,7 +213,7 @@ extern "C" int swa_stats_init(int symtype, const char* matrixname, int64_t match
     if (by_min < maxscore) out->upperscorethreshold = by_min;
   }
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" double swa_evalue(const swa_stats_t* st, int64_t score)
 {
@@ -233,7 +233,7 @@ extern "C" const char* swa_gencode_name(int gencode)
 }
 
 extern "C" int swa_translate_table(int gencode, uint8_t* table)
-{
+try {
   if (!table) return swa::fail(SWA_EINVAL, "swa_translate_table: null output");
   if (!swa_gencode_name(gencode)) return swa::fail(SWA_EINVAL, "Illegal genetic code specified.");
   const char* code = refdata_gencode[gencode - 1];           // 64 letters, codon positions in T,C,A,G order
@@ -261,11 +261,11 @@ extern "C" int swa_translate_table(int gencode, uint8_t* table)
     table[t] = uint8_t(out);
   }
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_translate(const uint8_t* dna, int64_t dlen, int strand, int frame, const uint8_t* table,
                              uint8_t* prot, int64_t* plen)
-{
+try {
   if (!table || !plen || dlen < 0 || (dlen > 0 && !dna) || frame < 0 || frame > 2 || strand < 0 || strand > 1)
     return swa::fail(SWA_EINVAL, "swa_translate: bad argument");
   const int64_t n = dlen - frame > 0 ? (dlen - frame) / 3 : 0;
@@ -284,4 +284,4 @@ extern "C" int swa_translate(const uint8_t* dna, int64_t dlen, int strand, int f
     prot[k] = table[256 * a + 16 * b + c];
   }
   return SWA_OK;
-}
+} SWA_CATCH

@@ -1773,16 +1773,16 @@ int search_all(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, s
 extern "C" const char* swa_last_error(void) { return swa::g_last_error.c_str(); }
 
 extern "C" int swa_device_count(void)
-{
+try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} SWA_CATCH
 
 extern "C" int swa_db_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype,
                                   int device, int64_t first_seqno, int64_t total_seqcount,
                                   int64_t total_symcount, swa_db** out)
-{
+try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   if (nseq < 0 || !offsets || (!residues && nseq > 0 && offsets[nseq] > offsets[0]))
@@ -1803,11 +1803,11 @@ extern "C" int swa_db_from_memory(const uint8_t* residues, const int64_t* offset
   db->total_sym = total_symcount > 0 ? total_symcount : db->nsym;
   *out = db;
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_db_open(const char* basename, int symtype, int device, int64_t first_seqno,
                            int64_t last_seqno, swa_db** out)
-{
+try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   swa::HostDb h;
@@ -1822,12 +1822,12 @@ extern "C" int swa_db_open(const char* basename, int symtype, int device, int64_
     if (rc != SWA_OK) { swa_db_close(*out); *out = nullptr; }
   }
   return rc;
-}
+} SWA_CATCH
 
 extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
                                              int db_gencode, int device, int64_t first_seqno,
                                              int64_t total_seqcount, int64_t total_symcount, swa_db** out)
-{
+try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   if (nseq < 0 || !offsets || (!nt_residues && nseq > 0 && offsets[nseq] > offsets[0]))
@@ -1894,11 +1894,11 @@ extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const i
   guard.d = nullptr;
   *out = db;
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_db_open_translated(const char* basename, int db_gencode, int device, int64_t first_seqno,
                                       int64_t last_seqno, swa_db** out)
-{
+try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
   swa::HostDb h;
@@ -1912,12 +1912,12 @@ extern "C" int swa_db_open_translated(const char* basename, int db_gencode, int 
     if (rc != SWA_OK) { swa_db_close(*out); *out = nullptr; }
   }
   return rc;
-}
+} SWA_CATCH
 
 extern "C" int swa_blastdb_read(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno,
                                 uint8_t** residues, int64_t** offsets, int64_t* nseq, int64_t* total_seqcount,
                                 int64_t* total_symcount, int64_t* longest)
-{
+try {
   if (!residues || !offsets || !nseq) return fail(SWA_EINVAL, "null output");
   swa::HostDb h;
   const int rc = swa::read_blast_db(basename, symtype, first_seqno, last_seqno, h);
@@ -1932,12 +1932,12 @@ extern "C" int swa_blastdb_read(const char* basename, int symtype, int64_t first
   if (total_symcount) *total_symcount = h.total_symcount;
   if (longest) *longest = h.longest;
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" void swa_free(void* p) { std::free(p); }
 
 extern "C" int swa_blastdb_defline(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen, int64_t* seqlen)
-{
+try {
   if (!basename || !buf || buflen < 1) return fail(SWA_EINVAL, "bad argument");
   std::vector<std::string> d;
   std::vector<int64_t> len;
@@ -1946,10 +1946,10 @@ extern "C" int swa_blastdb_defline(const char* basename, int symtype, int64_t se
   std::snprintf(buf, size_t(buflen), "%s", d[0].substr(0, d[0].find('\n')).c_str());
   if (seqlen) *seqlen = len[0];
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_blastdb_deflines(const char* basename, int symtype, int64_t seqno, char* buf, int64_t buflen, int64_t* needed)
-{
+try {
   if (!basename || buflen < 0 || (buflen > 0 && !buf) || !needed) return fail(SWA_EINVAL, "bad argument");
   std::vector<std::string> d;
   std::vector<int64_t> len;
@@ -1959,10 +1959,10 @@ extern "C" int swa_blastdb_deflines(const char* basename, int symtype, int64_t s
   if (*needed > buflen) return fail(SWA_ERANGE, "defline buffer too small");
   std::memcpy(buf, d[0].c_str(), d[0].size() + 1);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
-{
+try {
   if (!db || !info) return fail(SWA_EINVAL, "null argument");
   info->seqcount = db->nseq / db->frames;
   info->symcount = db->frames == 1 ? db->nsym : db->nt_sym;
@@ -1973,10 +1973,10 @@ extern "C" int swa_db_info(const swa_db* db, swa_db_info_t* info)
   info->total_symcount = db->total_sym;
   info->hbm_bytes = int64_t(db->streamed ? streamed_hbm(db) : db->hbm_bytes());
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t n)
-{
+try {
   if (!db) return fail(SWA_EINVAL, "null database handle");
   if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   const int64_t real = db->nseq / db->frames;
@@ -2000,7 +2000,7 @@ extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t 
   db->view_of = nullptr;
   db->nwin = 0;
   return db->packed ? SWA_OK : ensure_main(db);
-}
+} SWA_CATCH
 
 extern "C" void swa_db_close(swa_db* db)
 {
@@ -2010,7 +2010,7 @@ extern "C" void swa_db_close(swa_db* db)
 }
 
 extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapopenextend, int64_t gapextend)
-{
+try {
   if (!db || !matrix) return fail(SWA_EINVAL, "null argument");
   int64_t lo = 100, hi = -100;                       // matrices.cc:561-572
   for (int i = 0; i < 1024; ++i) {
@@ -2035,7 +2035,7 @@ extern "C" int swa_set_scoring(swa_db* db, const int64_t* matrix, int64_t gapope
   db->scoring_set = true;
   db->bound_off.clear();
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters);
 
@@ -2227,7 +2227,7 @@ int download_scores(swa_db* db, const int32_t* dev, const DevBuf<long long>& dev
 #include "sw_streamed.inc"
 
 extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters)
-{
+try {
   if (db && db->streamed) {
     const int rc0 = check_query(db, query, qlen);
     return rc0 != SWA_OK ? rc0 : streamed_all_scores(db, query, qlen, scores, counters);
@@ -2235,12 +2235,12 @@ extern "C" int swa_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_
   const int rc = search_all(db, query, nullptr, qlen, counters);
   if (rc != SWA_OK || !scores || db->nseq == 0) return rc;
   return download_scores(db, db->scores.p, db->scores64, scores);
-}
+} SWA_CATCH
 
 extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore,
                                int64_t maxscore, swa_hit_t* hits, int64_t* nhits, int64_t* totalhits,
                                int64_t* obvious, swa_counters_t* counters)
-{
+try {
   if (keep < 0 || (keep > 0 && !hits) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
   *nhits = 0;
@@ -2261,11 +2261,11 @@ extern "C" int swa_search_topk(swa_db* db, const uint8_t* query, int64_t qlen, i
   for (size_t i = 0; i < k; ++i) hits[i] = {cand[i].seqno, cand[i].score};
   *nhits = int64_t(k);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
                            int64_t* scores1, int64_t* scores2, swa_counters_t* counters)
-{
+try {
   if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
   int rc = search_all(db, query1, query2 ? query2 : query1, qlen, counters);
@@ -2273,12 +2273,12 @@ extern "C" int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* que
   if (scores1) rc = download_scores(db, db->scores.p, db->scores64, scores1);
   if (rc == SWA_OK && scores2) rc = download_scores(db, db->scores2.p, db->scores64b, scores2);
   return rc;
-}
+} SWA_CATCH
 
 extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen, int64_t keep,
                                 int64_t minscore, int64_t maxscore, swa_hit_t* hits, int32_t* which, int64_t* nhits,
                                 int64_t* totalhits, int64_t* obvious, swa_counters_t* counters)
-{
+try {
   if (keep < 0 || (keep > 0 && (!hits || !which)) || !nhits) return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
   if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
@@ -2301,7 +2301,7 @@ extern "C" int swa_search2_topk(swa_db* db, const uint8_t* query1, const uint8_t
   for (size_t i = 0; i < k; ++i) { hits[i] = {cand[i].seqno, cand[i].score}; which[i] = cand[i].which; }
   *nhits = int64_t(k);
   return SWA_OK;
-}
+} SWA_CATCH
 
 // Two different queries of a multi-query file in one pass (swipe.cc:2561-2575: the reference's unit of work is a query
 // FILE): each query keeps its own hit list, thresholds and counts; results equal two swa_search_topk calls.
@@ -2310,7 +2310,7 @@ extern "C" int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t q
                                     int64_t maxscore2, swa_hit_t* hits1, int64_t* nhits1, int64_t* totalhits1, int64_t* obvious1,
                                     swa_hit_t* hits2, int64_t* nhits2, int64_t* totalhits2, int64_t* obvious2,
                                     swa_counters_t* counters)
-{
+try {
   if (keep1 < 0 || keep2 < 0 || (keep1 > 0 && !hits1) || (keep2 > 0 && !hits2) || !nhits1 || !nhits2)
     return fail(SWA_EINVAL, "bad hit buffer");
   if (db && db->frames != 1) return fail(SWA_ESTATE, "translated shard: use swa_search_frames_topk");
@@ -2349,13 +2349,13 @@ extern "C" int swa_search_pair_topk(swa_db* db, const uint8_t* query1, int64_t q
   *nhits1 = int64_t(k1);
   *nhits2 = int64_t(k2);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* queries, const int64_t* qlens,
                                       const int32_t* qtags, int64_t keep, int64_t minscore, int64_t maxscore,
                                       swa_fhit_t* hits, int64_t* nhits, int64_t* totalhits, int64_t* obvious,
                                       swa_counters_t* counters)
-{
+try {
   if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (!db) return fail(SWA_EINVAL, "null database handle");
   if (nq < 1 || nq > 6 || !queries || !qlens) return fail(SWA_EINVAL, "between 1 and 6 query frames expected");
@@ -2388,10 +2388,10 @@ extern "C" int swa_search_frames_topk(swa_db* db, int nq, const uint8_t* const* 
   }
   *nhits = int64_t(k);
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_set_option(swa_db* db, const char* key, const char* value)
-{
+try {
   if (!db || !key) return fail(SWA_EINVAL, "null argument");
   for (const OptionKey& k : kOptionKeys)
     if (!std::strcmp(k.key, key)) {
@@ -2403,7 +2403,7 @@ extern "C" int swa_set_option(swa_db* db, const char* key, const char* value)
       return SWA_OK;
     }
   return fail(SWA_EINVAL, std::string("unknown option ") + key);
-}
+} SWA_CATCH
 
 namespace {
 // index of (seqno, dstrand, dframe) among the sequences the shard holds; *minus = reverse-complement on the fly
@@ -2568,7 +2568,7 @@ int fetch_sequences(swa_db* db, const int64_t* seqnos, const int32_t* dstrands, 
 extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
                                            const int32_t* dstrands, const int32_t* dframes, int64_t n, int64_t* scores,
                                            int64_t* bestpos, int64_t* bestq)
-{
+try {
   if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
@@ -2583,17 +2583,17 @@ extern "C" int swa_search_endpoints_strand(swa_db* db, const uint8_t* query, int
     bestq[i] = out[size_t(2 * n + i)];
   }
   return SWA_OK;
-}
+} SWA_CATCH
 
 extern "C" int swa_search_endpoints(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos, int64_t n,
                                     int64_t* scores, int64_t* bestpos, int64_t* bestq)
-{
+try {
   return swa_search_endpoints_strand(db, query, qlen, seqnos, nullptr, nullptr, n, scores, bestpos, bestq);
-}
+} SWA_CATCH
 
 extern "C" int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, int dframe, uint8_t* buf, int64_t cap,
                                int64_t* len, int64_t* ntlen)
-{
+try {
   if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   if (!db || !len || cap < 0 || (cap > 0 && !buf)) return fail(SWA_EINVAL, "bad argument");
   std::vector<uint8_t> seq;
@@ -2604,7 +2604,7 @@ extern "C" int swa_db_sequence(swa_db* db, int64_t seqno, int dstrand, int dfram
   if (int64_t(seq.size()) > cap) return fail(SWA_ERANGE, "sequence buffer too small");
   if (!seq.empty()) std::memcpy(buf, seq.data(), seq.size());
   return SWA_OK;
-}
+} SWA_CATCH
 
 namespace {
 // hits_align's call of align() (hits.cc:585-616) for one sequence already on the host.  hint_score != 0:
@@ -2637,7 +2637,7 @@ int align_on_host(const uint8_t* query, int64_t qlen, const uint8_t* dseq, int64
 extern "C" int swa_traceback(const uint8_t* query, int64_t qlen, const uint8_t* dseq, int64_t dlen, const int64_t* M,
                              int64_t gapopen, int64_t gapextend, int64_t hint_score, int64_t hint_q_end,
                              int64_t hint_d_end, swa_alignment_t* out, char* text, int64_t text_cap, int64_t* text_used)
-{
+try {
   if (!query || !dseq || !M || !out || !text_used || text_cap < 0 || (text_cap > 0 && !text) || qlen < 0 || dlen < 0)
     return fail(SWA_EINVAL, "bad argument");
   for (int64_t i = 0; i < qlen; ++i) if (query[i] >= 32) return fail(SWA_EINVAL, "query symbol code >= 32");
@@ -2657,14 +2657,14 @@ extern "C" int swa_traceback(const uint8_t* query, int64_t qlen, const uint8_t* 
   if (*text_used > text_cap) return fail(SWA_ERANGE, "text buffer too small for the edit script");
   std::memcpy(text, s.c_str(), s.size() + 1);
   return SWA_OK;
-}
+} SWA_CATCH
 
 // align_chunk + hits_align (swipe.cc:339-414, hits.cc:546-618): end points on the GPU, start point and edit
 // script on the host
 extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, const int64_t* seqnos,
                               const int32_t* dstrands, const int32_t* dframes, int64_t n, swa_alignment_t* out,
                               char* text, int64_t text_cap, int64_t* text_used)
-{
+try {
   if (not_streamed(db) != SWA_OK) return SWA_ESTATE;
   int rc = check_query(db, query, qlen);
   if (rc != SWA_OK) return rc;
@@ -2726,4 +2726,4 @@ extern "C" int swa_align_hits(swa_db* db, const uint8_t* query, int64_t qlen, co
   if (int64_t(all.size()) > text_cap) return fail(SWA_ERANGE, "text buffer too small for the edit scripts");
   std::memcpy(text, all.data(), all.size());
   return SWA_OK;
-}
+} SWA_CATCH

@@ -24,7 +24,7 @@ struct swa_db {
   int frames = 1;
   uint64_t scoring = 0;
   std::vector<uint8_t> include;
-  bool fail_search = false;
+  bool fail_search = false, throw_search = false;
 };
 
 static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; return x ^ (x >> 33); }
@@ -65,6 +65,7 @@ int swa_set_scoring(swa_db* d, const int64_t* m, int64_t goe, int64_t ge) { d->s
 int swa_set_option(swa_db* d, const char* key, const char* value)
 {
   if (!std::strcmp(key, "fail_search")) { d->fail_search = value && value[0] == '1' && d->first > 100; return SWA_OK; }   // every shard but the first
+  if (!std::strcmp(key, "throw_search")) { d->throw_search = value && value[0] == '1' && d->first > 100; return SWA_OK; }
   return std::strcmp(key, "bound") ? swa::fail(SWA_EINVAL, std::string("unknown option ") + key) : SWA_OK;
 }
 int swa_db_set_inclusion(swa_db* d, const uint8_t* inc, int64_t n)
@@ -77,6 +78,7 @@ static bool included(const swa_db* d, int64_t local) { return d->include.empty()
 int swa_search(swa_db* d, const uint8_t* q, int64_t qlen, int64_t* scores, swa_counters_t* c)
 {
   if (d->fail_search) return swa::fail(SWA_ENOMEM, "stand-in failure");
+  if (d->throw_search) throw std::bad_alloc();           // the real C ABI never throws (SWA_CATCH); the group survives one that does
   const uint64_t qh = qhash(q, qlen);
   for (int64_t s = 0; s < d->nseq && scores; ++s)
     for (int f = 0; f < d->frames; ++f) scores[s * d->frames + f] = included(d, s) ? fake_score(d, d->first + s, f, qh) : -1;

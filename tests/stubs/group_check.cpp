@@ -107,6 +107,13 @@ static void run(int nseq, int nshards, int gencode, unsigned seed)
     EXPECT(std::strstr(swa_last_error(), "shard 1") != nullptr);
     EXPECT(swa_group_set_option(g, "fail_search", "0") == SWA_OK);
     EXPECT(swa_group_search_topk(g, q, 4, 4, 0, 100, h, &n, nullptr, nullptr, nullptr) == SWA_OK);
+    // an exception on a shard's thread becomes a status on the caller's
+    EXPECT(swa_group_set_option(g, "throw_search", "1") == SWA_OK);
+    std::vector<int64_t> all(size_t(nseq * frames) + 1);
+    EXPECT(swa_group_search(g, q, 4, all.data(), nullptr) == SWA_ENOMEM);
+    EXPECT(std::strstr(swa_last_error(), "exception on a shard's thread") != nullptr);
+    EXPECT(swa_group_set_option(g, "throw_search", "0") == SWA_OK);
+    EXPECT(swa_group_search(g, q, 4, all.data(), nullptr) == SWA_OK);
   }
   swa_group_close(g);
   swa_group_close(ref);

@@ -514,6 +514,31 @@ def test_group_layer_is_thread_sanitizer_clean(tmp_path):
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "group check ok" in r.stdout, r.stderr[-3000:]
 
 
+def test_no_exception_leaves_the_c_abi():
+    """Every entry point of the host translation units that returns a status is a function-try-block closed by SWA_CATCH
+    (csrc/host_util.h: std::bad_alloc / length_error -> SWA_ENOMEM, anything else -> SWA_EINVAL with its text): the
+    reference ends the process when an allocation fails (xmalloc -> fatal, swipe.cc:158-182), a library leaves that to
+    its caller.  (What a shard's thread of swa_group does with an exception is exercised by the ThreadSanitizer test.)"""
+    import re
+    csrc = os.path.join(ROOT, "swipe_amd", "csrc")
+    seen = 0
+    for name in ("swipe_amd.cpp", "group.cpp", "blastdb.cpp", "scoring.cpp", "sw_streamed.inc"):
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'^extern "C" (?:int|int64_t) (swa_\w+)\(', text, flags=re.M):
+            rest = text[m.end():]
+            end_of_sig = re.search(r'\)\s*(;|\{|try \{)', rest)
+            assert end_of_sig, m.group(1)
+            if end_of_sig.group(1) == ";":
+                continue                                          # a declaration
+            body = rest[end_of_sig.end():]
+            if end_of_sig.group(1) == "{" and "\n" not in body[:body.index("}")]:
+                continue                                          # a one-line accessor: nothing in it allocates
+            assert end_of_sig.group(1) == "try {", "%s in %s is not a function-try-block" % (m.group(1), name)
+            assert re.search(r'^\} SWA_CATCH$', body, flags=re.M), m.group(1)
+            seen += 1
+    assert seen >= 50, seen
+
+
 def test_bound_reference_binaries_have_no_cpu_path(tmp_path):
     """oracle/_ref/swipe_bound_* (the reference with INTEGRATION.md's binding spliced in, linked against libswipe_amd.so)
     start, parse SWIPE's options, open the database with the reference's own db_open - and, without a device, stop in the
