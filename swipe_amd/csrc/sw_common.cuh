@@ -20,6 +20,7 @@ __device__ __forceinline__ u32 as_u32(h2 v) { return __builtin_bit_cast(u32, v);
 
 #define DPP_ROW_SHR1 0x111
 #define DPP_ROW_SHL1 0x101
+#define DPP_ROW_ROR1 0x121       /* rotate right within the 16 lanes of a row: lane 0 takes lane 15's */
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
 // value of lane-1 within the 16-lane row; lane 0 of each row receives `fill`
