@@ -26,6 +26,20 @@ __device__ __forceinline__ u32 as_u32(h2 v) { return __builtin_bit_cast(u32, v);
 // value of lane-1 within the 16-lane row; lane 0 of each row receives `fill`
 __device__ __forceinline__ u32 row_shr1(u32 v, u32 fill)
 { return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_ROW_SHR1, 0xF, 0xF, false); }
+// The residue register of a chain of G lanes moves on by one lane and the chain's first lane takes `fresh`.  A 16-lane
+// chain is a DPP row: shift, with `fresh` preset where no lane sends (a v_mov, since the preset has to sit in the
+// destination).  Shorter chains need a select for the first lanes inside the row anyway: rotate instead (every lane
+// has a sender, nothing to preset) and select on all first lanes - one instruction less per step.
+template <int G>
+__device__ __forceinline__ u32 chain_advance(u32 cur, u32 fresh, bool first)
+{
+  if constexpr (G < 16) {
+    const u32 r = (u32)__builtin_amdgcn_mov_dpp((int)cur, DPP_ROW_ROR1, 0xF, 0xF, false);
+    return first ? fresh : r;
+  } else {
+    return row_shr1(cur, fresh);
+  }
+}
 __device__ __forceinline__ u32 row_shl1(u32 v)
 { return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHL1, 0xF, 0xF, false); }
 

@@ -321,7 +321,6 @@ swa_narrow_split_kernel(swa_narrow_params p)
   const int lane = threadIdx.x & 63;
   const int lg = lane & (G - 1), pairno = lane / G;       // pair of the wave: batch pairno >> 2, row pairno & 3
   const u32 l16 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (u32)(lane & 15) * 16;
-  const bool inner_first = lg == 0 && (lane & 15) != 0;   // first lane of a pair that is not first in its DPP row
   const h2 negQR = as_h2(p.negQR), negR = as_h2(p.negR);
   const h2 zero = {0, 0};
   const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
@@ -387,8 +386,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
 #define SWA_STEPG(ODD)                                                                         \
     {                                                                                          \
       const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
-      const u32 shifted = row_shr1(cur, pl);                                                   \
-      cur = inner_first ? pl : shifted;                                                        \
+      cur = chain_advance<G>(cur, pl, lg == 0);                                                   \
       pl = pl2;                                                                                \
       h2 hup, F;                                                                               \
       if constexpr (MP) {       /* lane 0 keeps the hand-over of its column, which then moves on one lane */ \
@@ -476,8 +474,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
 #define SWA_ADVANCE()                                                                          \
       {                                                                                        \
         const u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)pl, DPP_ROW_SHL1, 0xF, 0xF, true); \
-        const u32 shifted = row_shr1(cur, pl);                                                 \
-        cur = inner_first ? pl : shifted;                                                      \
+        cur = chain_advance<G>(cur, pl, lg == 0);                                                   \
         pl = pl2;                                                                              \
         aoff = (cur & 0xFFFF) | l16;                                                           \
         boff = (cur >> 16) | l16;                                                              \
