@@ -478,7 +478,10 @@ def main():
     import torch
     import swipe_amd
     from swipe_amd import blastdb, parallel, synth
-    if not torch.cuda.is_available() or swipe_amd._lib.load().swa_device_count() <= local:
+    ndev = swipe_amd._lib.load().swa_device_count() if torch.cuda.is_available() else 0
+    if ndev == 1 and "SWA_BENCH_DEVICE" not in os.environ:
+        local = 0           # a launcher that narrows each rank's view to its own GPU (HIP_VISIBLE_DEVICES per rank)
+    if ndev <= local:
         raise SystemExit("bench.py needs a HIP device per rank (swipe_amd has no CPU path)")
     torch.cuda.set_device(local)
     dist = None
