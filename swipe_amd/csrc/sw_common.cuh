@@ -30,6 +30,13 @@ __device__ __forceinline__ u32 row_shr1(u32 v, u32 fill)
 // chain is a DPP row: shift, with `fresh` preset where no lane sends (a v_mov, since the preset has to sit in the
 // destination).  Shorter chains need a select for the first lanes inside the row anyway: rotate instead (every lane
 // has a sender, nothing to preset) and select on all first lanes - one instruction less per step.
+// LDS offsets of a stream word's two residues (low byte: the pair's first sequence) as offA | offB << 16, cs = bytes per
+// residue of the profile.  Written with 24-bit multiplies: left alone the compiler folds the shift into the factor
+// ((raw >> 8) * (cs << 16)), which no longer fits 24 bits and costs a quarter-rate v_mul_lo_u32 per block of columns.
+__device__ __forceinline__ u32 pair_offsets(u32 raw, u32 cs)
+{
+  return __umul24(raw & 0xFFu, cs) + __umul24(raw & 0xFF00u, cs << 8);
+}
 template <int G>
 __device__ __forceinline__ u32 chain_advance(u32 cur, u32 fresh, bool first)
 {

@@ -217,7 +217,7 @@ swa_narrow_kernel(swa_narrow_params p)
 
     for (int m = 0; m <= nchunks; ++m) {
       // residues of the 16 steps of this chunk, pre-scaled to LDS byte offsets
-      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+      u32 pl = pair_offsets(raw, CS);
       raw = (m + 1 < nchunks) ? (u32)s[(int64_t)(m + 1) * 64 + lane] : (u32)(SWA_PAD | (SWA_PAD << 8));
 
 #pragma unroll 2
@@ -443,7 +443,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
 
     if constexpr (PIPE != 2) {
       for (int m = 0; m * G < total; ++m) {               // m-th block of G columns of the 16-column chunks
-        u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+        u32 pl = pair_offsets(raw, CS);
         const int col = (m + 1) * G;
         raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW;
         const int n = total - m * G < G ? total - m * G : G;
@@ -467,7 +467,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
     } else {
       // PIPE == 2: the residue register is advanced and the first profile unit of a step is fetched while the
       // previous step still computes, so no LDS latency is exposed at a step boundary
-      u32 pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);
+      u32 pl = pair_offsets(raw, CS);
       raw = ((G >> 4) < mychunks) ? (u32)s[(int64_t)(G >> 4) * 64 + (G & 15)] : PADRAW;
       u32 aoff, boff;
       u4v na, nb;
@@ -495,7 +495,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
             nb = *(lds_u4_ptr)(uintptr_t)(boff + (c + 1) * 256);                               \
           } else {      /* last unit in flight: the next step's residue offsets and its unit 0 */ \
             if (RELOAD) {                                                                      \
-              pl = ((raw & 0xFF) * CS) | (((raw >> 8) * CS) << 16);                            \
+              pl = pair_offsets(raw, CS);                                                      \
               const int col = (m + 2) * G;                                                     \
               raw = ((col >> 4) < mychunks) ? (u32)s[(int64_t)(col >> 4) * 64 + (col & 15)] : PADRAW; \
             }                                                                                  \

@@ -224,11 +224,11 @@ def test_one_lane_bound_build_is_the_default_up_to_60_rows():
     db = swipe_amd.Database.from_arrays(res, off)
     db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
     Mo = oracle.matrix_builtin("BLOSUM62")
-    for qlen, form, rows in ((49, 8, 49), (60, 8, 60), (61, 8, 31)):
-        q = full[:qlen]
+    for qlen, form, rows in ((49, 8, (49,)), (60, 8, (60,)), (61, 8, (31, 32, 33, 34))):   # 61: two lanes of ceil(61 / 2) rows,
+        q = full[:qlen]                                                                    # or up to 3 more (kernel_choice.cpp)
         want = oracle.search_all63(res, off, q, Mo, 12, 1, threads=THREADS)
         hits, tot, obv, c = db.search_topk(q, keep=30, minscore=70)
-        assert (c["narrow_shifted"], c["narrow_rows"]) == (form, rows), c
+        assert c["narrow_shifted"] == form and c["narrow_rows"] in rows, c
         assert (hits, tot, obv) == _expected_topk(want, 30, 70)
         scores, c = db.search(q)
         assert c["narrow_shifted"] == 7 and np.array_equal(scores, want)
