@@ -89,11 +89,13 @@ struct swa_group {
   std::vector<int> device;
   std::vector<int64_t> first, count;                      // global number of a shard's first sequence, its sequences
   std::vector<std::unique_ptr<Worker>> worker;
+  std::mutex call;                                        // the contract is one caller at a time; two are serialised, not mixed up
   int frames = 1;
 
   // fn(i) on every shard's own thread, all at once; the first failure (by shard number) is reported
   int run_all(const std::function<int(int)>& fn)
   {
+    std::lock_guard<std::mutex> one_caller(call);
     const int n = int(worker.size());
     for (int i = 0; i < n; ++i) worker[size_t(i)]->post([&fn, i] { return fn(i); });
     int rc = SWA_OK;
@@ -107,6 +109,7 @@ struct swa_group {
   }
   int run_one(int i, const std::function<int()>& fn)
   {
+    std::lock_guard<std::mutex> one_caller(call);
     worker[size_t(i)]->post(fn);
     std::string e;
     const int r = worker[size_t(i)]->wait(&e);
@@ -491,8 +494,10 @@ try {
 extern "C" int swa_fhits_merge(const swa_fhit_t* lists, const int64_t* counts, int nlists, int64_t stride, int64_t keep,
                                swa_fhit_t* out, int64_t* nout)
 try {
-  if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
+  if (!lists || !counts || nlists < 0 || keep < 0 || stride < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
   std::vector<swa_fhit_t> all;
+  for (int l = 0; l < nlists; ++l)
+    if (counts[l] < 0 || counts[l] > stride) return fail(SWA_EINVAL, "a list longer than its stride");
   for (int l = 0; l < nlists; ++l)
     for (int64_t i = 0; i < counts[l]; ++i) all.push_back(lists[int64_t(l) * stride + i]);
   std::stable_sort(all.begin(), all.end(), [](const swa_fhit_t& a, const swa_fhit_t& b) {
@@ -508,8 +513,10 @@ try {
 extern "C" int swa_hits_merge(const swa_hit_t* lists, const int64_t* counts, int nlists, int64_t stride,
                               int64_t keep, swa_hit_t* out, int64_t* nout)
 try {
-  if (!lists || !counts || nlists < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
+  if (!lists || !counts || nlists < 0 || keep < 0 || stride < 0 || !nout || (keep > 0 && !out)) return fail(SWA_EINVAL, "bad argument");
   std::vector<swa_hit_t> all;
+  for (int l = 0; l < nlists; ++l)
+    if (counts[l] < 0 || counts[l] > stride) return fail(SWA_EINVAL, "a list longer than its stride");
   for (int l = 0; l < nlists; ++l)
     for (int64_t i = 0; i < counts[l]; ++i) all.push_back(lists[int64_t(l) * stride + i]);
   std::stable_sort(all.begin(), all.end(), hit_before);
