@@ -381,6 +381,79 @@ Writes a synthetic BLAST v4 protein database to local disk, runs swipe_amd_cli o
             mode, ts[0], len(pick), ts[1], per * 1e3, np.mean(kms), 100 * np.mean(kms) / (per * 1e3)))
     subprocess.run(["rm", "-rf", d])
 
+def cmd_dropin(a):
+    """What a SWIPE user sees after the switch: the SAME query file against the SAME BLAST v4 database on local disk through
+(1) the unmodified reference (oracle/_ref/swipe, SSSE3, best -a), (2) the reference with search_chunk() bound to the library
+- binding A (every score through hits_enter), B (top-K on the device), C (B over swa_group) - and (3) swipe_amd_cli.
+Steady-state seconds per query = (T_N - T_1) / (N - 1); -m 8 output of all five must be identical or the tool fails."""
+    import os, sys, time, tempfile, subprocess, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    nseq, nq = a.nseq, a.nq
+    q = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, nseq, query=q)
+    d = tempfile.mkdtemp(prefix="dropin_", dir="/tmp")
+    nvol = max(1, int(np.ceil((off[-1] + nseq) / 3.5e9)))
+    names = []
+    for v in range(nvol):
+        lo, hi = nseq * v // nvol, nseq * (v + 1) // nvol
+        name = os.path.join(d, "db.%02d" % v)
+        blastdb.write_protein_volume_arrays(name, res, off[lo:hi + 1], first_id=lo)
+        names.append(name)
+    blastdb.write_alias(os.path.join(d, "db"), names, protein=True)
+    lens = np.diff(off)
+    cand = np.nonzero((lens > 330) & (lens < 420))[0]
+    pick = cand[:: max(1, len(cand) // nq)][:nq]
+    sym = "-ABCDEFGHIKLMNPQRSTVWXYZU*OJ"
+    def fasta(ids, path):
+        with open(path, "w") as f:
+            for i in ids:
+                f.write(">q%d\n%s\n" % (i, "".join(sym[c] for c in res[off[i]:off[i + 1]])))
+    fasta(pick[:1], os.path.join(d, "q1.fa"))
+    fasta(pick, os.path.join(d, "qn.fa"))
+    fasta(pick[:a.ref_queries], os.path.join(d, "qr.fa"))
+    cells = float(off[-1]) * float(np.mean([lens[i] for i in pick]))
+    del res, off
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "oracle", "_ref")
+    progs = [("reference (SSSE3, -a %d)" % a.ref_threads, os.path.join(ref, "swipe"), ["-a", str(a.ref_threads)], a.ref_queries),
+             ("reference + binding A (all scores -> hits_enter)", os.path.join(ref, "swipe_bound_scores"), ["-a", "1"], nq),
+             ("reference + binding B (top-K on the device)", os.path.join(ref, "swipe_bound_topk"), ["-a", "1"], nq),
+             ("reference + binding C (swa_group, 1 shard)", os.path.join(ref, "swipe_bound_group"), ["-a", "1"], nq),
+             ("swipe_amd_cli", os.path.join(os.path.dirname(swipe_amd.__file__), "swipe_amd_cli"), [], nq)]
+    strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("#"))
+    outs = {}
+    print("%d sequences, %d queries of %d..%d aa, -m 8 -v 250 -b 250 -e 10; %.3g cells per query" % (nseq, nq, min(lens[pick]), max(lens[pick]), cells))
+    for label, exe, extra, n in progs:
+        if not os.path.exists(exe):
+            print("%-52s not built" % label); continue
+        # n < nq: the CPU reference takes seconds per query, it gets the first few only (qr.fa)
+        ts = []
+        for qf in ("q1.fa", "qn.fa" if n == nq else "qr.fa"):
+            best = 1e9
+            for _ in range(a.reps):
+                out = os.path.join(d, "out_%s.txt" % os.path.basename(exe))
+                t = time.time()
+                r = subprocess.run([exe, "-d", os.path.join(d, "db"), "-i", os.path.join(d, qf), "-o", out, "-m", "8", "-v", "250", "-b", "250",
+                                    "-e", "10"] + extra, capture_output=True, text=True)
+                best = min(best, time.time() - t)
+                if r.returncode:
+                    print(label, "failed:", r.stderr[-500:]); sys.exit(1)
+            ts.append(best)
+            if qf != "q1.fa":
+                outs[label] = (n, strip(open(out).read()))
+        per = (ts[1] - ts[0]) / max(1, n - 1)
+        print("%-52s first query %6.2f s (open + search), then %8.1f ms per query = %7.0f GCUPS end to end" % (label, ts[0], per * 1e3, cells / per / 1e9))
+    full = [v[1] for k, v in outs.items() if v[0] == nq]
+    if any(x != full[0] for x in full):
+        print("OUTPUT DIFFERS between the bound programs"); sys.exit(1)
+    for k, (n, text) in outs.items():
+        if n < nq and not full[0].startswith(text.rstrip("\n")):
+            print("OUTPUT of %s differs from the bound programs' on the first %d queries" % (k, n)); sys.exit(1)
+    print("output: identical (%d hit lines for %d queries%s)" % (len(full[0].splitlines()), nq,
+          "; the unmodified reference's first %d queries equal the same lines" % a.ref_queries if a.ref_queries < nq else ""))
+    subprocess.run(["rm", "-rf", d])
+
 
 def cmd_align(a):
     """How long does the alignment phase take?  250 hits of the 375-aa bench query, and a long-query / long-sequence
@@ -652,6 +725,13 @@ def main():
     p.add_argument("--nseq", type=int, default=10_000_000)
     p.add_argument("--reps", type=int, default=10)
     p.set_defaults(fn=cmd_group)
+    p = sub.add_parser("dropin")
+    p.add_argument("--nseq", type=int, default=10_000_000)
+    p.add_argument("--nq", type=int, default=16)
+    p.add_argument("--reps", type=int, default=2)
+    p.add_argument("--ref-threads", type=int, default=16)
+    p.add_argument("--ref-queries", type=int, default=3)
+    p.set_defaults(fn=cmd_dropin)
     a = ap.parse_args()
     a.fn(a)
 
