@@ -444,6 +444,24 @@ def test_merge_hit_arrays_equals_merge_hits():
         assert [tuple(x) for x in got.tolist()] == swipe_amd.merge_hits(lists, keep)
 
 
+def test_merges_reject_lists_that_cannot_be():
+    """a negative keep used to become a huge size_t (every hit copied into a buffer sized for none); a count beyond the
+    stride would read the next shard's entries"""
+    import ctypes as C
+    from swipe_amd import _lib
+    L = _lib.load()
+    for fn, T in ((L.swa_hits_merge, _lib.Hit), (L.swa_fhits_merge, _lib.FrameHit)):
+        buf, out, nout = (T * 8)(), (T * 8)(), C.c_int64(-1)
+        cnt = (C.c_int64 * 2)(2, 2)
+        assert fn(buf, cnt, 2, 4, 3, out, C.byref(nout)) == 0 and nout.value == 3
+        assert fn(buf, cnt, 2, 4, -1, out, C.byref(nout)) != 0
+        cnt[1] = 5
+        assert fn(buf, cnt, 2, 4, 3, out, C.byref(nout)) != 0
+        cnt[1] = -1
+        assert fn(buf, cnt, 2, 4, 3, out, C.byref(nout)) != 0
+        assert b"stride" in L.swa_last_error()
+
+
 def test_synth_offsets_place_a_shard_of_one_database():
     """bench.py --gpus N: every rank derives the global length table, takes its shard_bounds slice and generates only
     that slice; the slices concatenate to the database a single rank generates"""
