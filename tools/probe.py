@@ -391,6 +391,7 @@ Steady-state seconds per query = (T_N - T_1) / (N - 1); -m 8 output of all five 
     from swipe_amd import synth, blastdb
     nseq, nq = a.nseq, a.nq
     q = blastdb.encode_protein(synth.QUERY_P07327)
+    t_start = time.time()
     res, off = swipe_amd.synth_db(1, nseq, query=q)
     d = tempfile.mkdtemp(prefix="dropin_", dir="/tmp")
     nvol = max(1, int(np.ceil((off[-1] + nseq) / 3.5e9)))
@@ -423,8 +424,10 @@ Steady-state seconds per query = (T_N - T_1) / (N - 1); -m 8 output of all five 
              ("swipe_amd_cli", os.path.join(os.path.dirname(swipe_amd.__file__), "swipe_amd_cli"), [], nq)]
     strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("#"))
     outs = {}
+    print("database generated and written as %d BLAST v4 volume(s) in %.1f s" % (nvol, time.time() - t_start), flush=True)
     print("%d sequences, %d queries of %d..%d aa, -m 8 -v 250 -b 250 -e 10; %.3g cells per query" % (nseq, nq, min(lens[pick]), max(lens[pick]), cells))
     for label, exe, extra, n in progs:
+        t_prog = time.time()
         if not os.path.exists(exe):
             print("%-52s not built" % label); continue
         # n < nq: the CPU reference takes seconds per query, it gets the first few only (qr.fa)
@@ -443,7 +446,7 @@ Steady-state seconds per query = (T_N - T_1) / (N - 1); -m 8 output of all five 
             if qf != "q1.fa":
                 outs[label] = (n, strip(open(out).read()))
         per = (ts[1] - ts[0]) / max(1, n - 1)
-        print("%-52s first query %6.2f s (open + search), then %8.1f ms per query = %7.0f GCUPS end to end" % (label, ts[0], per * 1e3, cells / per / 1e9), flush=True)
+        print("%-52s first query %6.2f s (open + search), then %8.1f ms per query = %7.0f GCUPS end to end" % (label, ts[0], per * 1e3, cells / per / 1e9) + "   [%.0f s in all]" % (time.time() - t_prog), flush=True)
     full = [v[1] for k, v in outs.items() if v[0] == nq]
     if any(x != full[0] for x in full):
         print("OUTPUT DIFFERS between the bound programs"); sys.exit(1)
