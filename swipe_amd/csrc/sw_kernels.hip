@@ -314,7 +314,7 @@ swa_narrow_split_kernel(swa_narrow_params p)
   constexpr u32 CS = C * 256;
   constexpr int NB = 16 / G;                              // batches per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  if constexpr (!MP) signal_block_started(p.done);
+  if constexpr (!MP) signal_block_started(p.done, W);
   build_profile_f16_split<K, G>(lds, p.query, p.gapextend_f, MP ? p.row0 : 0);
   __syncthreads();
 
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(64)
 swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restrict__ work, const int32_t* done,
                           const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
                           int* __restrict__ scores, int32_t* list_b, int32_t* __restrict__ work_b,
-                          const uint8_t* __restrict__ qseq_b, int qlen_b, int* __restrict__ scores_b)
+                          const uint8_t* __restrict__ qseq_b, int qlen_b, int* __restrict__ scores_b, int cus)
 {
   __shared__ int M[1024];
   __shared__ uint8_t ring[128];
@@ -837,7 +837,6 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
     list = list_b; work = work_b; qseq = qseq_b; qlen = qlen_b; scores = scores_b;
   }
   for (int i = g; i < 1024; i += 64) M[i] = matrix[i];
-  bool started = false;                                    // lane 0: the producer has been seen on the device
   for (;;) {
     __syncthreads();
     if (g == 0) {
@@ -846,7 +845,7 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
       if (w < cap) {
         // relaxed polls a few microseconds apart: an acquire per poll would invalidate the CU's caches under the
         // first-pass waves next door (measured: 1 024 polling waves cost the first pass 37 %)
-        for (int polls = 0;; ++polls) {
+        for (int polls = 1;; ++polls) {
           id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (id >= 0) break;
           if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -854,12 +853,16 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
             id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;                                // still -1: position w lies beyond the end of the list
           }
-          // The producer was submitted before this kernel, but a profiler that runs one kernel at a time may have
-          // dispatched this one first: never wait for a kernel that is not on the device.  About a millisecond without
-          // a sign of it and the follower leaves; the finishing kernel does all the work then.
-          if (!started) {
-            started = __hip_atomic_load(done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (!started && polls > 128) { fin = 1; id = -1; break; }
+          // Never wait for blocks that are not on the device (signal_block_started): about a millisecond without an entry
+          // and the follower looks at the producer - none of its blocks started (a profiler that runs one kernel at a
+          // time dispatched this one first) or fewer than the device holds of it when nothing is in the way (the missing
+          // ones may be waiting for the registers this very wave holds) and it leaves; the finishing kernel does the work
+          // then.  A producer that is all there is waited for.
+          if ((polls & 127) == 0) {
+            const int on = __hip_atomic_load(done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int grid = __hip_atomic_load(done + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int fit = cus * __hip_atomic_load(done + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (on == 0 || on < (grid < fit ? grid : fit)) { fin = 1; id = -1; break; }
           }
           __builtin_amdgcn_s_sleep(127);
           __builtin_amdgcn_s_sleep(127);
@@ -1178,11 +1181,11 @@ extern "C" hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t*
 extern "C" hipError_t swa_launch_requeue_follow(const swa_seqs* sq, int32_t* list, int cap,
                                                 int32_t* work, const int32_t* done, const uint8_t* qseq, int qlen,
                                                 const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st,
-                                                int32_t* list_b, int32_t* work_b, const uint8_t* qseq_b, int qlen_b, int* scores_b)
+                                                int32_t* list_b, int32_t* work_b, const uint8_t* qseq_b, int qlen_b, int* scores_b, int cus)
 {
   if (list_b) blocks *= 2;
 #define SWA_RQF(KK) hipLaunchKernelGGL((swa_requeue_follow_kernel<KK>), dim3(blocks), dim3(64), 0, st, *sq, list, cap, \
-                                       work, done, qseq, qlen, matrix, Q, R, scores, list_b, work_b, qseq_b, qlen_b, scores_b)
+                                       work, done, qseq, qlen, matrix, Q, R, scores, list_b, work_b, qseq_b, qlen_b, scores_b, cus)
   switch (swa_endpoints_rows_for(qlen > qlen_b ? qlen : qlen_b)) {
     case 2: SWA_RQF(2); break;
     case 4: SWA_RQF(4); break;

@@ -19,7 +19,7 @@ swa_dual_one_kernel(swa_mp_params p)
   constexpr int C = (K + 3) / 4;
   constexpr u32 CS = C * 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  signal_block_started(p.done);
+  signal_block_started(p.done, W);
   {
     u32* t = (u32*)lds;
     const int total = (NRES + 1) * C * 16 * 4;

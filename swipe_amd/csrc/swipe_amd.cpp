@@ -74,7 +74,7 @@ hipError_t swa_launch_fold(int* scores, long long* scores64, const int32_t* pare
 hipError_t swa_launch_requeue_follow(const swa_seqs* sq, int32_t* list, int cap, int32_t* work,
                                      const int32_t* done, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                      int* scores, int blocks, hipStream_t st, int32_t* list_b, int32_t* work_b,
-                                     const uint8_t* qseq_b, int qlen_b, int* scores_b);
+                                     const uint8_t* qseq_b, int qlen_b, int* scores_b, int cus);
 hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t* list, const int32_t* count,
                                    int cap, int32_t* work, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                    int* scores, int blocks, hipStream_t st);
@@ -1403,7 +1403,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       const int fblocks = db->opt.requeue_follow > 1 ? int(db->opt.requeue_follow) : std::max(1, db->cus / 2);
       HIP_TRY(swa_launch_requeue_follow(&sq, db->ovf_list.p, int(std::min<int64_t>(nids, REQUEUE_CAP)), db->ctl.p + 4,
                                         db->ctl.p + CTL_DONE, db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge),
-                                        db->scores.p, fblocks, db->stream2, nullptr, nullptr, nullptr, 0, nullptr));
+                                        db->scores.p, fblocks, db->stream2, nullptr, nullptr, nullptr, 0, nullptr, db->cus));
       HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
     }
     c.narrow = db->nseq;
@@ -1609,7 +1609,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
       HIP_TRY(swa_launch_requeue_follow(&sqf, db->ovf_list.p, int(std::min<int64_t>(nids2, REQUEUE_CAP)), db->ctl.p + 4,
                                         db->ctl.p + CTL_DONE, db->qseq_p, int(qa), db->matrix.p, int(db->goe), int(db->ge),
                                         db->scores.p, fblocks, db->stream2, db->ovf_list2.p, db->ctl.p + 6, db->qseq2_p, int(qb),
-                                        db->scores2.p));
+                                        db->scores2.p, db->cus));
       HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
     }
     c.narrow_rows = Kd;

@@ -9,7 +9,7 @@ import pytest
 import cases
 import oracle
 import swipe_amd
-from conftest import case_matrix, load_golden
+from conftest import ROOT, case_matrix, load_golden
 from swipe_amd import blastdb, synth
 
 pytestmark = pytest.mark.gpu
@@ -1706,3 +1706,42 @@ def test_windows_compose_with_subsets_translation_and_streaming():
         prot = oracle.translate(nseqs[50], frame // 3, frame % 3, table)
         assert int(s_win[6 * 50 + frame]) == oracle.fullsw(prot, q, Mo, 12, 1)
     tdb.close()
+
+
+_FOLLOWER_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import swipe_amd
+from swipe_amd import blastdb, synth
+q = blastdb.encode_protein(synth.QUERY_P07327)
+res, off = swipe_amd.synth_db(1, %d, query=q)
+lens = np.diff(off)
+pick = lambda n: res[off[np.nonzero(lens == n)[0][0]]:][:n]
+db = swipe_amd.Database.from_arrays(res, off)
+db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+pairs = [(384, 375), (410, 341), (496, 480), (375, 384), (416, 400), (200, 190), (100, 96)]
+rows = []
+for rnd in range(2):
+    for a, b in pairs:
+        qa, qb = pick(a), pick(b)
+        r = db.search_pair_topk(qa, qb, keep=250, minscore=(80, 80))
+        rows.append((r[2]["narrow_shifted"], r[2]["narrow_rows"]))
+        if rnd == 0:
+            one = [db.search_topk(x, keep=250, minscore=80) for x in (qa, qb)]
+            assert r[0][0] == one[0][0] and r[1][0] == one[1][0] and r[0][1] == one[0][1] and r[1][1] == one[1][1], (a, b)
+print("OK", rows)
+"""
+
+
+def test_pairs_of_queries_one_after_the_other_on_one_handle_do_not_wait_for_each_other():
+    """Round 3's CLI hung on the second pair of a query file against the 10 M-sequence database: the re-queue follower of a
+    52-row two-query bound build (2 x 224 registers + the follower's 72 > 512: the two cannot share a SIMD) reached some CUs
+    before the producer's blocks, those blocks stayed in the dispatcher's queue, and the follower waited for a flag that only
+    the LAST of ALL blocks raised.  Now the flag goes up with the last block that started, and a follower leaves a producer
+    that is not on the device in full (sw_common.cuh signal_block_*).  In a child process, so that a relapse is a failed
+    test and not a hung suite"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _FOLLOWER_SCRIPT % (ROOT, 10_000_000)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stderr[-2000:]
+    assert "(10, 52)" in r.stdout and "(10, 48)" in r.stdout and "(10, 62)" in r.stdout      # the builds that cannot share a SIMD with it
