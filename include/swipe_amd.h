@@ -209,6 +209,9 @@ SWA_API void swa_db_close(swa_db* db);
      long_lanes       0: the bound build's 2-, 4- and 8-lane chains stop at 48 rows per lane like the exact build's
                       (default 1: up to 62 rows, i.e. queries of 97..124 / 193..248 / 385..496 rows on half the lanes)
      endpoints_thread 1 ("thread"): one-thread 64-bit end-point kernel; 0 ("wave")
+     watchdog_s       n > 0: a search whose stream has not drained after n seconds fails with SWA_ENODEV and the device's
+                      control block (queue heads, re-queue counts, follower protocol words) in swa_last_error() instead of
+                      blocking for ever; the handle is unusable afterwards.  0 (default): block in hipStreamSynchronize
    A new handle takes its initial values from the environment variables SWA_<KEY> ONCE, at creation; the search path
    never reads the environment.  Unknown keys and unparsable values return SWA_EINVAL. */
 SWA_API int swa_set_option(swa_db* db, const char* key, const char* value);

@@ -845,6 +845,7 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
       if (w < cap) {
         // relaxed polls a few microseconds apart: an acquire per poll would invalidate the CU's caches under the
         // first-pass waves next door (measured: 1 024 polling waves cost the first pass 37 %)
+        int head = -1, still = 0;
         for (int polls = 1;; ++polls) {
           id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (id >= 0) break;
@@ -862,7 +863,19 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
             const int on = __hip_atomic_load(done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int grid = __hip_atomic_load(done + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int fit = cus * __hip_atomic_load(done + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (on == 0 || on < (grid < fit ? grid : fit)) { fin = 1; id = -1; break; }
+            // ... nor beside a producer that stands still: its queue head (the control block's first word, 32 ints below
+            // the flag) has not moved for ~30 ms and the flag is not up.  Round 3 saw exactly that on MI355X - every block of a
+            // 52-row two-query bound build (223 registers a wave, 512-thread blocks) "started", 256 followers of 68 registers
+            // resident beside them, the queue head frozen for good - whenever the two kernels reached the device together.
+            // Giving the registers back is what gets such a producer going again; a healthy one moves its head every few us.
+            const int now = __hip_atomic_load(done - 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            still = now == head ? still + 1 : 0;
+            head = now;
+            if (on == 0 || on < (grid < fit ? grid : fit) || still >= 32) {
+              fin = 1; id = -1;
+              atomicAdd(const_cast<int32_t*>(done) + (still >= 32 ? 13 : 11), 1);   // diagnostics (option watchdog_s): why followers left
+              break;
+            }
           }
           __builtin_amdgcn_s_sleep(127);
           __builtin_amdgcn_s_sleep(127);
@@ -889,6 +902,7 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
     // stream, many more waves)
     if (id < 0 || last) break;
   }
+  if (g == 0) atomicAdd(const_cast<int32_t*>(done) + 12, 1);    // diagnostics: follower blocks that have ended
 }
 
 // ------------------------------------------------------------------ launchers

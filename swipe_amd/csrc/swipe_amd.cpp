@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -153,6 +154,7 @@ struct Options {
   int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
   int64_t window_step = 0;       // distance between window starts; 0 = from the query (the overlap is never a knob: it is what makes it exact)
   int64_t long_lanes = 1;        // bound build: chains of 2 / 4 / 8 lanes with up to 62 rows per lane where the query fits them (0: 48)
+  int64_t watchdog_s = 0;        // > 0: a search whose stream does not drain within that many seconds fails with the control block in the message
 };
 struct OptionKey { const char* key; int64_t Options::*field; };
 const OptionKey kOptionKeys[] = {
@@ -162,7 +164,7 @@ const OptionKey kOptionKeys[] = {
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
   {"requeue_follow", &Options::requeue_follow}, {"window", &Options::window}, {"window_step", &Options::window_step},
-  {"long_lanes", &Options::long_lanes},
+  {"long_lanes", &Options::long_lanes}, {"watchdog_s", &Options::watchdog_s},
 };
 bool parse_option_value(const char* key, const char* value, int64_t* out)
 {
@@ -1065,6 +1067,7 @@ constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] 
 constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
 
+constexpr int FOLLOW_MAX_ROWS = 48;     // rows per lane of the largest build a re-queue follower shares a SIMD with (run_search)
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
 
@@ -1087,8 +1090,35 @@ int sync_ctl(swa_db* db, int ncand, hipStream_t st)
 {
   HIP_TRY(hipMemcpyAsync(db->pin, db->ctl.p, CTL_INTS * sizeof(int32_t) + size_t(ncand) * sizeof(swa_cand),
                          hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  return SWA_OK;
+  if (db->opt.watchdog_s <= 0) {
+    HIP_TRY(hipStreamSynchronize(st));
+    return SWA_OK;
+  }
+  // option "watchdog_s": poll instead of blocking; a stream that does not drain in time is reported with the control block
+  // as the device holds it (read over a stream of its own) - queue heads, re-queue counts, the follower protocol's words -
+  // and the call fails.  The handle is not usable afterwards (kernels may still be spinning): close the process.
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return SWA_OK;
+    if (q != hipErrorNotReady) HIP_TRY(q);
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > double(db->opt.watchdog_s)) break;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  std::string msg = "search did not come back within " + std::to_string(db->opt.watchdog_s) + " s; control block";
+  hipStream_t side = nullptr;
+  int32_t snap[CTL_INTS] = {};
+  if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+  for (int shot = 0; shot < 2 && side; ++shot) {          // twice, a second apart: stuck, or crawling?
+    if (shot) std::this_thread::sleep_for(std::chrono::seconds(1));
+    if (hipMemcpyAsync(snap, db->ctl.p, sizeof snap, hipMemcpyDeviceToHost, side) == hipSuccess && hipStreamSynchronize(side) == hipSuccess) {
+      msg += shot ? " || one second later" : "";
+      for (int i = 0; i < CTL_INTS; ++i) msg += (i % 16 == 0 ? " | " : " ") + std::to_string(snap[i]);
+    } else {
+      msg += " unreadable";
+    }
+  }
+  return fail(SWA_ENODEV, msg);
 }
 
 // query (+ its descriptor for the first-pass kernel) in ONE copy out of page-locked memory:
@@ -1375,7 +1405,12 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     // Only beside kernels that leave it register room: the bound builds (2 K + 40 registers) and exact builds of at most 32
     // rows per lane.  An exact build of 47 rows fills the register file with its two waves per SIMD; its list is the handful
     // of sequences that leave the f16 range, which the device-driven kernel after it takes in microseconds
-    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && (used_bound || K <= 32 || db->opt.requeue_follow > 1);
+    // ... and whose waves it can share a SIMD with: two producer waves + one follower wave within 512 registers.  That holds
+    // for the builds above up to 48 rows per lane (bound, 47 rows: 2 x 192 + 64); the long lanes of 49..62 rows (202..255
+    // registers) leave no room, and a follower that cannot be resident beside the producer must not be on the device with it
+    // (swa_requeue_follow_kernel: the second pair of a query file hung).  requeue_follow > 1 (that many blocks) overrides: tests
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 &&
+             (((used_bound || K <= 32) && K <= FOLLOW_MAX_ROWS) || db->opt.requeue_follow > 1);
     if (follow) {
       HIP_TRY(hipMemsetAsync(db->ovf_list.p, 0xFF, size_t(std::min<int64_t>(nids, REQUEUE_CAP)) * sizeof(int32_t), st));
       HIP_TRY(hipEventRecord(db->ev2[0], st));
@@ -1583,7 +1618,9 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     // 32 rows per lane.  Beside the 63-row nucleotide kernel (two waves x 256 registers) a follower that lands on a SIMD first
     // keeps a producer wave out for the whole pass: measured 603 -> 612 ms for the nucleotide bench, so it runs after it there
     // (the 33..48-row bound build: 205 registers x two waves leave room, like the one-query bound build's 219)
-    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 && (Kd <= 32 || used_bound);
+    // (... and up to 48 rows: 52 rows are 223 registers a wave, the follower of a 410-aa query 68 - see run_search)
+    follow = device_requeue_ok(db, qlen) && db->opt.requeue_follow != 0 &&
+             (((Kd <= 32 || used_bound) && Kd <= FOLLOW_MAX_ROWS) || db->opt.requeue_follow > 1);
     const int64_t nids2 = db->nseq + (windows ? db->nwin : 0);
     if (follow) {
       const size_t head = size_t(std::min<int64_t>(nids2, REQUEUE_CAP)) * sizeof(int32_t);
