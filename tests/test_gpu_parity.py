@@ -1751,3 +1751,56 @@ def test_pairs_of_queries_one_after_the_other_on_one_handle_do_not_wait_for_each
     r = subprocess.run([sys.executable, "-c", _FOLLOWER_SCRIPT % (ROOT, 10_000_000)], capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout[-500:], r.stderr[-2500:])
     assert "(10, 52)" in r.stdout and "(10, 48)" in r.stdout and "(10, 49)" in r.stdout
+
+
+_WARM_SCRIPT = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+os.environ["SWA_WATCHDOG_S"] = "30"
+import swipe_amd
+from swipe_amd import blastdb, synth
+q0 = blastdb.encode_protein(synth.QUERY_P07327)
+res, off = swipe_amd.synth_db(1, %d, query=q0)
+lens = np.diff(off)
+rng = np.random.default_rng(%d)
+db = swipe_amd.Database.from_arrays(res, off)
+db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+ref = swipe_amd.Database.from_arrays(res, off)            # the same shard, exact first pass, no follower: what must come out
+ref.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+ref.set_option("bound", 0); ref.set_option("requeue_follow", 0)
+def query():
+    n = int(rng.choice([rng.integers(5, 64), rng.integers(64, 520), rng.integers(520, 1300)]))
+    if rng.random() < 0.7:                                  # a database sequence (it has itself, and perhaps a family, as hits) ...
+        c = np.nonzero(lens == n)[0]
+        if len(c):
+            i = int(rng.choice(c)); return res[off[i]:off[i + 1]].copy()
+    return synth._random_residues(int(rng.integers(1 << 30)), 1, n, synth.residue_table_protein())   # ... or a random one
+forms, prev = set(), None
+for it in range(%d):
+    a = query()
+    if prev is not None and rng.random() < 0.5 and 4 * min(len(a), len(prev)) >= 3 * max(len(a), len(prev)):
+        r = db.search_pair_topk(prev, a, keep=100, minscore=(70, 70))
+        w = [ref.search_topk(x, keep=100, minscore=70) for x in (prev, a)]
+        assert (r[0][0], r[0][1], r[1][0], r[1][1]) == (w[0][0], w[0][1], w[1][0], w[1][1]), ("pair", it, len(prev), len(a))
+        forms.add((r[2]["narrow_shifted"], r[2]["narrow_rows"]))
+    else:
+        r = db.search_topk(a, keep=100, minscore=70)
+        w = ref.search_topk(a, keep=100, minscore=70)
+        assert r[:3] == w[:3], ("one", it, len(a))
+        forms.add((r[3]["narrow_shifted"], r[3]["narrow_rows"]))
+    prev = a
+print("OK", len(forms), sorted(forms))
+"""
+
+
+def test_a_query_file_of_mixed_lengths_on_one_warm_handle():
+    """the fuzz tools open a fresh handle per configuration, and a fresh handle is exactly what hid round 3's follower hang
+    (kernels whose first launch is slow never meet on the device).  Here ONE handle of a 3 M-sequence database takes 90
+    searches back to back - database sequences and random queries of 5..1300 residues, singly and two per pass, whatever
+    build the table picks for each (one lane, chains of 2..16 lanes, long lanes, passes) - and every hit list must equal the
+    one a second handle computes with the exact first pass and no follower.  Child process, watchdog on"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _WARM_SCRIPT % (ROOT, 3_000_000, 20260929, 90)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout[-500:], r.stderr[-2500:])
+    assert int(r.stdout.split()[1]) >= 25                    # that many different builds met on the one handle
