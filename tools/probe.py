@@ -457,6 +457,60 @@ Steady-state seconds per query = (T_N - T_1) / (N - 1); -m 8 output of all five 
           "; the unmodified reference's first %d queries equal the same lines" % a.ref_queries if a.ref_queries < nq else ""))
     subprocess.run(["rm", "-rf", d])
 
+def cmd_warm(a):
+    """A query file of mixed lengths on ONE warm handle (tests/test_gpu_parity.py::test_a_query_file_of_mixed_lengths_on_one_warm_handle
+at scale): database sequences and random queries of 5..1300 residues, singly and two per pass, back to back; every hit list
+against a second handle that runs the exact first pass without a follower.  --forced: the follower beside every build
+(requeue_follow = 128), i.e. the device-side defences of DESIGN 4.10 alone.  Watchdog on: a hang is an error message."""
+    import os, time, numpy as np
+    os.environ["SWA_WATCHDOG_S"] = "30"
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    q0 = blastdb.encode_protein(synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(1, a.nseq, query=q0)
+    lens = np.diff(off)
+    rng = np.random.default_rng(a.seed)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    if a.forced:
+        db.set_option("requeue_follow", 128)
+    ref = swipe_amd.Database.from_arrays(res, off)
+    ref.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    ref.set_option("bound", 0); ref.set_option("requeue_follow", 0)
+    def query():
+        n = int(rng.choice([rng.integers(5, 64), rng.integers(64, 520), rng.integers(520, 1300)]))
+        if rng.random() < 0.7:
+            c = np.nonzero(lens == n)[0]
+            if len(c):
+                i = int(rng.choice(c)); return res[off[i]:off[i + 1]].copy()
+        return synth._random_residues(int(rng.integers(1 << 30)), 1, n, synth.residue_table_protein())
+    forms, prev, bad, slow, t_all = {}, None, 0, 0, time.time()
+    for it in range(a.n):
+        x = query()
+        t = time.time()
+        if prev is not None and rng.random() < 0.5 and 4 * min(len(x), len(prev)) >= 3 * max(len(x), len(prev)):
+            r = db.search_pair_topk(prev, x, keep=100, minscore=(70, 70))
+            dt = time.time() - t
+            w = [ref.search_topk(y, keep=100, minscore=70) for y in (prev, x)]
+            ok = (r[0][0], r[0][1], r[1][0], r[1][1]) == (w[0][0], w[0][1], w[1][0], w[1][1])
+            key, cells = ("pair", r[2]["narrow_shifted"], r[2]["narrow_rows"]), float(off[-1]) * (len(x) + len(prev))
+        else:
+            r = db.search_topk(x, keep=100, minscore=70)
+            dt = time.time() - t
+            w = ref.search_topk(x, keep=100, minscore=70)
+            ok = r[:3] == w[:3]
+            key, cells = ("one", r[3]["narrow_shifted"], r[3]["narrow_rows"]), float(off[-1]) * len(x)
+        forms[key] = forms.get(key, 0) + 1
+        bad += 0 if ok else 1
+        if cells / dt / 1e9 < 3000:                         # a search that stalled (forced follower: ~0.5 s until it gives way)
+            slow += 1
+        if not ok:
+            print("MISMATCH at search %d: %s, %d / %d residues" % (it, key, len(x), len(prev) if prev is not None else 0), flush=True)
+        prev = x
+    print("warm handle, %d sequences, seed %d%s: %d searches in %.0f s, %d different builds, %d mismatches, %d searches below 3 TCUPS" % (
+        a.nseq, a.seed, ", follower forced" if a.forced else "", a.n, time.time() - t_all, len(forms), bad, slow), flush=True)
+    sys.exit(1 if bad else 0)
+
 
 def cmd_align(a):
     """How long does the alignment phase take?  250 hits of the 375-aa bench query, and a long-query / long-sequence
@@ -728,6 +782,12 @@ def main():
     p.add_argument("--nseq", type=int, default=10_000_000)
     p.add_argument("--reps", type=int, default=10)
     p.set_defaults(fn=cmd_group)
+    p = sub.add_parser("warm")
+    p.add_argument("--nseq", type=int, default=10_000_000)
+    p.add_argument("--n", type=int, default=300)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--forced", action="store_true")
+    p.set_defaults(fn=cmd_warm)
     p = sub.add_parser("dropin")
     p.add_argument("--nseq", type=int, default=10_000_000)
     p.add_argument("--nq", type=int, default=16)
