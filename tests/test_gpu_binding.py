@@ -121,3 +121,18 @@ def test_bound_reference_under_threshold_and_strand_options(tmp_path, name, i):
     for variant, tail, key in (("topk", ["-m", "8", "-a", "2"], "m8"), ("topk", ["-m", "7", "-b", "0"], "m7"), ("scores", ["-m", "8"], "m8")):
         r = subprocess.run([need(variant)] + args + rec["options"] + tail, capture_output=True, text=True)
         assert r.returncode == rec[key + "_rc"] and r.stdout == rec[key], (variant, rec["options"], r.stderr)
+
+
+def test_one_query_file_through_the_reference_the_bound_reference_and_the_cli_at_scale():
+    """the fixtures above hold a thousand sequences; this is the same comparison where searches take long enough for kernels
+    to meet on the device (tools/probe.py dropin, which found round 3's follower hang at 10 M sequences): a 2 M-sequence
+    database written as BLAST v4 volumes, an 8-query file of 332..410-aa database sequences, -m 8 with 250 alignments,
+    through the unmodified reference, the reference bound to the library three ways and swipe_amd_cli (which pairs adjacent
+    queries) - the tool fails unless all five outputs are identical"""
+    import sys
+    for v in BOUND:
+        need(v)
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "probe.py"), "dropin", "--nseq", "2000000", "--nq", "8",
+                        "--ref-queries", "8", "--reps", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "output: identical" in r.stdout and "swipe_amd_cli" in r.stdout

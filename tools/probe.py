@@ -457,6 +457,45 @@ Steady-state seconds per query = (T_N - T_1) / (N - 1); -m 8 output of all five 
           "; the unmodified reference's first %d queries equal the same lines" % a.ref_queries if a.ref_queries < nq else ""))
     subprocess.run(["rm", "-rf", d])
 
+def warm_nt(a):
+    """cmd_warm for a nucleotide database: both strands of every query in one pass (swa_search2_topk), queries of 12..3000 nt"""
+    import time, numpy as np
+    import swipe_amd
+    from swipe_amd import synth, blastdb
+    res, off = swipe_amd.synth_db(3, a.nseq, protein=False)
+    lens = np.diff(off)
+    rng = np.random.default_rng(a.seed)
+    mk = lambda: swipe_amd.Database.from_arrays(res, off, symtype=0)
+    db, ref = mk(), mk()
+    for h in (db, ref):
+        h.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)
+    if a.forced:
+        db.set_option("requeue_follow", 128)
+    ref.set_option("requeue_follow", 0)
+    forms, bad, t_all = {}, 0, time.time()
+    for it in range(a.n):
+        n = int(rng.choice([rng.integers(12, 64), rng.integers(64, 1100), rng.integers(1100, 3000)]))
+        if rng.random() < 0.7:
+            i = int(rng.integers(0, a.nseq)); L = int(lens[i]); m = min(n, L)
+            st = int(rng.integers(0, L - m + 1))
+            x = res[off[i] + st: off[i] + st + m].copy()      # a piece of a database sequence: it hits itself
+        else:
+            x = synth._random_residues(int(rng.integers(1 << 30)), 1, n, synth.residue_table_nucleotide())
+        if len(x) < 8:
+            continue
+        y = blastdb.revcomp_nt16(x)
+        r = db.search2_topk(x, y, keep=100, minscore=24)
+        w = ref.search2_topk(x, y, keep=100, minscore=24)
+        key = (r[3]["narrow_shifted"], r[3]["narrow_rows"])
+        forms[key] = forms.get(key, 0) + 1
+        if r[:3] != w[:3]:
+            bad += 1
+            print("MISMATCH at search %d: %s, %d nt" % (it, key, len(x)), flush=True)
+    print("warm handle, nucleotide, %d sequences, seed %d%s: %d searches of both strands in %.0f s, %d different builds, %d mismatches" % (
+        a.nseq, a.seed, ", follower forced" if a.forced else "", a.n, time.time() - t_all, len(forms), bad), flush=True)
+    sys.exit(1 if bad else 0)
+
+
 def cmd_warm(a):
     """A query file of mixed lengths on ONE warm handle (tests/test_gpu_parity.py::test_a_query_file_of_mixed_lengths_on_one_warm_handle
 at scale): database sequences and random queries of 5..1300 residues, singly and two per pass, back to back; every hit list
@@ -466,6 +505,8 @@ against a second handle that runs the exact first pass without a follower.  --fo
     os.environ["SWA_WATCHDOG_S"] = "30"
     import swipe_amd
     from swipe_amd import synth, blastdb
+    if a.nt:
+        return warm_nt(a)
     q0 = blastdb.encode_protein(synth.QUERY_P07327)
     res, off = swipe_amd.synth_db(1, a.nseq, query=q0)
     lens = np.diff(off)
@@ -787,6 +828,7 @@ def main():
     p.add_argument("--n", type=int, default=300)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--forced", action="store_true")
+    p.add_argument("--nt", action="store_true")
     p.set_defaults(fn=cmd_warm)
     p = sub.add_parser("dropin")
     p.add_argument("--nseq", type=int, default=10_000_000)
