@@ -1065,6 +1065,10 @@ int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, h
 //   [10..13] two 64-bit tallies (totalhits, obvious)                                 [16..] swa_cand records
 constexpr int CTL_INTS = 48;            // three 64-byte lines: counters | [16] blocks finished | [32] done flag (polled)
 constexpr int CTL_FINISHED = 16, CTL_DONE = 32;
+// the follower protocol's words sit at fixed distances from the flag it polls (sw_common.cuh signal_block_*,
+// sw_kernels.hip swa_requeue_follow_kernel): flag - 32 = [0] the producer's queue head; flag + 8 blocks started, + 9 grid,
+// + 10 blocks per CU, + 11 / + 13 followers that left (producer not resident / standing still), + 12 follower blocks ended
+static_assert(CTL_DONE == 32 && CTL_DONE + 13 < CTL_INTS, "follower protocol layout");
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
 
 constexpr int FOLLOW_MAX_ROWS = 48;     // rows per lane of the largest build a re-queue follower shares a SIMD with (run_search)
@@ -1118,6 +1122,7 @@ int sync_ctl(swa_db* db, int ncand, hipStream_t st)
       msg += " unreadable";
     }
   }
+  if (side) (void)hipStreamDestroy(side);
   return fail(SWA_ENODEV, msg);
 }
 
