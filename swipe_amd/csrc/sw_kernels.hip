@@ -854,7 +854,7 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
             id = __hip_atomic_load(list + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;                                // still -1: position w lies beyond the end of the list
           }
-          // Never wait for blocks that are not on the device (signal_block_started): about a millisecond without an entry
+          // Never wait for blocks that are not on the device (signal_block_started): 128 polls (1..15 ms) without an entry
           // and the follower looks at the producer - none of its blocks started (a profiler that runs one kernel at a
           // time dispatched this one first) or fewer than the device holds of it when nothing is in the way (the missing
           // ones may be waiting for the registers this very wave holds) and it leaves; the finishing kernel does the work
@@ -864,7 +864,7 @@ swa_requeue_follow_kernel(swa_seqs sq, int32_t* list, int cap, int32_t* __restri
             const int grid = __hip_atomic_load(done + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int fit = cus * __hip_atomic_load(done + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // ... nor beside a producer that stands still: its queue head (the control block's first word, 32 ints below
-            // the flag) has not moved for ~30 ms and the flag is not up.  Round 3 saw exactly that on MI355X - every block of a
+            // the flag) has not moved for 32 looks in a row (measured with the follower forced: 0.5 s) and the flag is not up.  Round 3 saw exactly that on MI355X - every block of a
             // 52-row two-query bound build (223 registers a wave, 512-thread blocks) "started", 256 followers of 68 registers
             // resident beside them, the queue head frozen for good - whenever the two kernels reached the device together.
             // Giving the registers back is what gets such a producer going again; a healthy one moves its head every few us.
