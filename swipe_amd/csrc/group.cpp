@@ -57,6 +57,7 @@ struct Worker {
       int r;
       try { r = f(); }                                     // the C ABI does not throw; a stand-in shard of the tests may
       catch (const std::exception& x) { r = fail(SWA_ENOMEM, std::string("exception on a shard's thread: ") + x.what()); }
+      catch (...) { r = fail(SWA_ENOMEM, "exception on a shard's thread"); }   // anything else would end the process (std::terminate)
       std::string e = r == SWA_OK ? std::string() : std::string(swa_last_error());   // thread-local on THIS thread
       l.lock();
       rc = r;
