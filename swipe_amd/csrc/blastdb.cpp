@@ -85,6 +85,23 @@ bool open_volume(const std::string& base, bool protein, Volume& v, std::string& 
   return true;
 }
 
+// Length of sequence s of a volume out of its index, every offset checked against the mapped files: a database cut
+// short by a download must end in a status, not in a read beyond the mapping (the reference trusts the index).
+int sequence_length(const Volume& v, bool protein, int64_t s, int64_t* len)
+{
+  const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
+  if (o2 < o1 || o2 > v.seq.n) return swa::fail(SWA_EIO, "corrupt sequence offsets in " + v.base);
+  if (protein) {
+    *len = o2 > o1 ? int64_t(o2 - o1 - 1) : 0;                         // entry includes its NUL terminator
+    return SWA_OK;
+  }
+  const uint64_t o3 = be32(v.amb_off + 4 * s);
+  if (o3 <= o1 || o3 > o2) return swa::fail(SWA_EIO, "corrupt ambiguity offsets in " + v.base);
+  const size_t packed = size_t(o3 - o1);
+  *len = int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3));   // database.cc:1260-1261
+  return SWA_OK;
+}
+
 // One alias file (database.cc:406-489): TITLE, DBLIST, OIDLIST, LENGTH, NSEQ, MAXOID, MEMB_BIT
 struct Alias {
   bool present = false;
@@ -284,17 +301,9 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
     const int64_t lo = first_seqno > vbase ? first_seqno - vbase : 0;
     const int64_t hi = last_seqno - vbase < v.nseq - 1 ? last_seqno - vbase : v.nseq - 1;
     for (int64_t s = lo; s <= hi; ++s) {
-      const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
-      if (o2 < o1 || o2 > v.seq.n) return fail(SWA_EIO, "corrupt sequence offsets in " + v.base);
       int64_t len;
-      if (protein) {
-        len = o2 > o1 ? int64_t(o2 - o1 - 1) : 0;                    // entry includes its NUL terminator
-      } else {
-        const uint64_t o3 = be32(v.amb_off + 4 * s);
-        if (o3 <= o1 || o3 > o2) return fail(SWA_EIO, "corrupt ambiguity offsets in " + v.base);
-        const size_t packed = size_t(o3 - o1);
-        len = int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3));   // database.cc:1260-1261
-      }
+      const int rc_len = sequence_length(v, protein, s, &len);
+      if (rc_len != SWA_OK) return rc_len;
       out.offsets.push_back(out.offsets.back() + len);
       src.push_back({&v, s});
       if (out.masked) out.included.push_back(bd.in_mask(size_t(&v - V.data()), s) ? 1 : 0);
@@ -371,17 +380,9 @@ int swa::read_blast_lengths(const char* basename, int symtype, std::vector<int64
   offsets.reserve(size_t(bd.nseq) + 1);
   for (const Volume& v : bd.vols) {
     for (int64_t s = 0; s < v.nseq; ++s) {
-      const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
-      if (o2 < o1 || o2 > v.seq.n) return fail(SWA_EIO, "corrupt sequence offsets in " + v.base);
       int64_t len;
-      if (bd.protein) {
-        len = o2 > o1 ? int64_t(o2 - o1 - 1) : 0;
-      } else {
-        const uint64_t o3 = be32(v.amb_off + 4 * s);
-        if (o3 <= o1 || o3 > o2) return fail(SWA_EIO, "corrupt ambiguity offsets in " + v.base);
-        const size_t packed = size_t(o3 - o1);
-        len = int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3));
-      }
+      const int rc_len = sequence_length(v, bd.protein, s, &len);
+      if (rc_len != SWA_OK) return rc_len;
       offsets.push_back(offsets.back() + len);
     }
   }
@@ -393,45 +394,59 @@ int swa::read_blast_lengths(const char* basename, int symtype, std::vector<int64
 // context-tagged with indefinite length, primitives are short definite; the walker accepts both forms.
 namespace {
 struct Ber {
+  // Damaged headers must not take the walker outside [p, end): every advance is clamped to `end`, a length that does
+  // not fit what is left of the buffer means "to the end of the buffer", nesting deeper than any header of the
+  // formatter (they reach 8 levels) ends the walk.
   const uint8_t* p;
   const uint8_t* end;
-  bool eoc() const { return p + 1 < end && p[0] == 0 && p[1] == 0; }
+  size_t left() const { return size_t(end - p); }
+  void advance(size_t n) { p = n < left() ? p + n : end; }
+  bool eoc() const { return left() >= 2 && p[0] == 0 && p[1] == 0; }
   bool more(const uint8_t* stop) const { return p < end && (stop ? p < stop : !eoc()); }
   int peek() const { return p < end ? *p : -1; }
-  // reads tag + length; content length or -1 for the indefinite form
+  // reads tag + length; content length (at most what is left) or -1 for the indefinite form
   bool head(int& tag, long& len)
   {
     if (p >= end) return false;
     tag = *p++;
     if (p >= end) return false;
-    int l = *p++;
+    const int l = *p++;
     if (l == 0x80) { len = -1; return true; }
+    size_t v = size_t(l);
     if (l & 0x80) {
       int n = l & 0x7f;
-      len = 0;
-      while (n-- && p < end) len = (len << 8) | *p++;
-    } else {
-      len = l;
+      v = 0;
+      bool huge = false;
+      while (n-- && p < end) { huge = huge || (v >> 48) != 0; v = (v << 8) | *p++; }
+      if (huge) v = left();
     }
+    len = long(std::min(v, left()));
     return true;
   }
-  const uint8_t* stop_of(long len) const { return len >= 0 ? p + len : nullptr; }
-  void skip()
+  const uint8_t* stop_of(long len) const { return len >= 0 ? p + std::min(size_t(len), left()) : nullptr; }
+  void skip(int depth = 0)
   {
     int tag; long len;
-    if (!head(tag, len)) { p = end; return; }
-    if (len >= 0) { p += len; return; }
-    while (p < end && !eoc()) skip();
-    p += 2;
+    if (depth > 64 || !head(tag, len)) { p = end; return; }
+    if (len >= 0) { advance(size_t(len)); return; }
+    while (p < end && !eoc()) skip(depth + 1);
+    advance(2);
   }
   // leaves a constructed element entered with head(): to its end, past the end-of-contents octets if indefinite
   void leave(const uint8_t* stop)
   {
     if (stop) { p = stop; return; }
     while (p < end && !eoc()) skip();
-    p += 2;
+    advance(2);
   }
-  std::string str() { int t; long l; if (!head(t, l) || l < 0) return std::string(); std::string s(reinterpret_cast<const char*>(p), size_t(std::min<long>(l, end - p))); p += l; return s; }
+  std::string str()
+  {
+    int t; long l;
+    if (!head(t, l) || l < 0) return std::string();
+    std::string s(reinterpret_cast<const char*>(p), size_t(l));       // head() keeps l within the buffer
+    advance(size_t(l));
+    return s;
+  }
   unsigned long integer() { int t; long l; unsigned long v = 0; if (!head(t, l) || l < 0) return 0; for (long i = 0; i < l && p < end; ++i) v = (v << 8) | *p++; return v; }
   // [tag] EXPLICIT string / integer if it is the next element
   bool opt_str(int tag, std::string& out)
@@ -735,14 +750,10 @@ int swa::read_blast_deflines(const char* basename, int symtype, const std::vecto
     rc = header_bytes(h, s, &p, &n, &vol, &local);
     if (rc != SWA_OK) break;
     deflines.push_back(render_deflines(p, n, f, nullptr));
-    const Volume& v = h->db.vols[vol];
-    const uint64_t o1 = be32(v.seq_off + 4 * local), o2 = be32(v.seq_off + 4 * (local + 1));
-    if (protein) lengths.push_back(o2 > o1 ? int64_t(o2 - o1 - 1) : 0);
-    else {
-      const uint64_t o3 = be32(v.amb_off + 4 * local);
-      const size_t packed = size_t(o3 - o1);
-      lengths.push_back(int64_t(4 * (packed - 1) + (v.seq.p[o1 + packed - 1] & 3)));
-    }
+    int64_t len;
+    rc = sequence_length(h->db.vols[vol], protein, local, &len);
+    if (rc != SWA_OK) break;
+    lengths.push_back(len);
   }
   swa_headers_close(h);
   return rc;

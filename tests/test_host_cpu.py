@@ -532,6 +532,41 @@ def test_group_layer_is_thread_sanitizer_clean(tmp_path):
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "group check ok" in r.stdout, r.stderr[-3000:]
 
 
+def test_damaged_database_files_end_in_a_status_not_in_a_wild_read(tmp_path):
+    """swipe_amd/csrc/blastdb.cpp - index walk, residue unpacking with ambiguity runs, OID masks, the BER walker of the
+    definition lines - compiled with -fsanitize=address,undefined and run over databases damaged one file at a time
+    (cut short, bytes replaced, huge big-endian words, a shifted tail; broken alias files): the two volumes the harness
+    writes itself plus the `headers` case (every Seq-id flavour, merged definition lines, behind an OID-mask alias too)
+    and the `nt` case (ambiguity codes).  The reference trusts the index (database.cc:566-601, 1237-1401) and dies on
+    such files; a library must return a status.  Round 3 found the length computation of read_blast_deflines and the BER
+    walker reading beyond the mapping this way."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "blastdb_fuzz")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                            os.path.join(ROOT, "tests", "stubs", "blastdb_fuzz.cpp"), os.path.join(ROOT, "swipe_amd", "csrc", "blastdb.cpp"),
+                            "-lpthread"], capture_output=True, text=True)
+    if build.returncode != 0 and ("asan" in build.stderr.lower() or "ubsan" in build.stderr.lower()):
+        pytest.skip("sanitizer runtimes not installed")
+    assert build.returncode == 0, build.stderr
+    hc = cases.get("headers")
+    vol = str(tmp_path / "hdrvol")
+    blastdb.write_volume(vol, hc.seqs, protein=True, headers=hc.extra["headers"], title="headers volume")
+    blastdb.write_mask_alias(str(tmp_path / "hdrmasked"), vol, hc.extra["include"], memb_bit=1,
+                             length=int(sum(len(x) for x, k in zip(hc.seqs, hc.extra["include"]) if k)), title="masked subset")
+    nc = cases.get("nt")
+    ntvol = str(tmp_path / "ntvol")
+    blastdb.write_volume(ntvol, nc.seqs, protein=False)
+    r = subprocess.run([exe, str(tmp_path), "1500", "7", vol + ":1", ntvol + ":0"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and "no sanitizer report" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    # the masked alias over the intact volume still reads (the alias itself is not one of the damaged files)
+    r = subprocess.run([exe, str(tmp_path), "0", "1", str(tmp_path / "hdrmasked") + ":1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_follower_has_register_room_beside_every_build_it_runs_with():
     """the re-queue follower may only be started beside a first-pass build whose block leaves one of its waves room on a
     SIMD (round 3: a 52-row two-query bound build, 2 x 224 registers in a 512-thread block, froze beside 72-register
