@@ -567,6 +567,27 @@ def test_damaged_database_files_end_in_a_status_not_in_a_wild_read(tmp_path):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
 
 
+def test_host_traceback_rescoring_identity_under_sanitizers(tmp_path):
+    """swipe_amd/csrc/traceback.cpp (forward / backward sweeps and the Myers-Miller diff of align.cc:70-467) compiled with
+    -fsanitize=address,undefined over 4 000 random pairs - random, partly asymmetric matrices, gap systems 1..14 + 1..4,
+    planted copies with substitutions, insertions and deletions: the edit script re-scored column by column equals the
+    forward sweep's score, starts and ends on a matched pair, spans the cells the sweeps returned, and the column counts
+    add up.  (Byte-for-byte agreement with the reference's align() is test_host_traceback_matches_reference_alignments.)"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "traceback_check")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                            os.path.join(ROOT, "tests", "stubs", "traceback_check.cpp"), os.path.join(ROOT, "swipe_amd", "csrc", "traceback.cpp")],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and ("asan" in build.stderr.lower() or "ubsan" in build.stderr.lower()):
+        pytest.skip("sanitizer runtimes not installed")
+    assert build.returncode == 0, build.stderr
+    r = subprocess.run([exe, "4000", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ", 0 bad" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_follower_has_register_room_beside_every_build_it_runs_with():
     """the re-queue follower may only be started beside a first-pass build whose block leaves one of its waves room on a
     SIMD (round 3: a 52-row two-query bound build, 2 x 224 registers in a 512-thread block, froze beside 72-register
