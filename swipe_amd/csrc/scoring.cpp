@@ -174,6 +174,16 @@ try {
   return swa::fail(SWA_EINVAL, "no default gap penalties for this matrix");
 } SWA_CATCH
 
+// (long) of a double as the reference's x86-64 binary performs it (hits.cc:491, 497: cvttsd2si): anything outside the range
+// of a long - an empty query makes Kmn 0 and the threshold -inf - becomes the "integer indefinite" value LONG_MIN.  In C++
+// that conversion is undefined behaviour (UBSan found it on the empty query of the multi-query fixture); spelled out, the
+// result is the same on every compiler.
+static int64_t to_long(double x)
+{
+  if (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) return INT64_MIN;
+  return int64_t(x);
+}
+
 extern "C" int swa_stats_init(int symtype, const char* matrixname, int64_t match, int64_t mismatch,
                               int64_t gapopen, int64_t gapextend, int64_t qlen,
                               int64_t db_seqcount, int64_t db_symcount, int64_t effdbsize,
@@ -206,10 +216,10 @@ try {
   out->m = qlen - adj;
   out->n = effdbsize > 0 ? effdbsize : dlen - int64_t(seqcount) * adj;
   out->Kmn = ka.K * double(out->m) * double(out->n);
-  const int64_t by_expect = int64_t(std::ceil(-std::log(expect / out->Kmn) / ka.lambda));  // hits.cc:491
+  const int64_t by_expect = to_long(std::ceil(-std::log(expect / out->Kmn) / ka.lambda));  // hits.cc:491
   if (by_expect > minscore) out->scorethreshold = by_expect;
   if (minexpect > 0.0) {
-    const int64_t by_min = int64_t(std::floor(-std::log(minexpect / out->Kmn) / ka.lambda));
+    const int64_t by_min = to_long(std::floor(-std::log(minexpect / out->Kmn) / ka.lambda));
     if (by_min < maxscore) out->upperscorethreshold = by_min;
   }
   return SWA_OK;

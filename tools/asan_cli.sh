@@ -1,0 +1,20 @@
+#!/bin/bash
+# The library's HOST side under AddressSanitizer on a GPU box (make -C swipe_amd/csrc asan builds swipe_amd/swipe_amd_cli_asan
+# in the build container; it travels with the snapshot).  The instrumented driver takes the place of swipe_amd_cli for the
+# tests that compare the command line's output with the reference's goldens: 1..5 shards, masks, taxid lists, translated
+# searches, alignments, query files.  Any ASan report makes the driver exit non-zero, so the test that ran it fails and
+# shows the report; reports are also kept under gpurun_out/asan/.
+#   bash tools/asan_cli.sh            (on the GPU box, from the repository root)
+cd "${GRAFT_REPO_ROOT:-.}"
+test -x swipe_amd/swipe_amd_cli_asan || { echo "no swipe_amd/swipe_amd_cli_asan: make -C swipe_amd/csrc asan"; exit 2; }
+mkdir -p gpurun_out/asan
+cp swipe_amd/swipe_amd_cli swipe_amd/swipe_amd_cli.plain
+cp swipe_amd/swipe_amd_cli_asan swipe_amd/swipe_amd_cli
+# protect_shadow_gap=0: the HSA runtime reserves address ranges inside ASan's shadow gap; leaks: the runtime's own at exit
+export ASAN_OPTIONS=protect_shadow_gap=0:detect_leaks=0:halt_on_error=1:log_path=$PWD/gpurun_out/asan/report
+timeout ${1:-600} python -m pytest tests/test_gpu_group.py tests/test_gpu_parity.py -m gpu -q \
+  -k "test_gpu_group or cli_output or cli_alignment or translated_cli or cli_real_database or cli_multi_query or cli_errors" 2>&1 | tail -25
+rc=${PIPESTATUS[0]}
+cp swipe_amd/swipe_amd_cli.plain swipe_amd/swipe_amd_cli
+echo "pytest rc=$rc; ASan report files: $(ls gpurun_out/asan | wc -l)"
+exit $rc
