@@ -696,7 +696,7 @@ int header_bytes(const swa_headers* h, int64_t seqno, const uint8_t** p, size_t*
 extern "C" int swa_headers_get(const swa_headers* h, int64_t seqno, int flags, char* buf, int64_t buflen, int64_t* needed)
 try {
   if (!h || buflen < 0 || (buflen > 0 && !buf) || !needed) return swa::fail(SWA_EINVAL, "bad argument");
-  const uint8_t* p; size_t n, vol; int64_t local;
+  const uint8_t* p = nullptr; size_t n = 0, vol = 0; int64_t local = 0;
   const int rc = header_bytes(h, seqno, &p, &n, &vol, &local);
   if (rc != SWA_OK) return rc;
   DeflineFilter f;
@@ -719,7 +719,7 @@ try {
   f.memb = (unsigned long)h->db.memb_bit;
   f.db = &h->db;
   for (int64_t i = 0; i < n; ++i) {
-    const uint8_t* p; size_t len, vol; int64_t local;
+    const uint8_t* p = nullptr; size_t len = 0, vol = 0; int64_t local = 0;
     const int rc = header_bytes(h, first_seqno + i, &p, &len, &vol, &local);
     if (rc != SWA_OK) return rc;
     bool ok = h->db.in_mask(vol, local);
@@ -738,7 +738,7 @@ int swa::read_blast_deflines(const char* basename, int symtype, const std::vecto
 {
   swa_headers* h = nullptr;
   int rc = swa_headers_open(basename, symtype, nullptr, &h);
-  if (rc != SWA_OK) return rc;
+  if (rc != SWA_OK || !h) return rc;
   deflines.clear();
   lengths.clear();
   DeflineFilter f;
@@ -746,7 +746,7 @@ int swa::read_blast_deflines(const char* basename, int symtype, const std::vecto
   f.db = &h->db;
   const bool protein = h->db.protein;
   for (int64_t s : seqnos) {
-    const uint8_t* p; size_t n, vol; int64_t local;
+    const uint8_t* p = nullptr; size_t n = 0, vol = 0; int64_t local = 0;
     rc = header_bytes(h, s, &p, &n, &vol, &local);
     if (rc != SWA_OK) break;
     deflines.push_back(render_deflines(p, n, f, nullptr));
