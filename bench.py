@@ -7,6 +7,7 @@ and the per-shard top-K lists are merged after one all_gather over RCCL.
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...   (no launcher: re-executes itself as the line above on a free port)
 
     --weak                      every rank its own --nseq sequences (N x 10M database)
     --workload protein100M      BASELINE.json configs[4]: 100 M proteins over the N ranks (12.5 M each at N = 8)
@@ -449,6 +450,20 @@ def predict_scaling(a, local):
                             "RCCL all_gather across xGMI instead of inside one rank (a 4 KB message: tens of microseconds)"}
 
 
+def relaunch_command(gpus, env, argv):
+    """The command `python bench.py --gpus N` turns itself into when N > 1 and no launcher set WORLD_SIZE: the driver's own
+    line (torch.distributed.run, one node, N ranks, rendezvous on 127.0.0.1 - the container's hostname may not resolve) on a
+    free port.  None when there is nothing to do."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -468,6 +483,14 @@ def main():
     ap.add_argument("--workload", choices=["protein", "protein100M", "nucleotide"], default="protein",
                     help="protein = BASELINE.json configs[1] (the headline); protein100M = configs[4]; nucleotide = configs[3]")
     a = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: become the launcher the driver uses (one rank per GPU over RCCL).  Under
+    # torch.distributed.run WORLD_SIZE is set and is what counts; --gpus is then only the caller's statement of it.
+    cmd = relaunch_command(a.gpus, os.environ, sys.argv[1:])
+    if cmd:
+        os.execv(cmd[0], cmd)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: running {os.environ['WORLD_SIZE']} ranks", file=sys.stderr)
 
     rank = int(os.environ.get("RANK", "0"))
     # SWA_BENCH_DEVICE / SWA_BENCH_BACKEND=gloo: tests run the N-rank code path on the ONE GPU a test box has (all ranks on

@@ -532,6 +532,21 @@ def test_group_layer_is_thread_sanitizer_clean(tmp_path):
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "group check ok" in r.stdout, r.stderr[-3000:]
 
 
+def test_bench_launches_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` outside torch.distributed.run re-executes itself as the driver's command (one node, N
+    ranks, rendezvous on 127.0.0.1); under a launcher (WORLD_SIZE set) and at N = 1 it runs as it is"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.relaunch_command(1, {}, ["--gpus", "1"]) is None
+    assert bench.relaunch_command(8, {"WORLD_SIZE": "8"}, ["--gpus", "8"]) is None
+    cmd = bench.relaunch_command(4, {}, ["--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+
+
 def test_damaged_database_files_end_in_a_status_not_in_a_wild_read(tmp_path):
     """swipe_amd/csrc/blastdb.cpp - index walk, residue unpacking with ambiguity runs, OID masks, the BER walker of the
     definition lines - compiled with -fsanitize=address,undefined and run over databases damaged one file at a time
