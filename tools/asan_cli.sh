@@ -8,10 +8,16 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 test -x swipe_amd/swipe_amd_cli_asan || { echo "no swipe_amd/swipe_amd_cli_asan: make -C swipe_amd/csrc asan"; exit 2; }
 mkdir -p gpurun_out/asan
-cp swipe_amd/swipe_amd_cli swipe_amd/swipe_amd_cli.plain
-cp swipe_amd/swipe_amd_cli_asan swipe_amd/swipe_amd_cli
 # protect_shadow_gap=0: the HSA runtime reserves address ranges inside ASan's shadow gap; leaks: the runtime's own at exit
 export ASAN_OPTIONS=protect_shadow_gap=0:detect_leaks=0:halt_on_error=1:log_path=$PWD/gpurun_out/asan/report
+export UBSAN_OPTIONS=print_stacktrace=1
+if [ -x swipe_amd/host_paths_asan ]; then      # the C ABI's other host paths, self-checking (tests/stubs/host_paths_check.cpp)
+  timeout 300 swipe_amd/host_paths_asan 0 2>&1 | tail -40
+  echo "host_paths_asan rc=${PIPESTATUS[0]}"
+fi
+[ "$2" = "paths-only" ] && { echo "ASan report files: $(ls gpurun_out/asan | wc -l)"; exit 0; }
+cp swipe_amd/swipe_amd_cli swipe_amd/swipe_amd_cli.plain
+cp swipe_amd/swipe_amd_cli_asan swipe_amd/swipe_amd_cli
 timeout ${1:-600} python -m pytest tests/test_gpu_group.py tests/test_gpu_parity.py -m gpu -q \
   -k "test_gpu_group or cli_output or cli_alignment or translated_cli or cli_real_database or cli_multi_query or cli_errors" 2>&1 | tail -25
 rc=${PIPESTATUS[0]}
