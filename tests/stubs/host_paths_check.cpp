@@ -342,13 +342,72 @@ static void nucleotide_shard(int device, std::mt19937_64& rng)
   swa_db_close(tr);
 }
 
+// the same arrays through BLAST v4 volumes on disk: whole, a range, streamed, six translated frames
+static void files_shard(int device, std::mt19937_64& rng, const std::string& dir)
+{
+  const std::vector<uint8_t> q = random_seq(rng, 120, true);
+  Db d;
+  d.off.push_back(0);
+  for (int s = 0; s < 60000; ++s) append(d, s % 611 == 2 ? homolog(rng, q, 0, 120, rng() % 40, rng() % 40, true) : random_seq(rng, s == 9 ? 0 : 5 + rng() % 800, true));   // 24 MB: streams under a 24 MiB budget
+  const int64_t n = d.nseq();
+  const std::string base = dir + "/hp_aa";
+  EXPECT(swa_blastdb_write(base.c_str(), SWA_SYMTYPE_PROTEIN, d.res.data(), d.off.data(), n, 1, "host paths") == SWA_OK);
+  int64_t M[1024];
+  EXPECT(swa_matrix_builtin("BLOSUM62", M) == SWA_OK);
+  swa_db *mem = nullptr, *whole = nullptr, *part = nullptr, *str = nullptr, *none = nullptr;
+  EXPECT(swa_db_from_memory(d.res.data(), d.off.data(), n, SWA_SYMTYPE_PROTEIN, device, 0, 0, 0, &mem) == SWA_OK);
+  EXPECT(swa_db_open(base.c_str(), SWA_SYMTYPE_PROTEIN, device, 0, -1, &whole) == SWA_OK);
+  EXPECT(swa_db_open(base.c_str(), SWA_SYMTYPE_PROTEIN, device, 300, 899, &part) == SWA_OK);
+  EXPECT(swa_db_open_streamed(base.c_str(), SWA_SYMTYPE_PROTEIN, device, 0, -1, int64_t(24) << 20, &str) == SWA_OK);
+  EXPECT(swa_db_open_streamed(base.c_str(), SWA_SYMTYPE_PROTEIN, device, 0, -1, int64_t(1) << 20, &none) == SWA_ENOMEM && !none);   // no room for one sequence
+  EXPECT(swa_db_open((base + "_missing").c_str(), SWA_SYMTYPE_PROTEIN, device, 0, -1, &none) == SWA_EIO && !none);
+  if (mem && whole && part && str) {
+    for (swa_db* h : {mem, whole, part, str}) EXPECT(swa_set_scoring(h, M, 12, 1) == SWA_OK);
+    const std::vector<int64_t> a = all_scores(mem, q, n);
+    EXPECT(all_scores(whole, q, n) == a);
+    EXPECT(all_scores(str, q, n) == a);
+    const std::vector<int64_t> p = all_scores(part, q, 600);
+    EXPECT(std::equal(p.begin(), p.end(), a.begin() + 300));
+    swa_db_info_t pi;
+    EXPECT(swa_db_info(part, &pi) == SWA_OK && pi.first_seqno == 300 && pi.seqcount == 600 && pi.total_seqcount == n);
+    check_topk(part, q, p, 300, 20, 35, 1000000);
+    check_topk(str, q, a, 0, 20, 35, 1000000);
+  }
+  for (swa_db* h : {mem, whole, part, str}) swa_db_close(h);
+
+  // nucleotide volumes opened as six translated frames = the arrays translated in memory
+  Db t;
+  t.off.push_back(0);
+  for (int s = 0; s < 300; ++s) append(t, random_seq(rng, 3 + rng() % 700, false));
+  const std::string nb = dir + "/hp_nt";
+  EXPECT(swa_blastdb_write(nb.c_str(), SWA_SYMTYPE_NUCLEOTIDE, t.res.data(), t.off.data(), t.nseq(), 1, "host paths nt") == SWA_OK);
+  swa_db *tm = nullptr, *tf = nullptr;
+  EXPECT(swa_db_from_memory_translated(t.res.data(), t.off.data(), t.nseq(), 11, device, 0, 0, 0, &tm) == SWA_OK);
+  EXPECT(swa_db_open_translated(nb.c_str(), 11, device, 0, -1, &tf) == SWA_OK);
+  if (tm && tf) {
+    EXPECT(swa_set_scoring(tm, M, 12, 1) == SWA_OK && swa_set_scoring(tf, M, 12, 1) == SWA_OK);
+    const std::vector<uint8_t> pq = random_seq(rng, 40, true);
+    EXPECT(all_scores(tm, pq, 6 * t.nseq()) == all_scores(tf, pq, 6 * t.nseq()));
+  }
+  swa_db_close(tm);
+  swa_db_close(tf);
+  for (const char* e : {".pin", ".psq", ".phr"}) std::remove((base + e).c_str());
+  for (const char* e : {".nin", ".nsq", ".nhr"}) std::remove((nb + e).c_str());
+}
+
 int main(int argc, char** argv)
 {
   const int device = argc > 1 ? std::atoi(argv[1]) : 0;
-  std::mt19937_64 rng(argc > 2 ? uint64_t(std::atoll(argv[2])) : 20260930);
+  const uint64_t seed = argc > 2 ? uint64_t(std::atoll(argv[2])) : 20260930;
+  const int rounds = argc > 3 ? std::atoi(argv[3]) : 1;
+  const std::string dir = argc > 4 ? argv[4] : "/tmp";
   if (swa_device_count() < 1) { std::fprintf(stderr, "host paths check: no HIP device (there is no CPU fallback)\n"); return 2; }
-  protein_shard(device, rng);
-  nucleotide_shard(device, rng);
-  std::printf("host paths check: %d comparisons, %d bad\n", checks, bad);
+  for (int r = 0; r < rounds; ++r) {
+    std::mt19937_64 rng(seed + uint64_t(r));
+    protein_shard(device, rng);
+    nucleotide_shard(device, rng);
+    files_shard(device, rng, dir);
+  }
+  std::printf("host paths check: %d rounds from seed %llu, %d comparisons, %d bad\n", rounds, (unsigned long long)seed, checks, bad);
   return bad == 0 ? 0 : 1;
 }
