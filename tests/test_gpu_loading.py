@@ -244,7 +244,7 @@ big = np.array(M, dtype=np.int64).copy(); big[big > 0] *= 40
 db.set_scoring(big, 400, 40); db.search(q0, want_scores=False); db.search_topk(q0, keep=10, minscore=1000); searches += 2
 db.close()
 # budgeted shard (two slots), nucleotide shard (both strands, 4-bit stream), a shard that streams in from disk
-sdb = swipe_amd.Database.from_arrays(res, off, hbm_budget=12 << 20); sdb.set_scoring(M, 11, 1)
+sdb = swipe_amd.Database.from_arrays(res, off, hbm_budget=24 << 20); sdb.set_scoring(M, 11, 1)    # two slots of 4 MiB beside the 2 x 8 MiB reserve
 sdb.search_topk(q0, keep=50, minscore=60); sdb.search(q0[:40], want_scores=False); sdb.close(); searches += 2
 nres, noff = swipe_amd.synth_db(3, 20_000, protein=False)
 ndb = swipe_amd.Database.from_arrays(nres, noff, symtype=0); ndb.set_scoring(swipe_amd.matrix_nucleotide(1, -3), 5, 2)

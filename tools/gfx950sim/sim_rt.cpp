@@ -1,0 +1,404 @@
+// gfx950sim: a stand-in for the 34 entry points of libamdhip64 that libswipe_amd.so uses, backed by the interpreter of
+// sim_isa.cpp. LD_PRELOAD it (tools/gfx950sim/run.sh) and the product library runs unchanged, kernels included, on a machine
+// without a GPU: "device" memory is host memory, every stream is synchronous, every kernel launch is interpreted at once,
+// every device access is checked against the table of live allocations. TEST INFRASTRUCTURE ONLY - see sim_core.h.
+//
+// Environment: HIPSIM_CACHE (default /tmp/gfx950sim-cache) disassembly cache; HIPSIM_CUS (default 8) multiProcessorCount
+// reported (persistent grids scale with it); HIPSIM_MEM_GB (default 16); HIPSIM_STATS=<file> per-kernel wave-instruction
+// counts appended at exit and at every hipDeviceSynchronize; HIPSIM_ABORT=1 abort() on the first device fault;
+// HIPSIM_POISON=<u32> initial register / LDS / allocation pattern; HIPSIM_SWITCH=<n> waves of a workgroup take turns every
+// <= n instructions in a seeded random order (race hunting); HIPSIM_TRACE=1 one line per launch.
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <atomic>
+#include <mutex>
+#include <sstream>
+#include "sim_core.h"
+
+namespace {
+
+std::recursive_mutex g_mu;
+using Lock = std::lock_guard<std::recursive_mutex>;
+
+struct Alloc { uint64_t size; void* raw; bool host; };
+std::map<uint64_t, Alloc> g_allocs;          // start -> allocation; the checked range is [start, start + size)
+uint64_t g_allocated = 0;
+std::atomic<uint64_t> g_gen{1};                // bumped by every allocation / free: invalidates the per-thread range caches
+thread_local uint64_t t_lo = 1, t_hi = 0, t_gen = 0;    // last range that answered mem_ok
+
+struct FatBin {
+    const uint8_t* bundle = nullptr;
+    size_t size = 0;
+    std::string dir;
+    bool loaded = false;
+    std::map<std::string, sim::Kernel> kernels;
+};
+struct Registered { FatBin* fb; std::string name; };
+std::map<const void*, Registered> g_funcs;
+std::string g_fault;                          // sticky
+hipError_t g_last = hipSuccess;
+
+struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
+thread_local std::vector<CallCfg> t_cfg;
+
+uint32_t poison() { static uint32_t p = getenv("HIPSIM_POISON") ? (uint32_t)strtoul(getenv("HIPSIM_POISON"), nullptr, 0) : 0xBAD0BAD1u; return p; }
+int env_int(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
+
+std::string self_dir() {
+    Dl_info di;
+    if (dladdr((void*)&self_dir, &di) && di.dli_fname) {
+        std::string p = di.dli_fname;
+        size_t s = p.rfind('/');
+        return s == std::string::npos ? "." : p.substr(0, s);
+    }
+    return ".";
+}
+
+bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+size_t bundle_size(const uint8_t* b) {
+    uint64_t n; memcpy(&n, b + 24, 8);
+    size_t p = 32, end = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t off, size, tl;
+        memcpy(&off, b + p, 8); memcpy(&size, b + p + 8, 8); memcpy(&tl, b + p + 16, 8);
+        p += 24 + tl;
+        if (off + size > end) end = off + size;
+    }
+    return end > p ? end : p;
+}
+
+bool load_fatbin(FatBin& fb, std::string& err) {
+    if (fb.loaded) return true;
+    if (memcmp(fb.bundle, "__CLANG_OFFLOAD_BUNDLE__", 24) != 0) { err = "fat binary is not an uncompressed clang offload bundle"; return false; }
+    fb.size = bundle_size(fb.bundle);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < fb.size; i++) { h ^= fb.bundle[i]; h *= 1099511628211ull; }
+    const char* cache = getenv("HIPSIM_CACHE");
+    std::string root = cache ? cache : "/tmp/gfx950sim-cache";
+    mkdir(root.c_str(), 0777);
+    char name[64]; snprintf(name, sizeof name, "/%016llx", (unsigned long long)h);
+    fb.dir = root + name;
+    if (!file_exists(fb.dir + "/ok")) {
+        std::string tmp = fb.dir + ".tmp." + std::to_string(getpid());
+        mkdir(tmp.c_str(), 0777);
+        std::string bf = tmp + "/bundle.bin";
+        { std::ofstream o(bf, std::ios::binary); o.write((const char*)fb.bundle, (std::streamsize)fb.size); }
+        const char* prep = getenv("HIPSIM_PREP");
+        // LD_PRELOAD must not follow into the tools
+        std::string cmd = "env -u LD_PRELOAD python3 " + (prep ? std::string(prep) : self_dir() + "/prep.py") + " " + bf + " " + tmp + " 1>&2";
+        if (system(cmd.c_str()) != 0) { err = "gfx950sim: '" + cmd + "' failed"; return false; }
+        unlink(bf.c_str());
+        if (rename(tmp.c_str(), fb.dir.c_str()) != 0 && !file_exists(fb.dir + "/ok")) { err = "gfx950sim: cannot move " + tmp; return false; }
+        if (file_exists(tmp)) { std::string rm = "rm -rf " + tmp; if (system(rm.c_str())) {} }
+    }
+    std::ifstream m(fb.dir + "/co.meta");
+    if (!m) { err = "gfx950sim: no co.meta in " + fb.dir; return false; }
+    std::string line;
+    sim::Kernel* cur = nullptr;
+    while (std::getline(m, line)) {
+        std::istringstream is(line);
+        std::string tag; is >> tag;
+        if (tag == "K") {
+            sim::Kernel k;
+            is >> k.name >> k.code_addr >> k.lds >> k.scratch >> k.kernarg >> k.rsrc1 >> k.rsrc2 >> k.rsrc3 >> k.props >> k.preload;
+            k.sfile = fb.dir + "/co.s";
+            cur = &(fb.kernels[k.name] = k);
+        } else if (tag == "A" && cur) {
+            sim::KArg a; is >> a.offset >> a.size >> a.kind;
+            cur->args.push_back(a);
+        }
+    }
+    fb.loaded = true;
+    return true;
+}
+
+void dump_stats() {
+    const char* path = getenv("HIPSIM_STATS");
+    if (!path) return;
+    Lock lk(g_mu);
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    static const char* cls[] = {"salu", "valu", "vop3p", "lds", "vmem", "smem", "branch", "other"};
+    for (auto& fr : g_funcs) {
+        auto it = fr.second.fb->kernels.find(fr.second.name);
+        if (it == fr.second.fb->kernels.end() || !it->second.launches) continue;
+        sim::Kernel& k = it->second;
+        fprintf(f, "{\"pid\": %d, \"kernel\": \"%s\", \"launches\": %llu, \"workgroups\": %llu", (int)getpid(), k.name.c_str(), (unsigned long long)k.launches, (unsigned long long)k.wgs);
+        for (int i = 0; i < sim::C_N; i++) fprintf(f, ", \"%s\": %llu", cls[i], (unsigned long long)k.count[i]);
+        fprintf(f, "}\n");
+        k.launches = k.wgs = 0;
+        for (int i = 0; i < sim::C_N; i++) k.count[i] = 0;
+    }
+    fclose(f);
+}
+struct AtExit { ~AtExit() { dump_stats(); } } g_atexit;
+
+hipError_t fail(hipError_t e) { g_last = e; return e; }
+hipError_t sync_status() { return g_fault.empty() ? hipSuccess : fail(hipErrorLaunchFailure); }
+
+bool check_dev(const void* p, size_t n, const char* what) {
+    if (n == 0 || sim::mem_ok((uint64_t)(uintptr_t)p, n)) return true;
+    fprintf(stderr, "gfx950sim: %s: %zu bytes at %p are not inside a live allocation: %s\n", what, n, p, sim::mem_describe((uint64_t)(uintptr_t)p).c_str());
+    if (env_int("HIPSIM_ABORT", 0)) abort();
+    return false;
+}
+
+}  // namespace
+
+namespace sim {
+// No lock: the table only changes under g_mu, and the thread that launched a kernel holds g_mu for as long as its workers run.
+bool mem_ok(uint64_t a, uint64_t n) {
+    const uint64_t gen = g_gen.load(std::memory_order_relaxed);
+    if (t_gen == gen && a >= t_lo && a + n <= t_hi) return true;
+    auto it = g_allocs.upper_bound(a);
+    if (it == g_allocs.begin()) return false;
+    --it;
+    if (a + n > it->first + it->second.size) return false;
+    t_lo = it->first; t_hi = it->first + it->second.size; t_gen = gen;
+    return true;
+}
+std::string mem_describe(uint64_t a) {
+    char buf[256];
+    auto it = g_allocs.upper_bound(a);
+    if (it != g_allocs.begin()) {
+        auto p = std::prev(it);
+        snprintf(buf, sizeof buf, "%lld bytes past the end of the %llu-byte allocation at 0x%llx", (long long)(a - (p->first + p->second.size)), (unsigned long long)p->second.size,
+                 (unsigned long long)p->first);
+        std::string s = buf;
+        if (it != g_allocs.end()) { snprintf(buf, sizeof buf, "; %llu bytes before the allocation at 0x%llx", (unsigned long long)(it->first - a), (unsigned long long)it->first); s += buf; }
+        return s;
+    }
+    if (it != g_allocs.end()) { snprintf(buf, sizeof buf, "%llu bytes before the first allocation", (unsigned long long)(it->first - a)); return buf; }
+    return "no allocation is live";
+}
+}  // namespace sim
+
+static void* dev_alloc(size_t size, bool host) {
+    const size_t guard = 256;
+    size_t n = size ? size : 1;
+    uint8_t* raw = (uint8_t*)aligned_alloc(256, (n + 2 * guard + 255) & ~(size_t)255);
+    if (!raw) return nullptr;
+    uint32_t p = poison();
+    if (n <= (64u << 20)) for (size_t i = 0; i + 4 <= n + 2 * guard; i += 4) memcpy(raw + i, &p, 4);     // big buffers stay untouched (lazy pages)
+    void* user = raw + guard;
+    g_allocs[(uint64_t)(uintptr_t)user] = Alloc{n, raw, host};
+    g_allocated += n;
+    g_gen++;
+    return user;
+}
+static hipError_t dev_free(void* p) {
+    if (!p) return hipSuccess;
+    auto it = g_allocs.find((uint64_t)(uintptr_t)p);
+    if (it == g_allocs.end()) { fprintf(stderr, "gfx950sim: free of %p which is not a live allocation\n", p); return fail(hipErrorInvalidValue); }
+    g_allocated -= it->second.size;
+    free(it->second.raw);
+    g_allocs.erase(it);
+    g_gen++;
+    return hipSuccess;
+}
+
+extern "C" {
+
+void** __hipRegisterFatBinary(const void* data) {
+    struct Wrapper { uint32_t magic, version; const void* binary; const void* unused; };
+    const Wrapper* w = (const Wrapper*)data;
+    Lock lk(g_mu);
+    FatBin* fb = new FatBin();
+    fb->bundle = (const uint8_t*)w->binary;
+    return (void**)fb;
+}
+void __hipUnregisterFatBinary(void** /*modules*/) { dump_stats(); }
+void __hipRegisterFunction(void** modules, const void* hostFunction, char* /*deviceFunction*/, const char* deviceName, unsigned, void*, void*, void*, void*, int*) {
+    Lock lk(g_mu);
+    g_funcs[hostFunction] = Registered{(FatBin*)modules, deviceName};
+}
+void __hipRegisterVar(void**, void*, char*, const char* name, int, size_t, int, int) { fprintf(stderr, "gfx950sim: device variable %s is not modelled\n", name); }
+void __hipRegisterManagedVar(void*, void**, void*, const char* name, size_t, unsigned) { fprintf(stderr, "gfx950sim: managed variable %s is not modelled\n", name); }
+
+hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shmem, hipStream_t stream) { t_cfg.push_back(CallCfg{grid, block, shmem, stream}); return hipSuccess; }
+hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hipStream_t* stream) {
+    if (t_cfg.empty()) return fail(hipErrorInvalidValue);
+    CallCfg c = t_cfg.back(); t_cfg.pop_back();
+    *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
+    return hipSuccess;
+}
+
+hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t) {
+    Lock lk(g_mu);
+    if (!g_fault.empty()) return fail(hipErrorLaunchFailure);
+    auto it = g_funcs.find(func);
+    if (it == g_funcs.end()) { fprintf(stderr, "gfx950sim: launch of an unregistered function %p\n", func); return fail(hipErrorInvalidDeviceFunction); }
+    std::string err;
+    FatBin& fb = *it->second.fb;
+    if (!load_fatbin(fb, err)) { fprintf(stderr, "%s\n", err.c_str()); g_fault = err; return fail(hipErrorInvalidDeviceFunction); }
+    auto kit = fb.kernels.find(it->second.name);
+    if (kit == fb.kernels.end()) { fprintf(stderr, "gfx950sim: kernel %s not in its code object\n", it->second.name.c_str()); return fail(hipErrorInvalidDeviceFunction); }
+    sim::Kernel& k = kit->second;
+    size_t kbytes = ((size_t)k.kernarg + 255) & ~(size_t)255;
+    uint8_t* ka = (uint8_t*)dev_alloc(kbytes, true);
+    memset(ka, 0, kbytes);
+    int ai = 0;
+    uint32_t dims = grid.z > 1 ? 3 : grid.y > 1 ? 2 : 1;
+    for (auto& a : k.args) {
+        uint8_t* p = ka + a.offset;
+        auto put = [&](uint64_t v) { memcpy(p, &v, a.size); };
+        if (a.kind.rfind("hidden_", 0) != 0) { memcpy(p, args[ai++], a.size); continue; }
+        if (a.kind == "hidden_block_count_x") put(grid.x);
+        else if (a.kind == "hidden_block_count_y") put(grid.y);
+        else if (a.kind == "hidden_block_count_z") put(grid.z);
+        else if (a.kind == "hidden_group_size_x") put(block.x);
+        else if (a.kind == "hidden_group_size_y") put(block.y);
+        else if (a.kind == "hidden_group_size_z") put(block.z);
+        else if (a.kind == "hidden_grid_dims") put(dims);
+        else if (a.kind == "hidden_dynamic_lds_size") put(shmem);
+        else if (a.kind == "hidden_private_base") put(0x00020000u);
+        else if (a.kind == "hidden_shared_base") put(0x00010000u);
+        // remainders, global offsets, printf / hostcall / heap / queue pointers: zero
+    }
+    if (env_int("HIPSIM_TRACE", 0))
+        fprintf(stderr, "gfx950sim: launch %s grid (%u,%u,%u) block (%u,%u,%u) lds %u+%zu\n", k.name.c_str(), grid.x, grid.y, grid.z, block.x, block.y, block.z, k.lds, shmem);
+    std::string f = sim::run_kernel(k, sim::Dim3{grid.x, grid.y, grid.z}, sim::Dim3{block.x, block.y, block.z}, ka, (uint32_t)shmem);
+    dev_free(ka);
+    if (!f.empty()) {
+        g_fault = f;
+        fprintf(stderr, "gfx950sim: DEVICE FAULT: %s\n", f.c_str());
+        if (env_int("HIPSIM_ABORT", 0)) abort();
+        return fail(hipErrorLaunchFailure);
+    }
+    return hipSuccess;
+}
+
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : fail(hipErrorInvalidDevice); }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* p, int d) {
+    if (d != 0) return fail(hipErrorInvalidDevice);
+    memset(p, 0, sizeof *p);
+    snprintf(p->name, sizeof p->name, "gfx950sim (CPU interpreter)");
+    snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950:sramecc+:xnack-");
+    p->totalGlobalMem = (size_t)env_int("HIPSIM_MEM_GB", 16) << 30;
+    p->sharedMemPerBlock = 64 << 10;
+    p->maxSharedMemoryPerMultiProcessor = 160 << 10;
+    p->sharedMemPerBlockOptin = 160 << 10;
+    p->regsPerBlock = 65536;
+    p->warpSize = 64;
+    p->maxThreadsPerBlock = 1024;
+    p->maxThreadsDim[0] = p->maxThreadsDim[1] = p->maxThreadsDim[2] = 1024;
+    p->maxGridSize[0] = p->maxGridSize[1] = p->maxGridSize[2] = 2147483647;
+    p->clockRate = 2400000;
+    p->memoryClockRate = 2000000;
+    p->memoryBusWidth = 8192;
+    p->multiProcessorCount = env_int("HIPSIM_CUS", 8);
+    p->l2CacheSize = 4 << 20;
+    p->maxThreadsPerMultiProcessor = 2048;
+    p->major = 9; p->minor = 5;
+    p->concurrentKernels = 1;
+    p->asyncEngineCount = 2;
+    p->canMapHostMemory = 1;
+    return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+    switch (a) {
+        case hipDeviceAttributeMultiprocessorCount: *v = env_int("HIPSIM_CUS", 8); break;
+        case hipDeviceAttributeWarpSize: *v = 64; break;
+        case hipDeviceAttributeMaxSharedMemoryPerBlock: *v = 64 << 10; break;
+        default: *v = 0; break;
+    }
+    return hipSuccess;
+}
+const char* hipGetErrorString(hipError_t e) {
+    switch (e) {
+        case hipSuccess: return "no error";
+        case hipErrorLaunchFailure: return g_fault.empty() ? "unspecified launch failure" : g_fault.c_str();
+        case hipErrorInvalidValue: return "invalid argument";
+        case hipErrorOutOfMemory: return "out of memory";
+        case hipErrorInvalidDeviceFunction: return "invalid device function";
+        case hipErrorInvalidDevice: return "invalid device ordinal";
+        default: return "gfx950sim: error";
+    }
+}
+const char* hipGetErrorName(hipError_t e) { return hipGetErrorString(e); }
+hipError_t hipGetLastError() { hipError_t e = g_last; g_last = hipSuccess; return e; }
+hipError_t hipPeekAtLastError() { return g_last; }
+
+hipError_t hipMalloc(void** p, size_t n) {
+    Lock lk(g_mu);
+    uint64_t cap = (uint64_t)env_int("HIPSIM_MEM_GB", 16) << 30;
+    if (g_allocated + n > cap) { *p = nullptr; return fail(hipErrorOutOfMemory); }
+    *p = dev_alloc(n, false);
+    return *p ? hipSuccess : fail(hipErrorOutOfMemory);
+}
+hipError_t hipFree(void* p) { Lock lk(g_mu); return dev_free(p); }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { Lock lk(g_mu); *p = dev_alloc(n, true); g_allocated -= n ? n : 1; return *p ? hipSuccess : fail(hipErrorOutOfMemory); }
+hipError_t hipHostFree(void* p) {
+    Lock lk(g_mu);
+    auto it = g_allocs.find((uint64_t)(uintptr_t)p);
+    if (it != g_allocs.end()) g_allocated += it->second.size;
+    return dev_free(p);
+}
+hipError_t hipMemGetInfo(size_t* fr, size_t* tot) {
+    Lock lk(g_mu);
+    uint64_t cap = (uint64_t)env_int("HIPSIM_MEM_GB", 16) << 30;
+    *tot = cap; *fr = cap > g_allocated ? cap - g_allocated : 0;
+    return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    Lock lk(g_mu);
+    bool ok = true;
+    if (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice) ok &= check_dev(dst, n, "copy destination");
+    if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) ok &= check_dev(src, n, "copy source");
+    if (!ok) return fail(hipErrorInvalidValue);
+    if (n) memmove(dst, src, n);
+    return sync_status();
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t) { return hipMemcpy(dst, src, n, kind); }
+hipError_t hipMemset(void* dst, int v, size_t n) {
+    Lock lk(g_mu);
+    if (!check_dev(dst, n, "memset")) return fail(hipErrorInvalidValue);
+    if (n) memset(dst, v, n);
+    return sync_status();
+}
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { return hipMemset(dst, v, n); }
+
+hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+hipError_t hipStreamDestroy(hipStream_t s) { free((void*)s); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { Lock lk(g_mu); return sync_status(); }
+hipError_t hipStreamSynchronize(hipStream_t) { Lock lk(g_mu); return sync_status(); }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { dump_stats(); Lock lk(g_mu); return sync_status(); }
+hipError_t hipDeviceReset() { return hipSuccess; }
+
+struct SimEvent { std::chrono::steady_clock::time_point t; bool recorded; };
+hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t) new SimEvent{std::chrono::steady_clock::now(), false}; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) { delete (SimEvent*)e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { auto* s = (SimEvent*)e; s->t = std::chrono::steady_clock::now(); s->recorded = true; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { Lock lk(g_mu); return sync_status(); }
+hipError_t hipEventQuery(hipEvent_t) { Lock lk(g_mu); return sync_status(); }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    auto* x = (SimEvent*)a; auto* y = (SimEvent*)b;
+    double d = std::chrono::duration<double, std::milli>(y->t - x->t).count();
+    *ms = (float)(d > 1e-6 ? d : 1e-6);
+    return hipSuccess;
+}
+
+// diagnostics for tools and tests
+const char* hipsim_fault() { return g_fault.c_str(); }
+void hipsim_clear_fault() { Lock lk(g_mu); g_fault.clear(); g_last = hipSuccess; }
+void hipsim_dump_stats() { dump_stats(); }
+unsigned long long hipsim_live_allocations() { Lock lk(g_mu); return g_allocs.size(); }
+
+}  // extern "C"
