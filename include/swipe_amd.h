@@ -424,6 +424,12 @@ SWA_API int swa_group_from_memory(const uint8_t* residues, const int64_t* offset
                           int nshards, const int* devices, int64_t first_seqno, int64_t total_seqcount,
                           int64_t total_symcount, swa_group** out);
 SWA_API void swa_group_close(swa_group* g);
+/* swa_group_open returns as soon as every shard's index is read; the residues stream in behind it (swa_db_open_async per
+   shard) and a search follows the loaders.  swa_group_wait blocks until every shard is resident and returns the first load
+   error (truncated file, residue code out of range, ...); swa_group_load_progress sums swa_db_load_progress over the
+   shards.  Mirrors: db_open + db_mapsequences over all volumes, database.cc:1082-1131. */
+SWA_API int swa_group_wait(swa_group* g);
+SWA_API int swa_group_load_progress(swa_group* g, int64_t* bytes_loaded, int64_t* bytes_total, int32_t* parts_ready, int32_t* parts_total);
 /* *nshards = shards actually created; info describes the union of the shards (hbm_bytes summed) */
 SWA_API int swa_group_info(const swa_group* g, swa_db_info_t* info, int* nshards);
 /* shard i's own handle (borrowed; for swa_db_info and the A/B tools - searches go through the group) */

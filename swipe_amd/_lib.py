@@ -60,7 +60,7 @@ EXPORTS = [
     "swa_matrix_parse", "swa_default_gaps",
     "swa_synth_length", "swa_synth_offsets", "swa_synth_fill",
     "swa_shard_bounds", "swa_blastdb_shard_bounds", "swa_group_open", "swa_group_open_streamed", "swa_group_from_memory", "swa_group_close", "swa_group_info",
-    "swa_group_shard", "swa_group_set_scoring", "swa_group_set_option", "swa_group_set_inclusion", "swa_group_search",
+    "swa_group_shard", "swa_group_wait", "swa_group_load_progress", "swa_group_set_scoring", "swa_group_set_option", "swa_group_set_inclusion", "swa_group_search",
     "swa_group_search_topk", "swa_group_search_pair_topk", "swa_group_search_frames_topk", "swa_group_align_hits",
     "swa_group_db_sequence", "swa_kernel_choice", "swa_kernel_rate", "swa_kernel_choice2", "swa_kernel_rate2",
 ]
@@ -156,6 +156,8 @@ def load():
     L.swa_group_shard.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.swa_group_set_scoring.argtypes = [vp, vp, i64, i64]
     L.swa_group_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.swa_group_wait.argtypes = [vp]
+    L.swa_group_load_progress.argtypes = [vp, i64p, i64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.swa_group_set_inclusion.argtypes = [vp, vp, i64]
     L.swa_group_search.argtypes = L.swa_search.argtypes
     L.swa_group_search_topk.argtypes = L.swa_search_topk.argtypes

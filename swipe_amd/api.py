@@ -432,10 +432,14 @@ class Group(Database):
         return cls.from_arrays(res, off, devices=devices, **kw)
 
     def wait(self):
-        raise SwaError("a Group is resident when swa_group_open returns")
+        """swa_group_open streams every shard in behind the call: block until all are resident (a load error - a truncated
+        .psq, a residue code out of range - is raised here rather than by the first search)"""
+        _check(_lib.load().swa_group_wait(self._h))
 
     def load_progress(self):
-        raise SwaError("a Group is resident when swa_group_open returns")
+        a, b, r, t = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        _check(_lib.load().swa_group_load_progress(self._h, C.byref(a), C.byref(b), C.byref(r), C.byref(t)))
+        return {"bytes_loaded": a.value, "bytes_total": b.value, "parts_ready": r.value, "parts_total": t.value}
 
     def info(self):
         i, n = _lib.DbInfo(), C.c_int()

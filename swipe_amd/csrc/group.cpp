@@ -326,6 +326,33 @@ try {
   return g->run_all([&](int i) { return swa_set_scoring(g->shard[size_t(i)], matrix, gapopenextend, gapextend); });
 } SWA_CATCH
 
+// Shards of swa_group_open stream in behind the call (swa_db_open_async): wait for all of them, first error wins.
+extern "C" int swa_group_wait(swa_group* g)
+try {
+  if (!g) return fail(SWA_EINVAL, "null group handle");
+  return g->run_all([&](int i) { return swa_db_wait(g->shard[size_t(i)]); });
+} SWA_CATCH
+
+// sums over the shards (all zero once every shard is resident); a failed load is reported here as by swa_db_load_progress
+extern "C" int swa_group_load_progress(swa_group* g, int64_t* bytes_loaded, int64_t* bytes_total, int32_t* parts_ready, int32_t* parts_total)
+try {
+  if (!g) return fail(SWA_EINVAL, "null group handle");
+  int64_t done = 0, total = 0;
+  int32_t ready = 0, parts = 0;
+  for (swa_db* db : g->shard) {
+    int64_t d = 0, t = 0;
+    int32_t r = 0, p = 0;
+    const int rc = swa_db_load_progress(db, &d, &t, &r, &p);
+    if (rc != SWA_OK) return rc;
+    done += d; total += t; ready += r; parts += p;
+  }
+  if (bytes_loaded) *bytes_loaded = done;
+  if (bytes_total) *bytes_total = total;
+  if (parts_ready) *parts_ready = ready;
+  if (parts_total) *parts_total = parts;
+  return SWA_OK;
+} SWA_CATCH
+
 extern "C" int swa_group_set_option(swa_group* g, const char* key, const char* value)
 try {
   if (!g || !key) return fail(SWA_EINVAL, "null argument");

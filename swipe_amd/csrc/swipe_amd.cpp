@@ -400,7 +400,8 @@ int streamed_candidates(swa_db* front, const uint8_t* query, int64_t qlen, int64
 int streamed_all_scores(swa_db* front, const uint8_t* query, int64_t qlen, int64_t* scores, swa_counters_t* counters,
                         const uint8_t* query2 = nullptr, int64_t* scores2 = nullptr);
 int streamed_by_owner(swa_db* front, const int64_t* seqnos, int64_t n, const std::function<int(swa_db*, const std::vector<int64_t>&)>& fn);
-int settle_loading(swa_db* db, bool wait, bool* still);
+int settle_loading(swa_db* db, bool wait, bool* still, bool explicit_wait = false);
+void release_loader_leftovers(swa_db* db);
 size_t loading_hbm(const swa_db* db);
 // entry points that want ONE resident shard: not for streamed handles; a shard that is still loading is waited for
 int loaded(swa_db* db)
@@ -695,18 +696,24 @@ uint32_t f16_pair(float v)
 // all sequences, one per DPP row (dual-query kernel, and the 32-bit kernel when f16 does not apply)
 int ensure_single(swa_db* db)
 {
+  const int lrc = settle_loading(db, true, nullptr);     // h_order is the loader's to fill: an empty set must never be marked built
+  if (lrc != SWA_OK) return lrc;
   if (db->single.built) return SWA_OK;
   return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 1, db->single);
 }
 // the same at 4 bits per base (nucleotide shards, two-query kernel with 16-lane chains)
 int ensure_single4(swa_db* db)
 {
+  const int lrc = settle_loading(db, true, nullptr);
+  if (lrc != SWA_OK) return lrc;
   if (db->single4.built) return SWA_OK;
   return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 1, db->single4, true);
 }
 // all sequences, two per DPP row
 int ensure_main(swa_db* db)
 {
+  const int lrc = settle_loading(db, true, nullptr);
+  if (lrc != SWA_OK) return lrc;
   if (db->main.built) return SWA_OK;
   return build_batches(db, db->h_order.data(), int64_t(db->h_order.size()), 2, db->main);
 }
@@ -792,7 +799,9 @@ int prepare_view(swa_db* db, const BatchSet& set, int per_row, int64_t qlen, con
   for (; nskip < set.nbatches; ++nskip) {
     bool any = false;
     for (int j = 0; j < per_batch; ++j) { const int32_t id = id_at(nskip, j); any |= id >= 0 && db->len_of(id) > wp.Lmax; }
-    if (!any) break;
+    // a merged table (streamed-in shard) is ordered by batch STEPS with ties broken by part: a batch without a long member may
+    // come before one with - stop only where no later batch can hold one (steps = longest member rounded up to even)
+    if (!any && (set.h_slots.empty() || set.h_steps[size_t(nskip)] <= wp.Lmax)) break;
     for (int j = 0; j < per_batch; ++j) {
       const int32_t id = id_at(nskip, j);
       if (id >= 0) (db->len_of(id) > wp.Lmax ? longs : rest).push_back(id);
@@ -1249,6 +1258,7 @@ int launch_dual_passes(swa_db* db, const BatchSet& bs, int64_t qlen, int nres, h
 //   [10..13] two 64-bit tallies (totalhits, obvious)                                 [16..] swa_cand records
 constexpr int CTL_INTS = 48;            // three 64-byte lines of counters (the third: tallies of a pair's second query)
 constexpr int CTL_CAND = 8, CTL_TALLY = 10;
+constexpr int CTL_LOADFLAGS = 6;        // OR of every byte the loader has stripped so far (a part-wise first pass copies it here)
 
 constexpr int CAND_EAGER = 4096;        // candidate records copied back together with the counters
 constexpr int REQUEUE_CAP = 1 << 16;    // sequences the device-driven re-queue takes; longer lists go through the host
@@ -1376,6 +1386,12 @@ int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int
   // time): a wave per sequence - the end-point kernel of the alignment phase, 64 lanes on one sequence - finishes the
   // 1 500 sequences the bound build sends back for the bench query in 1.3 ms instead of 1.5, the 390 of a 5 000-row
   // query in a fraction of the batch kernel's 20 passes.
+  {
+    // the host-driven paths below read the shard's length order and build sets from it: a shard whose first pass went part
+    // by part is complete by now (its parts' events are behind us) - adopt the loader's tables before touching them
+    const int lrc = settle_loading(db, true, nullptr);
+    if (lrc != SWA_OK) return lrc;
+  }
   const swa_seqs sq = db->seqs();
   bool by_wave = !requeue.empty() && requeue.size() <= size_t(REQUEUE_CAP) && int64_t(requeue.size()) < db->nseq &&
                  wave_requeue_ok(db, qlen);
@@ -1651,6 +1667,10 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
         HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
       }
       c.loading_parts = P;
+      // every unterminate kernel is ordered before the last part's event, so the OR of all residue bytes is final here: it
+      // comes back with the counters and settle_search refuses scores computed from codes >= 32 (they index outside the LDS
+      // profile and the 32 x 32 matrix; the resident reader rejects such a volume before any kernel runs)
+      HIP_TRY(hipMemcpyAsync(db->ctl.p + CTL_LOADFLAGS, LD->flags.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     } else {
       HIP_TRY(launch_first(p, blocks, st));
     }
@@ -1918,6 +1938,8 @@ int settle_search(swa_db* db, Pending& pd, const uint8_t* q1, const uint8_t* q2,
   *again = *changed = false;
   hipStream_t st = db->stream;
   if (pd.empty) return SWA_OK;
+  if (pd.c.loading_parts > 0 && (uint32_t(ctl_host(db)[CTL_LOADFLAGS]) & ~0x1Fu))
+    return fail(SWA_EINVAL, "database load failed: database residue code out of range (must be < 32)");
   const int64_t n1 = pd.dev1 ? ctl_host(db)[1] : 0, n2 = pd.dev2 ? ctl_host(db)[3] : 0;
   if (pd.dev1 || pd.dev2) {
     const int64_t lists = pd.dev2 ? 2 : 1;
@@ -2228,6 +2250,7 @@ try {
   const int64_t real = db->nseq / db->frames;
   if (include && n != real) return fail(SWA_EINVAL, "inclusion array must have one entry per sequence of the shard");
   HIP_TRY(hipSetDevice(db->device));
+  release_loader_leftovers(db);
   std::vector<int32_t> in, ex;
   db->active_sym = 0;
   for (int64_t v = 0; v < db->nseq; ++v) {
@@ -2276,6 +2299,7 @@ try {
     return streamed_set_scoring(db, matrix, gapopenextend, gapextend);
   }
   HIP_TRY(hipSetDevice(db->device));
+  release_loader_leftovers(db);                      // (a no-op unless a streamed-in shard's tables were adopted by a search)
   HIP_TRY(hipMemcpyAsync(db->matrix.p, db->h_matrix, sizeof db->h_matrix, hipMemcpyHostToDevice, db->stream));
   HIP_TRY(hipStreamSynchronize(db->stream));
   db->scoring_set = true;

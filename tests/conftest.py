@@ -55,3 +55,15 @@ def shard_devices(k):
     env = os.environ.get("SWA_TEST_DEVICES", "").strip()
     pool = [int(x) for x in env.split(",") if x.strip() != ""] if env else list(range(max(1, swipe_amd._lib.load().swa_device_count())))
     return [pool[i % len(pool)] for i in range(k)]
+
+
+def under_interpreter():
+    """the suite is running on tools/gfx950sim (LD_PRELOAD, no GPU): kernels are interpreted, every device access is checked"""
+    return os.environ.get("HIPSIM") == "1"
+
+
+def interpreter_clear_fault():
+    """a device fault is sticky, as on hardware; a test that provokes one on purpose clears it for the tests after it"""
+    if under_interpreter():
+        import ctypes
+        ctypes.CDLL(None).hipsim_clear_fault()

@@ -177,6 +177,36 @@ def test_group_api_equals_one_shard(shards):
     grp.close()
 
 
+@pytest.mark.late
+def test_group_wait_and_load_errors(tmp_path):
+    """swa_group_open streams its shards in behind the call; swa_group_wait / swa_group_load_progress are how a caller
+    waits for them and sees a load error (here: a residue code >= 32 in the second shard) before the first search"""
+    q = blastdb.encode_protein(swipe_amd.synth.QUERY_P07327)
+    res, off = swipe_amd.synth_db(3, 20000, query=q)
+    base = str(tmp_path / "g")
+    swipe_amd.write_blastdb(base, res, off, first_id=0)
+    grp = swipe_amd.Group.open(base, devices=tuple(shard_devices(3)))
+    p = grp.load_progress()
+    assert set(p) == {"bytes_loaded", "bytes_total", "parts_ready", "parts_total"}
+    grp.wait()
+    assert grp.load_progress() == {"bytes_loaded": 0, "bytes_total": 0, "parts_ready": 0, "parts_total": 0}
+    grp.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    one = swipe_amd.Database.from_arrays(res, off)
+    one.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+    assert grp.search_topk(q, 100, 50)[:3] == one.search_topk(q, 100, 50)[:3]
+    one.close()
+    grp.close()
+    with open(base + ".psq", "r+b") as f:
+        f.seek(int(off[15000]) + 15000 + 3)
+        f.write(bytes([99]))
+    bad = swipe_amd.Group.open(base, devices=tuple(shard_devices(3)))
+    try:
+        with pytest.raises(swipe_amd.SwaError, match="out of range"):
+            bad.wait()
+    finally:
+        bad.close()
+
+
 def test_group_of_a_translated_nucleotide_database():
     case = cases.get("tblastn")
     res, off = oracle.pack(case.seqs)

@@ -193,6 +193,34 @@ def test_residue_code_out_of_range_is_reported(volumes, tmp_path):
         db.close()
 
 
+@pytest.mark.late
+def test_search_before_wait_on_a_corrupt_volume_fails(volumes, tmp_path):
+    """a search that FOLLOWS the loader must not return scores computed from residue codes >= 32 (they index outside
+    the LDS profile); the flag the unterminate kernels OR together comes back with the search's own counters"""
+    import shutil
+    for ext in ("pin", "psq", "phr"):
+        shutil.copy(volumes["one"] + "." + ext, str(tmp_path / ("bad2." + ext)))
+    with open(str(tmp_path / "bad2.psq"), "r+b") as f:
+        f.seek(int(volumes["off"][59_000]) + 59_000 + 5)          # in the LAST part: every earlier part is searched first
+        f.write(bytes([77]))
+    for entry in ("topk", "all"):
+        with _Env(**SLOW):
+            db = swipe_amd.Database.open(str(tmp_path / "bad2"), wait=False)
+        try:
+            db.set_scoring(_matrix(), 11, 1)
+            # hardware: an LDS read beyond the profile returns 0, the kernel ends, the flag refuses the result ("load failed");
+            # tools/gfx950sim: the out-of-range LDS read itself is the fault
+            with pytest.raises(swipe_amd.SwaError, match="load failed|LDS access out of range"):
+                if entry == "topk":
+                    db.search_topk(Q, keep=10, minscore=50)
+                else:
+                    db.search(Q)
+        finally:
+            db.close()
+            from conftest import interpreter_clear_fault
+            interpreter_clear_fault()
+
+
 def test_truncated_sequence_file_is_reported(volumes, tmp_path):
     import shutil
     for ext in ("pin", "psq", "phr"):
