@@ -158,7 +158,7 @@ SWA_API int swa_db_from_memory_translated(const uint8_t* nt_residues, const int6
    buffering) - and merges the per-part candidates, so hit lists, counts and scores are those of the resident shard.
    The handle answers every search entry point (nucleotide parts carry the 4-bit one-sequence-per-row tables their both-strand
    searches run over) and - the owning part bound to a slot for the call - swa_search_endpoints[_strand], swa_align_hits and
-   swa_db_sequence; swa_db_set_inclusion returns SWA_ESTATE (subsets need a resident shard).  hbm_budget_bytes <= 0 or large
+   swa_db_sequence; swa_db_set_inclusion re-plans every part's tables for the admitted sequences (db_check_inclusion, database.cc:670-772).  hbm_budget_bytes <= 0 or large
    enough: an ordinary resident shard.
    The budget covers what the default searches use: the two slots with their residues, tables and first-pass stream.  What a
    part does not carry is built per part and search OUTSIDE it: the pair stream of a nucleotide part for a single-strand
@@ -417,7 +417,7 @@ SWA_API int swa_blastdb_shard_bounds(const char* basename, int symtype, int nsha
 SWA_API int swa_group_open(const char* basename, int symtype, int db_gencode, int nshards, const int* devices, swa_group** out);
 /* every shard with an HBM budget of its own (swa_db_open_streamed: the reference maps any range of a database a chunk at a
    time with any thread count, database.cc:1082-1131); hbm_budget_bytes is PER DEVICE.  Searches, end points, alignments and
-   sequence fetches work as on resident shards; inclusion masks need resident shards. */
+   sequence fetches and inclusion masks (swa_group_set_inclusion, masked aliases) work as on resident shards. */
 SWA_API int swa_group_open_streamed(const char* basename, int symtype, int nshards, const int* devices, int64_t hbm_budget_bytes,
                             swa_group** out);
 SWA_API int swa_group_from_memory(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int db_gencode,

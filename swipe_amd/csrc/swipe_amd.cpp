@@ -226,6 +226,7 @@ struct Options {
   int64_t load_threads = 0;      // reader threads per chunk; 0 = half the hardware threads, 2..16
   int64_t load_delay_ms = 0;     // tests: the loader sleeps that long after every chunk
   int64_t load_trace = 0;        // 1: one line on stderr with the stages of the load
+  int64_t stream_reserve = -1;   // budgeted shards (sw_streamed.inc): bytes of a slot set aside for buffers that do not scale with the part; -1 = 8 MiB (tests: small databases in several parts)
 };
 struct OptionKey { const char* key; int64_t Options::*field; };
 const OptionKey kOptionKeys[] = {
@@ -237,7 +238,7 @@ const OptionKey kOptionKeys[] = {
   {"requeue_follow", &Options::requeue_follow}, {"window", &Options::window}, {"window_step", &Options::window_step},
   {"long_lanes", &Options::long_lanes}, {"watchdog_s", &Options::watchdog_s}, {"pipelined", &Options::pipelined},
   {"load_part", &Options::load_part}, {"load_chunk", &Options::load_chunk}, {"load_threads", &Options::load_threads},
-  {"load_delay_ms", &Options::load_delay_ms}, {"load_trace", &Options::load_trace},
+  {"load_delay_ms", &Options::load_delay_ms}, {"load_trace", &Options::load_trace}, {"stream_reserve", &Options::stream_reserve},
 };
 bool parse_option_value(const char* key, const char* value, int64_t* out)
 {
@@ -393,6 +394,7 @@ struct swa_db {
 
 namespace {
 int streamed_set_scoring(swa_db* front, const int64_t* matrix, int64_t goe, int64_t ge);
+int streamed_set_inclusion(swa_db* front, const uint8_t* include, int64_t n);
 size_t streamed_hbm(const swa_db* front);
 int streamed_candidates(swa_db* front, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore, int64_t maxscore,
                         std::vector<struct Cand>& cand, int64_t* tot, int64_t* obv, swa_counters_t* counters,
@@ -407,12 +409,6 @@ size_t loading_hbm(const swa_db* db);
 int loaded(swa_db* db)
 {
   return db && db->loading ? settle_loading(db, true, nullptr) : SWA_OK;
-}
-int not_streamed(swa_db* db, bool wait = true)
-{
-  if (wait && db && db->loading) { const int rc = settle_loading(db, true, nullptr); if (rc != SWA_OK) return rc; }
-  return db && db->streamed ? fail(SWA_ESTATE, "a shard opened with an HBM budget has no inclusion masks: open it resident "
-                                               "(swa_db_open) to search a subset") : SWA_OK;
 }
 
 // fn(lo, hi) over [0, n) on a few host threads (disjoint ranges; at least `grain` items per thread)
@@ -2246,7 +2242,8 @@ try {
 extern "C" int swa_db_set_inclusion(swa_db* db, const uint8_t* include, int64_t n)
 try {
   if (!db) return fail(SWA_EINVAL, "null database handle");
-  { const int src_ = not_streamed(db); if (src_ != SWA_OK) return src_; }
+  if (db->streamed) return streamed_set_inclusion(db, include, n);     // a budgeted shard: per part (sw_streamed.inc)
+  { const int src_ = loaded(db); if (src_ != SWA_OK) return src_; }
   const int64_t real = db->nseq / db->frames;
   if (include && n != real) return fail(SWA_EINVAL, "inclusion array must have one entry per sequence of the shard");
   HIP_TRY(hipSetDevice(db->device));

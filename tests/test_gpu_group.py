@@ -178,6 +178,84 @@ def test_group_api_equals_one_shard(shards):
 
 
 @pytest.mark.late
+@pytest.mark.parametrize("variant", ["masked", "masked_gis_taxid", "taxlist", "plain_taxid", "masked_taxlist"])
+def test_cli_masks_and_taxid_lists_with_an_hbm_budget(tmp_path, variant):
+    """OID-mask aliases and -x taxid lists on shards that walk their parts through two device slots
+    (db_check_inclusion works on whatever range the reference has mapped, database.cc:670-772, 1403-1481) - the reference's
+    golden output, byte for byte, at about a half and a quarter of the footprint; SWA_STREAM_RESERVE shrinks the fixed
+    allowance of a slot so that this small database really is cut into parts"""
+    from test_host_cpu import build_headers_db, HEADER_VARIANTS
+    case, vol, masked, tx = build_headers_db(tmp_path)
+    ref = load_golden("headers")["variants"][variant]
+    dbn, flags, taxlist = HEADER_VARIANTS[variant]
+    qf = str(tmp_path / "q.fa")
+    open(qf, "w").write(">query test\n" + "".join(blastdb.NCBISTDAA[c] for c in case.query) + "\n")
+    nsym, nseq = sum(len(x) for x in case.seqs), len(case.seqs)
+    footprint = int(2.04 * nsym + 77 * nseq) + 4096
+    env = dict(os.environ, SWA_STREAM_RESERVE="2048")
+    for shards in (1, 2):
+        for frac in (0.5, 0.25):
+            budget = int(frac * footprint / shards) + 2 * 2048 + 2 * int(2.04 * max(len(x) for x in case.seqs) + 77)
+            args = [EXE, "-d", vol if dbn == "vol" else masked, "-i", qf, "-v", str(case.keep), "-e", "1e6", "--hbm-budget", str(budget)] + shard_args(shards)
+            args += (["-I"] if flags & 1 else []) + (["-H"] if flags & 2 else []) + (["-x", tx] if taxlist else [])
+            run = lambda extra: subprocess.run(args + extra, capture_output=True, text=True, check=True, env=env).stdout
+            assert run(["-m", "7", "-b", "5"]) == ref["m7"], (shards, frac)
+            assert run(["-m", "8", "-b", str(case.keep)]) == ref["m8"], (shards, frac)
+            plain = run(["-m", "0", "-b", "5"])
+            assert plain[plain.index("Sequences producing"):] == ref["m0"], (shards, frac)
+
+
+@pytest.mark.late
+@pytest.mark.parametrize("nt", [False, True])
+def test_inclusion_set_on_a_budgeted_shard(nt):
+    """swa_db_set_inclusion on a handle opened with an HBM budget: every part re-plans its tables for the admitted sequences;
+    all scores, top-K with counts, pairs / both strands, end points and alignments equal the resident shard's under the same
+    set - including sets that empty whole parts - and lifting the set restores the full answers"""
+    from swipe_amd import synth
+    rng = np.random.default_rng(11)
+    if nt:
+        res, off = swipe_amd.synth_db(4, 12_000, protein=False)
+        q = synth._random_residues(17, 1, 300, synth.residue_table_nucleotide())
+        M, go, ge, sym = swipe_amd.matrix_nucleotide(1, -3), 5, 2, 0
+    else:
+        q = blastdb.encode_protein(synth.QUERY_P07327)
+        res, off = swipe_amd.synth_db(8, 12_000, query=q)
+        M, go, ge, sym = swipe_amd.matrix_builtin("BLOSUM62"), 11, 1, 1
+    n = len(off) - 1
+    footprint = int((1.02 if nt else 2.04) * int(off[-1]) + 90 * n)
+    os.environ["SWA_STREAM_RESERVE"] = "65536"
+    try:
+        sdb = swipe_amd.Database.from_arrays(res, off, symtype=sym, hbm_budget=footprint // 3 + 2 * 65536)
+    finally:
+        os.environ.pop("SWA_STREAM_RESERVE", None)
+    one = swipe_amd.Database.from_arrays(res, off, symtype=sym)
+    assert sdb.info()["hbm_bytes"] < one.info()["hbm_bytes"]          # it really is over budget: two slots of a part each
+    for d in (one, sdb):
+        d.set_scoring(M, go, ge)
+    sets = [rng.random(n) < 0.5, np.arange(n) >= n * 2 // 3, np.arange(n) % 997 == 5, None]
+    for inc in sets:
+        u8 = None if inc is None else inc.astype(np.uint8)
+        one.set_inclusion(u8)
+        sdb.set_inclusion(u8)
+        if nt:
+            qr = blastdb.revcomp_nt16(q)
+            assert one.search2_topk(q, qr, keep=60, minscore=25)[:3] == sdb.search2_topk(q, qr, keep=60, minscore=25)[:3]
+            a, b = one.search2(q, qr)[:2], sdb.search2(q, qr)[:2]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        else:
+            assert np.array_equal(one.search(q)[0], sdb.search(q)[0])
+            for keep, lo in ((100, 45), (7, 1)):
+                assert one.search_topk(q, keep, lo)[:3] == sdb.search_topk(q, keep, lo)[:3], (keep, lo)
+            q2 = np.ascontiguousarray(q[30:330])
+            x, y = one.search_pair_topk(q, q2, keep=(50, 20), minscore=(45, 40)), sdb.search_pair_topk(q, q2, keep=(50, 20), minscore=(45, 40))
+            assert x[0] == y[0] and x[1] == y[1]
+            hits = [h[0] for h in sdb.search_topk(q, 30, 45)[0]]
+            assert one.align(q, hits) == sdb.align(q, hits)
+    one.close()
+    sdb.close()
+
+
+@pytest.mark.late
 def test_group_wait_and_load_errors(tmp_path):
     """swa_group_open streams its shards in behind the call; swa_group_wait / swa_group_load_progress are how a caller
     waits for them and sees a load error (here: a residue code >= 32 in the second shard) before the first search"""

@@ -46,7 +46,8 @@ struct Kernel {
     uint64_t code_addr = 0;
     uint32_t lds = 0, scratch = 0, kernarg = 0, rsrc1 = 0, rsrc2 = 0, rsrc3 = 0, props = 0, preload = 0;
     std::vector<KArg> args;
-    std::vector<Inst> code;   // parsed lazily
+    std::vector<Inst> code;   // parsed lazily; device functions the kernel calls are appended when first called
+    std::unordered_map<uint64_t, int> at;       // instruction address -> index into code
     bool parsed = false;
     std::string sfile;
     // statistics (wave instructions)
@@ -58,6 +59,7 @@ struct Dim3 { uint32_t x, y, z; };
 // run one dispatch to completion; returns "" or the description of the fault that ended it
 std::string run_kernel(Kernel& k, Dim3 grid, Dim3 block, const uint8_t* kernarg, uint32_t dyn_lds);
 bool parse_kernel(Kernel& k, std::string& err);
+int parse_function_at(Kernel& k, uint64_t addr, std::string& err);   // index of the instruction at addr (parsing its function if needed), -1 on error
 
 // memory map of the stand-in runtime (every device access is checked against it)
 bool mem_ok(uint64_t addr, uint64_t n);

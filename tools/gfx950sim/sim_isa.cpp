@@ -338,16 +338,29 @@ static bool parse_line(const std::string& line, Inst& in, std::string& err) {
     return true;
 }
 
-bool parse_kernel(Kernel& k, std::string& err) {
-    if (k.parsed) return true;
+// one symbol's instructions appended to k.code; the symbol is named (want_name) or is the one that contains want_addr
+static bool parse_symbol(Kernel& k, const std::string& want_name, uint64_t want_addr, std::string& err) {
     init_tables();
     std::ifstream f(k.sfile);
     if (!f) { err = "cannot open " + k.sfile; return false; }
-    std::string want = " <" + k.name + ">:";
+    std::string want = " <" + want_name + ">:";
     std::string line;
     uint32_t ln = 0;
     bool in_k = false;
-    std::unordered_map<uint64_t, int> at;
+    const size_t first = k.code.size();
+    // by address: remember the last label at or below the address, then parse from there (second pass)
+    if (want_name.empty()) {
+        std::string best;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '\t' || !isxdigit((unsigned char)line[0]) || line.back() != ':') continue;
+            uint64_t a = strtoull(line.c_str(), nullptr, 16);
+            size_t lt = line.find('<');
+            if (lt == std::string::npos) continue;
+            if (a <= want_addr) best = line.substr(lt + 1, line.size() - lt - 3);
+        }
+        if (best.empty()) { err = "no symbol contains address " + std::to_string(want_addr); return false; }
+        return parse_symbol(k, best, 0, err);
+    }
     while (std::getline(f, line)) {
         ln++;
         if (!in_k) {
@@ -363,20 +376,54 @@ bool parse_kernel(Kernel& k, std::string& err) {
         Inst in;
         in.line = ln;
         std::string e;
-        if (!parse_line(line, in, e)) { err = k.name + ": co.s:" + std::to_string(ln) + ": " + e + " in '" + line + "'"; return false; }
-        at[in.addr] = (int)k.code.size();
+        if (!parse_line(line, in, e)) { err = want_name + ": co.s:" + std::to_string(ln) + ": " + e + " in '" + line + "'"; return false; }
+        k.at[in.addr] = (int)k.code.size();
         k.code.push_back(in);
     }
-    if (k.code.empty()) { err = "kernel " + k.name + " not found in " + k.sfile; return false; }
-    for (auto& in : k.code) {
-        if (in.cls != C_BRANCH) continue;
+    if (k.code.size() == first) { err = "symbol " + want_name + " not found in " + k.sfile; return false; }
+    for (size_t i = first; i < k.code.size(); i++) {
+        Inst& in = k.code[i];
+        if (in.cls != C_BRANCH || in.op == OP_s_swappc_b64 || in.op == OP_s_setpc_b64) continue;
         uint64_t tgt = in.addr + 4 + (int64_t)in.simm * 4;
-        auto it = at.find(tgt);
-        if (it == at.end()) { err = k.name + ": branch target outside the kernel"; return false; }
+        auto it = k.at.find(tgt);
+        if (it == k.at.end()) { err = want_name + ": branch target outside the symbol"; return false; }
         in.target = it->second;
+    }
+    return true;
+}
+
+bool parse_kernel(Kernel& k, std::string& err) {
+    if (k.parsed) return true;
+    if (!parse_symbol(k, k.name, 0, err)) return false;
+    // a kernel that calls: every other symbol of the code object is parsed NOW (launches are serialised; the workers of a
+    // launch only ever read k.code)
+    bool calls = false;
+    for (const Inst& in : k.code) calls |= in.op == OP_s_swappc_b64;
+    if (calls) {
+        std::vector<std::string> names;
+        std::ifstream f(k.sfile);
+        std::string line;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '\t' || !isxdigit((unsigned char)line[0]) || line.back() != ':') continue;
+            size_t lt = line.find('<');
+            if (lt == std::string::npos) continue;
+            uint64_t a = strtoull(line.c_str(), nullptr, 16);
+            if (!k.at.count(a)) names.push_back(line.substr(lt + 1, line.size() - lt - 3));
+        }
+        for (const std::string& n : names) {
+            std::string e;
+            (void)parse_symbol(k, n, 0, e);       // a symbol the interpreter cannot parse only matters if it is called
+        }
     }
     k.parsed = true;
     return true;
+}
+
+int parse_function_at(Kernel& k, uint64_t addr, std::string& err) {
+    auto it = k.at.find(addr);
+    if (it != k.at.end()) return it->second;
+    err = "no parsed instruction at that address (parse_kernel reads every symbol of a code object whose kernel calls)";
+    return -1;
 }
 
 // ------------------------------------------------------------------------------------------------ execution
@@ -1038,6 +1085,15 @@ static bool step(Ctx& c, Wave& w) {
         case OP_s_endpgm: w.state = 2; return false;
         case OP_s_barrier: w.state = 1; w.pc = next; return false;
         case OP_s_trap: throw Fault("s_trap " + std::to_string((long long)in.o[0].imm) + " (abort / failed assert in device code)");
+        case OP_s_getpc_b64: ws64(w, in.o[0], in.addr + 4); break;
+        case OP_s_swappc_b64: case OP_s_setpc_b64: {
+            const uint64_t tgt = rs64(w, in.o[in.op == OP_s_swappc_b64 ? 1 : 0]);
+            if (in.op == OP_s_swappc_b64) ws64(w, in.o[0], in.addr + 4);
+            std::string e;
+            next = parse_function_at(*c.k, tgt, e);
+            if (next < 0) throw Fault("call / return to 0x" + std::to_string(tgt) + ": " + e);
+            break;
+        }
         case OP_s_branch: next = in.target; break;
         case OP_s_cbranch_scc0: if (!w.scc) next = in.target; break;
         case OP_s_cbranch_scc1: if (w.scc) next = in.target; break;
@@ -1187,6 +1243,7 @@ static bool step(Ctx& c, Wave& w) {
 }
 
 static uint32_t g_poison = 0xBAD0BAD1u;
+static uint64_t g_trace = 0;           // HIPSIM_TRACE_INSN=n: the first n instructions of wave 0 of the first workgroup, to stderr
 static uint64_t g_switch = 0;          // > 0: waves of a workgroup take turns after this many instructions, in a seeded random order
 static uint64_t g_max_steps = 0;
 static int g_threads = 0;
@@ -1256,7 +1313,19 @@ static void run_workgroup(Worker& W, Kernel& k, Dim3 block, const uint8_t* kerna
             c.cur = (int)order[oi];
             uint64_t quantum = g_switch ? 1 + W.rng() % g_switch : UINT64_MAX;
             progressed = true;
-            while (quantum-- && step(c, w)) {
+            while (quantum--) {
+                if (g_trace && order[oi] == 0 && W.wgs == 1) {
+                    g_trace--;
+                    const Inst& ti = c.k->code[w.pc];
+                    fprintf(stderr, "T %u exec=%016llx vcc=%016llx scc=%d", ti.line, (unsigned long long)EXEC(w), (unsigned long long)VCC(w), (int)w.scc);
+                    for (int oi2 = 0; oi2 < ti.nops; oi2++) {
+                        const Opnd& o = ti.o[oi2];
+                        if (o.kind == K_SGPR) fprintf(stderr, " s%u=%x", o.reg, w.s[o.reg]);
+                        else if (o.kind == K_VGPR) fprintf(stderr, " v%u=[%x %x %x .. %x]", o.reg, w.v[o.reg][0], w.v[o.reg][1], w.v[o.reg][2], w.v[o.reg][63]);
+                    }
+                    fprintf(stderr, "\n");
+                }
+                if (!step(c, w)) break;
                 if (g_max_steps && ++c.steps > g_max_steps) throw Fault("HIPSIM_MAX_STEPS exceeded (a wave that never ends?)");
             }
             if (w.state == 2) done++;
@@ -1291,6 +1360,7 @@ std::string run_kernel(Kernel& k, Dim3 grid, Dim3 block, const uint8_t* kernarg,
         env = true;
         if (const char* e = getenv("HIPSIM_POISON")) g_poison = (uint32_t)strtoul(e, nullptr, 0);
         if (const char* e = getenv("HIPSIM_SWITCH")) g_switch = strtoull(e, nullptr, 0);
+        if (const char* e = getenv("HIPSIM_TRACE_INSN")) g_trace = strtoull(e, nullptr, 0);
         if (const char* e = getenv("HIPSIM_MAX_STEPS")) g_max_steps = strtoull(e, nullptr, 0);
         const char* f = getenv("HIPSIM_FAST");
         g_fast = (!f || atoi(f) != 0) && simfast::available();

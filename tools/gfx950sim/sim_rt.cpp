@@ -11,6 +11,8 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <chrono>
@@ -26,11 +28,25 @@
 
 namespace {
 
-std::recursive_mutex g_mu;
 using Lock = std::lock_guard<std::recursive_mutex>;
 
 struct Alloc { uint64_t size; void* raw; bool host; };
-std::map<uint64_t, Alloc> g_allocs;          // start -> allocation; the checked range is [start, start + size)
+struct FatBin;
+struct Registered { FatBin* fb; std::string name; };
+// Everything with a constructor lives in ONE object made on first use and never destroyed: a program that links
+// libswipe_amd.so directly (swipe_amd_cli) runs the library's fat-binary registration before this preloaded library's own
+// static initialisers, and may call in from atexit handlers after its destructors.
+struct State {
+    std::recursive_mutex mu;
+    std::map<uint64_t, Alloc> allocs;        // start -> allocation; the checked range is [start, start + size)
+    std::map<const void*, Registered> funcs;
+    std::string fault;                       // sticky
+};
+State& S() { static State* s = new State; return *s; }
+#define g_mu (S().mu)
+#define g_allocs (S().allocs)
+#define g_funcs (S().funcs)
+#define g_fault (S().fault)
 uint64_t g_allocated = 0;
 std::atomic<uint64_t> g_gen{1};                // bumped by every allocation / free: invalidates the per-thread range caches
 thread_local uint64_t t_lo = 1, t_hi = 0, t_gen = 0;    // last range that answered mem_ok
@@ -42,9 +58,6 @@ struct FatBin {
     bool loaded = false;
     std::map<std::string, sim::Kernel> kernels;
 };
-struct Registered { FatBin* fb; std::string name; };
-std::map<const void*, Registered> g_funcs;
-std::string g_fault;                          // sticky
 hipError_t g_last = hipSuccess;
 
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
@@ -142,6 +155,16 @@ void dump_stats() {
     fclose(f);
 }
 struct AtExit { ~AtExit() { dump_stats(); } } g_atexit;
+
+// HIPSIM_BACKTRACE=1: a SIGSEGV / SIGABRT of the host program prints its stack (the image has no debugger)
+void on_fatal(int sig) {
+    void* frames[64];
+    int n = backtrace(frames, 64);
+    fprintf(stderr, "gfx950sim: signal %d, backtrace:\n", sig);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(128 + sig);
+}
+struct Install { Install() { if (env_int("HIPSIM_BACKTRACE", 0)) { signal(SIGSEGV, on_fatal); signal(SIGABRT, on_fatal); signal(SIGBUS, on_fatal); } } } g_install;
 
 hipError_t fail(hipError_t e) { g_last = e; return e; }
 hipError_t sync_status() { return g_fault.empty() ? hipSuccess : fail(hipErrorLaunchFailure); }

@@ -1,5 +1,20 @@
 // EXPERIMENT, not part of the product: the re-queue drain inside the first-pass kernels as it stood when it was
 // abandoned - kept so that tools/ubench/drain_test.hip builds and shows the codegen-dependent results on gfx950.
+//
+// ROOT CAUSE (round 5, found with tools/gfx950sim: the wrong scores are deterministic, single-wave mode included - no race).
+// The claim loop of drain_list ends in a DIVERGENT branch - `if (lane == 0) scores[id] = best;` (or the lane-0 atomicAdd of
+// DRAIN_MARK) - whose join point is the loop latch, and the next iteration starts with `if (lane == 0) { claim }` followed by
+// the convergent readfirstlane.  hipcc threads the else side of the tail branch across the back-edge: on that path lane != 0
+// is known, so `mine` is the constant -1, readfirstlane(-1) folds to -1 and the lanes go to `return`.  In the ISA the tail's
+// lane-0 block executes `s_xor_b64 s[4:5], exec, -1` and the latch ORs s[4:5] into the set of lanes that left the loop: from
+// the SECOND claimed sequence on EXEC = 0x1 and the whole wave DP runs in lane 0 alone (scores of at most two matches).  This
+// is the hole in LLVM's convergence rules that its ConvergentOperations document describes (a convergent operation in a cycle
+// whose iterations are not anchored; the convergence-control tokens that close it are not what hipcc 7.2 emits) - not a
+// random miscompile, which is why it came and went with unrelated code (a printf or a call at the tail changes what can be
+// threaded).  The rule for every persistent "claim, broadcast, work" loop in this repository: NO divergent branch may join
+// at the latch - a uniform value is stored by every lane (-DSWA_DRAIN_FIXED below), or a convergent operation sits between
+// the tail branch and the back-edge (swa_requeue_wave_kernel's __syncthreads at the loop head has been doing that since
+// round 3, for the same reason, then unexplained).
 // One database sequence against the query by the 64 lanes of ONE wave, 32-bit arithmetic: the body of the alignment
 // phase's end-point kernel and of the re-queue (sw_util_kernels.hip), and - round 4 - of the re-queue DRAIN that every
 // single-launch first-pass kernel runs when its queue of batches is exhausted (see drain_requeue below).
@@ -226,7 +241,11 @@ __device__ __forceinline__ void drain_list(const swa_drain& d, unsigned char* ba
       seq_span(d.seqs, id, o, len64);
       int best, bcol, brow;
       endpoints_wave_one<KW, false, true>(M, ring, d.seqs, o, (int)len64, false, qseq, qlen, d.Q, d.R, nullptr, nullptr, best, bcol, brow);
-      if (lane == 0) scores[id] = best;
+#ifdef SWA_DRAIN_FIXED
+      scores[id] = best;                         // uniform value, stored by every lane: nothing diverges before the back-edge
+#else
+      if (lane == 0) scores[id] = best;          // the tail branch that gets threaded across the back-edge (see the file header)
+#endif
 #ifdef SWA_DRAIN_PRINT
       if (lane == 0 && id < 3) printf("id %d o %lld len %d qlen %d Q %d R %d M33 %d M34 %d ringoff %d q0 %d r0 %d best %d\n", id, (long long)o, (int)len64, qlen, d.Q, d.R, M[33], M[34], (int)(ring - base), (int)qseq[0], (int)seq_residue(d.seqs, o), best);
 #endif
