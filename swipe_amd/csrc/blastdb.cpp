@@ -401,39 +401,63 @@ int swa::plan_blast_load(const char* basename, int symtype, int64_t first_seqno,
   out = LoadPlan{};
   out.total_seqcount = bd.nseq;
   out.total_symcount = bd.nsym;
+  out.nucleotide = !bd.protein;
+  out.masked = bd.memb_bit != 0;
+  out.masked_seqcount = bd.masked_nseq;
+  out.masked_symcount = bd.masked_nsym;
   if (first_seqno < 0) first_seqno = 0;
   if (last_seqno < 0 || last_seqno >= bd.nseq) last_seqno = bd.nseq - 1;
   out.first_seqno = first_seqno;
-  if (!bd.protein || bd.memb_bit != 0 || last_seqno < first_seqno) return SWA_OK;        // regular stays false
+  if (last_seqno < first_seqno) return SWA_OK;                                              // regular stays false
   const int64_t n = last_seqno - first_seqno + 1;
   out.offsets.assign(size_t(n) + 1, 0);
-  int64_t vbase = 0, done = 0, residues = 0;
+  if (out.nucleotide) out.raw_seq.assign(size_t(n) + 1, 0);
+  if (out.masked) out.included.assign(size_t(n), 0);
+  int64_t vbase = 0, done = 0, residues = 0, raw = 0;
   for (const Volume& v : bd.vols) {
     const int64_t lo = first_seqno > vbase ? first_seqno - vbase : 0;
     const int64_t hi = last_seqno - vbase < v.nseq - 1 ? last_seqno - vbase : v.nseq - 1;    // inclusive
     vbase += v.nseq;
     if (hi < lo) continue;
     const int64_t cnt = hi - lo + 1;
+    const size_t vol = size_t(&v - bd.vols.data());
     const uint64_t o_lo = be32(v.seq_off + 4 * lo), o_hi = be32(v.seq_off + 4 * (hi + 1));
     if (o_hi > v.seq.n || o_hi < o_lo) return SWA_OK;                                      // read_blast_db reports it
-    // entry s = [o_s, o_{s+1}): at least its terminator; lengths o_{s+1} - o_s - 1.  A few threads over the index.
+    // protein: entry s = [o_s, o_{s+1}), at least its terminator; lengths o_{s+1} - o_s - 1, from the index alone.
+    // nucleotide: entry s = [o_s, o_{s+1}) = packed bases [o_s, a_s) + ambiguity data [a_s, o_{s+1}); the length wants the
+    // remainder count in the last packed byte (database.cc:1260-1261): one byte of the sequence file per sequence.
+    // A few threads over the index; lengths land in dst[i + 1], the running sum follows.
     const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, cnt >> 16}));
-    std::vector<int64_t> longest(size_t(nthreads), 0);
+    std::vector<int64_t> longest(size_t(nthreads), 0), longest_entry(size_t(nthreads), 0);
     std::vector<uint8_t> bad(size_t(nthreads), 0);
     int64_t* dst = out.offsets.data() + done;
+    int64_t* rdst = out.nucleotide ? out.raw_seq.data() + done : nullptr;
+    uint8_t* inc = out.masked ? out.included.data() + done : nullptr;
     auto walk = [&](int64_t t) {
       const int64_t a = cnt * t / nthreads, b = cnt * (t + 1) / nthreads;
       uint64_t prev = be32(v.seq_off + 4 * (lo + a));
-      int64_t lg = 0;
+      int64_t lg = 0, le = 0;
       bool wrong = false;
       for (int64_t i = a; i < b; ++i) {
         const uint64_t next = be32(v.seq_off + 4 * (lo + i + 1));
         wrong |= next <= prev;
-        lg = std::max<int64_t>(lg, int64_t(next - prev) - 1);
-        dst[i + 1] = residues + int64_t(next - o_lo) - (i + 1);       // prefix sum of (entry - 1)
+        int64_t len;
+        if (out.nucleotide) {
+          const uint64_t amb = be32(v.amb_off + 4 * (lo + i));
+          if (amb <= prev || amb > next || next > v.seq.n) { wrong = true; len = 0; }
+          else len = int64_t(4 * (amb - prev - 1) + (v.seq.p[amb - 1] & 3));
+          rdst[i] = raw + int64_t(prev - o_lo);
+          le = std::max<int64_t>(le, int64_t(next - prev));
+        } else {
+          len = int64_t(next - prev) - 1;
+        }
+        lg = std::max(lg, len);
+        dst[i + 1] = len;
+        if (inc) inc[i] = bd.in_mask(vol, lo + i) ? 1 : 0;
         prev = next;
       }
       longest[size_t(t)] = lg;
+      longest_entry[size_t(t)] = le;
       bad[size_t(t)] = wrong;
     };
     if (nthreads == 1) walk(0);
@@ -445,17 +469,20 @@ int swa::plan_blast_load(const char* basename, int symtype, int64_t first_seqno,
     for (int64_t t = 0; t < nthreads; ++t) {
       if (bad[size_t(t)]) return SWA_OK;                                                   // not back to back: the old reader decides
       out.longest = std::max(out.longest, longest[size_t(t)]);
+      out.longest_entry = std::max(out.longest_entry, longest_entry[size_t(t)]);
     }
+    for (int64_t i = 0; i < cnt; ++i) { residues += dst[i + 1]; dst[i + 1] = residues; }  // lengths -> prefix sums
     LoadPiece piece;
-    piece.path = v.base + ".psq";
+    piece.path = v.base + (bd.protein ? ".psq" : ".nsq");
     piece.file_begin = int64_t(o_lo);
     piece.file_end = int64_t(o_hi);
     piece.first = done;
     out.pieces.push_back(piece);
-    residues += int64_t(o_hi - o_lo) - cnt;
+    raw += int64_t(o_hi - o_lo);
     done += cnt;
   }
   if (done != n) return SWA_OK;
+  if (out.nucleotide) out.raw_seq[size_t(n)] = raw;
   out.regular = true;
   return SWA_OK;
 }

@@ -52,8 +52,9 @@ int read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_
 // What a pipelined open needs before the first residue is read (db_open + the index half of db_mapsequences,
 // database.cc:775-925, 1082-1131): the lengths of the sequences [first_seqno, last_seqno] out of the index files, and the
 // byte ranges of the sequence files that hold them.  `regular` says the loader may take the files as they lie: protein
-// volumes whose entries are [residues NUL] back to back, no OID mask.  Anything else (nucleotide volumes with their 2-bit
-// packing and ambiguity runs, masked aliases, an index whose entries overlap or run backwards) is left to read_blast_db.
+// volumes whose entries are [residues NUL] back to back, nucleotide volumes whose entries are [packed bases | ambiguity data]
+// back to back (round 5), with or without an OID mask.  An index whose entries overlap or run backwards is left to
+// read_blast_db, which reports it.
 struct LoadPiece {
   std::string path;                   // a .psq file
   int64_t file_begin = 0, file_end = 0;   // its bytes [file_begin, file_end): whole entries, each [residues NUL]
@@ -62,8 +63,17 @@ struct LoadPiece {
 struct LoadPlan {
   bool regular = false;
   std::vector<int64_t> offsets;       // nseq + 1 prefix sums of the lengths (offsets[0] = 0)
-  std::vector<LoadPiece> pieces;      // in sequence order: concatenated they are the range as [residues NUL]*
+  std::vector<LoadPiece> pieces;      // in sequence order: concatenated they are the range as [residues NUL]* (protein)
   int64_t first_seqno = 0, total_seqcount = 0, total_symcount = 0, longest = 0;
+  // nucleotide volumes: the pieces are .nsq ranges, whole entries [packed bases | ambiguity data]; raw_seq[s] = where entry s
+  // starts in the concatenation of the pieces (nseq + 1 values), longest_entry = bytes of the largest entry
+  bool nucleotide = false;
+  std::vector<int64_t> raw_seq;
+  int64_t longest_entry = 0;
+  // OID mask of a masked alias (database.cc:687-706): included[s] per sequence of the range, and the alias's own totals
+  bool masked = false;
+  std::vector<uint8_t> included;
+  int64_t masked_seqcount = 0, masked_symcount = 0;
 };
 int plan_blast_load(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, LoadPlan& out);
 // prefix sums of the sequence lengths of the whole database, from the index files alone (nseq + 1 entries)

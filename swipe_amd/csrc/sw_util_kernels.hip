@@ -412,6 +412,71 @@ swa_unterminate(const uint8_t* __restrict__ chunk, long long c0, long long c1, c
   }
   if (acc & ~0x1Fu) atomicOr(flags, acc);
 }
+// Pipelined open of NUCLEOTIDE volumes (database.cc:1237-1323 on the device).  A chunk holds WHOLE entries of the .nsq as the
+// file has them: sequence s occupies raw bytes [raw[s], raw[s + 1]) = packed bases, 4 per byte, first base in the two high
+// bits (the last packed byte carries the remainder count in its low 2 bits - the length is already known: offsets) followed
+// by its ambiguity data: a big-endian header word (bit 31: 8-byte entries) and runs (code, length, position) that overwrite
+// bases.  Output: the shard's 4-bit residue array (one-hot A=1 C=2 G=4 T=8, or the ambiguity code), residue i in byte i >> 1,
+// low nibble first, whatever sequence it belongs to.  One wave per sequence; a lane takes one output dword (8 bases).  The
+// first and the last dword of a sequence may be shared with its neighbours: those are OR-ed into the array, which the loader
+// zeroed; the dwords in between are stored.  Ambiguity runs follow behind a fence, nibble by nibble (AND out, OR in).
+extern "C" __global__ void __launch_bounds__(256)
+swa_unpack_nt(const uint8_t* __restrict__ chunk, long long c0, const int64_t* __restrict__ raw, const int64_t* __restrict__ offsets,
+              int s0, int n, uint8_t* __restrict__ residues)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = (int64_t)gridDim.x * 4;
+  unsigned* out = reinterpret_cast<unsigned*>(residues);
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += waves) {
+    const int64_t s = s0 + i;
+    const int64_t o = offsets[s], len = offsets[s + 1] - o;
+    const uint8_t* body = chunk + (raw[s] - c0);
+    if (len > 0) {
+      const int64_t d0 = o >> 3, d1 = (o + len - 1) >> 3;                 // output dwords [d0, d1]
+      for (int64_t d = d0 + lane; d <= d1; d += 64) {
+        unsigned w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t k = d * 8 + j - o;                                 // base of this sequence in nibble j of dword d
+          if (k >= 0 && k < len) w |= (1u << ((body[k >> 2] >> ((3 - (int)(k & 3)) << 1)) & 3)) << (4 * j);
+        }
+        if (d == d0 || d == d1) atomicOr(out + d, w);
+        else out[d] = w;
+      }
+    }
+    const int64_t packed = (len >> 2) + 1, abytes = raw[s + 1] - raw[s] - packed;
+    if (abytes >= 4) {
+      __threadfence();                                                     // the bases are in place before a run overwrites them
+      const uint8_t* a = body + packed;
+      const unsigned hdr = ((unsigned)a[0] << 24) | ((unsigned)a[1] << 16) | ((unsigned)a[2] << 8) | a[3];
+      const int esize = (hdr >> 31) ? 8 : 4;
+      const int64_t nent = (abytes - 4) / esize;
+      for (int64_t e = lane; e < nent; e += 64) {
+        const uint8_t* q = a + 4 + e * esize;
+        unsigned long long v = 0;
+        for (int b = 0; b < esize; ++b) v = (v << 8) | q[b];
+        unsigned code;
+        int64_t run, off;
+        if (esize == 8) { code = (unsigned)(v >> 60); run = (int64_t)((v >> 48) & 0xfff) + 1; off = (int64_t)(v & 0x0000fffffffffffULL); }
+        else { code = (unsigned)(v >> 28) & 15u; run = (int64_t)((v >> 24) & 0xf) + 1; off = (int64_t)(v & 0x00ffffff); }
+        for (int64_t r = 0; r < run && off + r < len; ++r) {
+          const int64_t g = o + off + r;
+          const int sh = 4 * (int)(g & 7);
+          atomicAnd(out + (g >> 3), ~(15u << sh));
+          atomicOr(out + (g >> 3), code << sh);
+        }
+      }
+    }
+  }
+}
+extern "C" hipError_t swa_launch_unpack_nt(const uint8_t* chunk, long long c0, const int64_t* raw, const int64_t* offsets, int s0, int n,
+                                           uint8_t* residues, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  const int blocks = (n + 3) / 4 < 16384 ? (n + 3) / 4 : 16384;
+  hipLaunchKernelGGL(swa_unpack_nt, dim3(blocks), dim3(256), 0, st, chunk, c0, raw, offsets, s0, n, residues);
+  return hipGetLastError();
+}
 extern "C" hipError_t swa_launch_unterminate(const uint8_t* chunk, long long c0, long long c1, const int64_t* offsets, int s0, int n,
                                              uint8_t* residues, unsigned* flags, hipStream_t st)
 {

@@ -72,6 +72,8 @@ hipError_t swa_launch_format(const swa_seqs* sq, const int32_t* slots, const swa
                              int nibbles, hipStream_t st);
 hipError_t swa_launch_unterminate(const uint8_t* chunk, long long c0, long long c1, const int64_t* offsets, int s0, int n,
                                   uint8_t* residues, unsigned* flags, hipStream_t st);
+hipError_t swa_launch_unpack_nt(const uint8_t* chunk, long long c0, const int64_t* raw, const int64_t* offsets, int s0, int n,
+                                uint8_t* residues, hipStream_t st);
 hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,
                              long long maxscore, int* cand_count, int cand_cap, swa_cand* cand,
                              unsigned long long* tallies, hipStream_t st);
@@ -404,6 +406,7 @@ int streamed_all_scores(swa_db* front, const uint8_t* query, int64_t qlen, int64
 int streamed_by_owner(swa_db* front, const int64_t* seqnos, int64_t n, const std::function<int(swa_db*, const std::vector<int64_t>&)>& fn);
 int settle_loading(swa_db* db, bool wait, bool* still, bool explicit_wait = false);
 void release_loader_leftovers(swa_db* db);
+int apply_inclusion(swa_db* db, const uint8_t* include, int64_t n);
 size_t loading_hbm(const swa_db* db);
 // entry points that want ONE resident shard: not for streamed handles; a shard that is still loading is waited for
 int loaded(swa_db* db)
@@ -1531,7 +1534,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   const int K = swa_narrow_rows_for(int(std::min<int64_t>(qlen, 4096)));     // tuned single-pass kernels: qlen <= 1024
   const bool force_mp = db->opt.force_mp == 1;
   const bool single_pass = qlen <= 16 * 58 && K > 0 && !force_mp;
-  if (loading && !(f16 && single_pass && db->opt.narrow_variant != 1)) {     // any other first pass wants the whole shard
+  if (loading && (db->packed || !(f16 && single_pass && db->opt.narrow_variant != 1))) {     // any other first pass (and a nucleotide shard's pair stream) wants the whole shard
     rc = settle_loading(db, true, nullptr);
     if (rc != SWA_OK) return rc;
     loading = false;
@@ -2244,6 +2247,12 @@ try {
   if (!db) return fail(SWA_EINVAL, "null database handle");
   if (db->streamed) return streamed_set_inclusion(db, include, n);     // a budgeted shard: per part (sw_streamed.inc)
   { const int src_ = loaded(db); if (src_ != SWA_OK) return src_; }
+  return apply_inclusion(db, include, n);
+} SWA_CATCH
+
+namespace {
+int apply_inclusion(swa_db* db, const uint8_t* include, int64_t n)
+{
   const int64_t real = db->nseq / db->frames;
   if (include && n != real) return fail(SWA_EINVAL, "inclusion array must have one entry per sequence of the shard");
   HIP_TRY(hipSetDevice(db->device));
@@ -2266,7 +2275,8 @@ try {
   db->view_of = nullptr;
   db->nwin = 0;
   return db->packed ? SWA_OK : ensure_main(db);
-} SWA_CATCH
+}
+}  // namespace
 
 extern "C" void swa_db_close(swa_db* db)
 {

@@ -240,6 +240,112 @@ def test_close_while_loading(volumes):
         db.close()                                        # stops and joins the loader; nothing hangs, nothing leaks a thread
 
 
+@pytest.fixture(scope="module")
+def nt_volumes(tmp_path_factory):
+    """30 000 synthetic nucleotide sequences in THREE volumes behind a .nal, ~4 % of them with runs of ambiguity codes (the
+    .nsq entries carry ambiguity tables behind the packed bases, database.cc:1284-1323), lengths of every residue mod 4"""
+    d = tmp_path_factory.mktemp("ntloading")
+    res, off = swipe_amd.synth_db(6, 30_000, protein=False)
+    res = res.copy()
+    rng = np.random.default_rng(3)
+    n = len(off) - 1
+    for s in rng.choice(n, 1200, replace=False):
+        L = int(off[s + 1] - off[s])
+        for _ in range(int(rng.integers(1, 4))):
+            if L < 8:
+                break
+            a = int(rng.integers(0, L - 4))
+            k = int(rng.integers(1, min(40, L - a)))
+            res[off[s] + a: off[s] + a + k] = int(rng.choice([15, 5, 10, 3, 12, 7, 14]))
+    seqs = [res[off[i]:off[i + 1]] for i in range(n)]
+    base = str(d / "nt3")
+    blastdb.write_db(base, seqs, protein=False, volumes=3)
+    q = synth._random_residues(21, 1, 220, synth.residue_table_nucleotide())
+    Mo = oracle.matrix_nucleotide(1, -3)
+    cpus = os.cpu_count() or 1
+    ref = (oracle.search_all63(res, off, q, Mo, 7, 2, threads=cpus), oracle.search_all63(res, off, blastdb.revcomp_nt16(q), Mo, 7, 2, threads=cpus))
+    return {"base": base, "res": res, "off": off, "q": q, "ref": ref}
+
+
+NT_SLOW = dict(SWA_LOAD_PART=1 << 20, SWA_LOAD_CHUNK=1 << 19, SWA_LOAD_DELAY_MS=15)
+
+
+@pytest.mark.late
+def test_nucleotide_volumes_stream_in(nt_volumes):
+    """nucleotide volumes take the pipelined open too - the .nsq as it lies (whole entries per chunk), 2-bit
+    -> one-hot nibbles and the ambiguity runs on the device, 4-bit one-sequence-per-row parts merged into the set both-strand
+    searches stream.  Residues, both-strand scores and hit lists equal the old reader's and the oracle's."""
+    v = nt_volumes
+    q, qr = v["q"], blastdb.revcomp_nt16(v["q"])
+    M = swipe_amd.matrix_nucleotide(1, -3)
+    with _Env(SWA_PIPELINED=0):
+        old = swipe_amd.Database.open(v["base"], symtype=0)
+    with _Env(**NT_SLOW):
+        new = swipe_amd.Database.open(v["base"], symtype=0, wait=False)
+    try:
+        p = new.load_progress()
+        assert p["parts_total"] >= 3 and p["parts_ready"] < p["parts_total"], p
+        for d in (old, new):
+            d.set_scoring(M, 5, 2)
+        # every residue of a sample of sequences, ambiguity runs included (before anything else forces the load to end)
+        s1, s2, c = new.search2(q, qr)
+        assert np.array_equal(s1, v["ref"][0]) and np.array_equal(s2, v["ref"][1])
+        new.wait()
+        rng = np.random.default_rng(9)
+        for s in list(rng.choice(len(v["off"]) - 1, 300, replace=False)) + [0, len(v["off"]) - 2]:
+            want = v["res"][v["off"][s]:v["off"][s + 1]]
+            assert np.array_equal(new.sequence(int(s)), want), s
+            assert np.array_equal(old.sequence(int(s)), want), s
+        assert new.info()["symcount"] == old.info()["symcount"] == int(v["off"][-1])
+        a, b = old.search2_topk(q, qr, keep=80, minscore=22), new.search2_topk(q, qr, keep=80, minscore=22)
+        assert a[:3] == b[:3]
+        o1, o2, _ = old.search2(q, qr)
+        assert np.array_equal(o1, s1) and np.array_equal(o2, s2)
+        # a single-strand search (pair stream built on demand) and end points on the streamed-in shard
+        assert np.array_equal(new.search(q)[0], v["ref"][0])
+    finally:
+        old.close()
+        new.close()
+
+
+@pytest.mark.late
+@pytest.mark.parametrize("early", [True, False])
+def test_masked_alias_streams_in(volumes, tmp_path, early):
+    """an OID-mask alias through the pipelined open: a search that follows the loader marks the excluded sequences, the
+    adopted tables hold the members only; hit lists, counts and the statistics' totals are the old reader's"""
+    n = 60_000
+    inc = (np.arange(n) * 7919 % 10) < 4
+    length = int(sum(int(volumes["off"][i + 1] - volumes["off"][i]) for i in np.nonzero(inc)[0]))
+    alias = str(tmp_path / "msk")
+    for ext in ("pin", "psq", "phr"):
+        os.symlink(volumes["one"] + "." + ext, str(tmp_path / ("one." + ext)))
+    blastdb.write_mask_alias(alias, str(tmp_path / "one"), inc, memb_bit=1, length=length)
+    ref = np.where(inc, volumes["ref"], -1)
+    want_hits, want_tot = _expected_topk(ref, 100, 60)
+    with _Env(SWA_PIPELINED=0):
+        old = swipe_amd.Database.open(alias)
+    with _Env(**SLOW):
+        new = swipe_amd.Database.open(alias, wait=False)
+    try:
+        for d in (old, new):
+            d.set_scoring(_matrix(), 11, 1)
+        if not early:
+            new.wait()
+        hits, tot, obv, c = new.search_topk(Q, keep=100, minscore=60)
+        assert (c["loading_parts"] > 0) == early
+        assert (hits, tot) == (want_hits, want_tot)
+        assert old.search_topk(Q, keep=100, minscore=60)[:2] == (want_hits, want_tot)
+        new.wait()
+        io, inw = old.info(), new.info()
+        assert all(io[k] == inw[k] for k in ("seqcount", "symcount", "total_seqcount", "total_symcount")) and inw["total_seqcount"] == int(inc.sum())
+        sc, c2 = new.search(Q)
+        assert c2["loading_parts"] == 0 and np.array_equal(np.where(inc, sc, -1), ref) and c2["cells"] == length * len(Q)
+        assert new.search_topk(Q, keep=100, minscore=60)[:2] == (want_hits, want_tot)
+    finally:
+        old.close()
+        new.close()
+
+
 _REDZONE_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, %r)

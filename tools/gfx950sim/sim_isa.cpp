@@ -1113,6 +1113,13 @@ static bool step(Ctx& c, Wave& w) {
         case OP_s_bcnt1_i32_b32: { uint32_t r = (uint32_t)__builtin_popcount(rs32(w, in.o[1])); ws32(w, in.o[0], r); w.scc = r != 0; break; }
         case OP_s_ff1_i32_b64: { uint64_t x = rs64(w, in.o[1]); ws32(w, in.o[0], x ? (uint32_t)__builtin_ctzll(x) : 0xffffffffu); break; }
         case OP_s_ff1_i32_b32: { uint32_t x = rs32(w, in.o[1]); ws32(w, in.o[0], x ? (uint32_t)__builtin_ctz(x) : 0xffffffffu); break; }
+        case OP_s_brev_b32: { uint32_t a = rs32(w, in.o[1]), r = 0; for (int i = 0; i < 32; i++) if (a & (1u << i)) r |= 1u << (31 - i); ws32(w, in.o[0], r); break; }
+        case OP_s_brev_b64: { uint64_t a = rs64(w, in.o[1]), r = 0; for (int i = 0; i < 64; i++) if (a & (1ull << i)) r |= 1ull << (63 - i); ws64(w, in.o[0], r); break; }
+        case OP_s_flbit_i32_b32: { uint32_t a = rs32(w, in.o[1]); ws32(w, in.o[0], a ? (uint32_t)__builtin_clz(a) : 0xffffffffu); break; }
+        case OP_s_flbit_i32_b64: { uint64_t a = rs64(w, in.o[1]); ws32(w, in.o[0], a ? (uint32_t)__builtin_clzll(a) : 0xffffffffu); break; }
+        case OP_s_ff0_i32_b32: { uint32_t a = ~rs32(w, in.o[1]); ws32(w, in.o[0], a ? (uint32_t)__builtin_ctz(a) : 0xffffffffu); break; }
+        case OP_s_bitset1_b32: ws32(w, in.o[0], w.s[in.o[0].reg] | (1u << (rs32(w, in.o[1]) & 31))); break;
+        case OP_s_bitset0_b32: ws32(w, in.o[0], w.s[in.o[0].reg] & ~(1u << (rs32(w, in.o[1]) & 31))); break;
         case OP_s_sext_i32_i16: ws32(w, in.o[0], (uint32_t)(int32_t)(int16_t)rs32(w, in.o[1])); break;
         case OP_s_sext_i32_i8: ws32(w, in.o[0], (uint32_t)(int32_t)(int8_t)rs32(w, in.o[1])); break;
         case OP_s_abs_i32: { int32_t x = (int32_t)rs32(w, in.o[1]); uint32_t r = x < 0 ? (uint32_t)-(int64_t)x : (uint32_t)x; ws32(w, in.o[0], r); w.scc = r != 0; break; }
