@@ -1750,7 +1750,11 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   const int64_t qa = qlen_a ? qlen_a : qlen, qb = qlen_b ? qlen_b : qlen;      // rows of query 1 / 2; qlen = the longer
   int rc = check_query(db, q1, qa);
   if (rc == SWA_OK) rc = check_query(db, q2, qb);
-  if (rc == SWA_OK) rc = settle_loading(db, true, nullptr);         // the two-query kernels want the whole shard
+  // a shard that is still loading (sw_loading.inc): the single-pass two-query builds go part by part when the parts are in the
+  // layout they stream - the 4-bit one-sequence-per-row parts of a nucleotide shard under 16-lane chains (the reference's
+  // both-strand search, swipe.cc:1403), the pair-stream parts of a protein shard under chains of 2 / 4 / 8 lanes
+  bool loading = false;
+  if (rc == SWA_OK) rc = settle_loading(db, false, &loading);
   if (rc != SWA_OK) return rc;
   HIP_TRY(hipSetDevice(db->device));
   hipStream_t st = db->stream;
@@ -1761,7 +1765,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (bound_min > 0) db->cur_qhash = swa_db::hash_query(q1, qa, q2, qb);
   rc = ensure_pin(db, PIN_CTL_BYTES + 32 + 8192);
   if (rc != SWA_OK) return rc;
-  if (qlen == 0 || db->h_order.empty()) return finish_empty(db, pd, true, st);
+  if (qlen == 0 || (db->h_order.empty() && !loading)) return finish_empty(db, pd, true, st);
   HIP_TRY(hipEventRecord(db->ev[0], st));
   rc = upload_queries(db, q1, q2, qlen, st, qlen_a, qlen_b);
   if (rc != SWA_OK) return rc;
@@ -1795,23 +1799,42 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   env.want_bound = bound_wanted(db, qlen, bound_min);
   env.hi = db->hi; env.goe = db->goe; env.ge = db->ge;
   env.longest = db->longest;
-  env.mean_len = db->h_order.empty() ? 325.0 : double(db->active_sym) / double(db->h_order.size());
+  env.mean_len = loading ? double(db->active_sym) / double(std::max<int64_t>(1, db->nseq))
+                         : db->h_order.empty() ? 325.0 : double(db->active_sym) / double(db->h_order.size());
   env.lanes = int(db->opt.lanes);
   env.long_lanes = db->opt.long_lanes != 0;
   env.bound_period = Nb;
   const swa::KernelPick pick = dual_mp ? swa::KernelPick{} : swa::pick_dual(env, nres, int(db->opt.dual_kmax));
   const int Gd = pick.G ? pick.G : 16, Kd = pick.K;
+  if (loading) {
+    const bool part_ok = f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024 &&
+                         (db->loading->nt ? (Gd == 16 && nib) : Gd < 16);
+    if (!part_ok) {                                        // any other build wants a set the parts are not: wait for the shard
+      rc = settle_loading(db, true, nullptr);
+      if (rc != SWA_OK) return rc;
+      loading = false;
+    }
+  }
+  Loading* const LD = loading ? db->loading.get() : nullptr;
   if (f16_applicable(db) && Kd > 0 && f16_limit(db, Kd) >= 1024) {
-    rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
-    if (rc != SWA_OK) return rc;
-    const BatchSet& whole = Gd < 16 ? db->main : nib ? db->single4 : db->single;
-    rc = prepare_view(db, whole, Gd < 16 ? 2 : 1, qlen, &bsp, slots_per_cu(Gd, Kd, pick.bound, 1));
-    if (rc == SWA_OK) rc = reserve2(bsp != &whole);
-    if (rc != SWA_OK) return rc;
-    const BatchSet& set = *bsp;
-    windows = bsp != &whole;
+    static const BatchSet no_set{};
+    const BatchSet* setp = &no_set;
+    if (!loading) {
+      rc = Gd < 16 ? ensure_main(db) : nib ? ensure_single4(db) : ensure_single(db);
+      if (rc != SWA_OK) return rc;
+      const BatchSet& whole = Gd < 16 ? db->main : nib ? db->single4 : db->single;
+      rc = prepare_view(db, whole, Gd < 16 ? 2 : 1, qlen, &bsp, slots_per_cu(Gd, Kd, pick.bound, 1));
+      if (rc == SWA_OK) rc = reserve2(bsp != &whole);
+      if (rc != SWA_OK) return rc;
+      setp = bsp;
+      windows = bsp != &whole;
+    } else {
+      rc = reserve2(false);                                // (the parts of a loading shard are searched as they are: no windows)
+      if (rc != SWA_OK) return rc;
+    }
+    const BatchSet& set = *setp;
     swa_mp_params p{};
-    p.nibbles = set.nibbles ? 1 : 0;
+    p.nibbles = loading ? (LD->nt ? 1 : 0) : (set.nibbles ? 1 : 0);
     p.qlen_a = int32_t(qlen_a);
     p.qlen_b = int32_t(qlen_b);
     p.qseq = db->qseq_p;
@@ -1842,11 +1865,42 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     if (used_bound) {
       p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
       for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
-      HIP_TRY(swa_launch_dual_bound(Gd, Kd, &p, db->cus, st));
-    } else if (Gd == 1) {
-      HIP_TRY(swa_launch_dual_one(Kd, nres, &p, db->cus, st));
+    }
+    auto launch_first2 = [&](const swa_mp_params& q, hipStream_t s) -> hipError_t {
+      if (used_bound) return swa_launch_dual_bound(Gd, Kd, &q, db->cus, s);
+      if (Gd == 1) return swa_launch_dual_one(Kd, nres, &q, db->cus, s);
+      return swa_launch_dual(Kd, nres, Gd, &q, db->cus, s);
+    };
+    if (loading) {
+      // part by part as the loader publishes them, exactly as run_search does: a queue head per launch, the launches
+      // alternating between the handle's two streams, every part writing the two score arrays and the two re-queue lists
+      const int P = int(LD->parts.size());
+      HIP_TRY(hipMemsetAsync(LD->heads.p, 0, size_t(P) * sizeof(int32_t), st));
+      HIP_TRY(hipEventRecord(db->ev2[0], st));
+      HIP_TRY(hipStreamWaitEvent(db->stream2, db->ev2[0], 0));
+      for (int i = 0; i < P; ++i) {
+        rc = wait_part(LD, i);
+        if (rc != SWA_OK) return rc;
+        const LoadPart& part = LD->parts[size_t(i)];
+        hipStream_t ps = (i & 1) ? db->stream2 : st;
+        HIP_TRY(hipStreamWaitEvent(ps, part.ready, 0));
+        swa_mp_params q = p;
+        q.stream = LD->arena.p;
+        q.batches = LD->pbatches.p + part.batch_base;
+        q.slots = LD->pslots.p + size_t(part.batch_base) * SWA_SLOTS;
+        q.nbatches = int32_t(part.plan.batches.size());
+        q.counter = LD->heads.p + i;
+        if (q.nbatches == 0) continue;
+        HIP_TRY(launch_first2(q, ps));
+      }
+      if (P > 1) {
+        HIP_TRY(hipEventRecord(db->ev2[1], db->stream2));
+        HIP_TRY(hipStreamWaitEvent(st, db->ev2[1], 0));
+      }
+      c.loading_parts = P;
+      if (!LD->nt) HIP_TRY(hipMemcpyAsync(db->ctl.p + CTL_LOADFLAGS, LD->flags.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     } else {
-      HIP_TRY(swa_launch_dual(Kd, nres, Gd, &p, db->cus, st));
+      HIP_TRY(launch_first2(p, st));
     }
     c.narrow_rows = Kd;
     c.narrow_shifted = used_bound ? 10 : Gd == 1 ? 12 : 4;   // single-pass dual kernel / its bound build / one lane per sequence
@@ -2543,7 +2597,7 @@ try {
 extern "C" int swa_search2(swa_db* db, const uint8_t* query1, const uint8_t* query2, int64_t qlen,
                            int64_t* scores1, int64_t* scores2, swa_counters_t* counters)
 try {
-  { const int src_ = loaded(db); if (src_ != SWA_OK) return src_; }
+  if (!db) return fail(SWA_EINVAL, "null database handle");
   if (!query2 && qlen > 0) return fail(SWA_EINVAL, "bad query");
   if (db && db->streamed) {
     int rc0 = check_query(db, query1, qlen);

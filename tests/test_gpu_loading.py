@@ -242,14 +242,14 @@ def test_close_while_loading(volumes):
 
 @pytest.fixture(scope="module")
 def nt_volumes(tmp_path_factory):
-    """30 000 synthetic nucleotide sequences in THREE volumes behind a .nal, ~4 % of them with runs of ambiguity codes (the
+    """12 000 synthetic nucleotide sequences in THREE volumes behind a .nal, ~4 % of them with runs of ambiguity codes (the
     .nsq entries carry ambiguity tables behind the packed bases, database.cc:1284-1323), lengths of every residue mod 4"""
     d = tmp_path_factory.mktemp("ntloading")
-    res, off = swipe_amd.synth_db(6, 30_000, protein=False)
+    res, off = swipe_amd.synth_db(6, 12_000, protein=False)
     res = res.copy()
     rng = np.random.default_rng(3)
     n = len(off) - 1
-    for s in rng.choice(n, 1200, replace=False):
+    for s in rng.choice(n, 500, replace=False):
         L = int(off[s + 1] - off[s])
         for _ in range(int(rng.integers(1, 4))):
             if L < 8:
@@ -260,14 +260,14 @@ def nt_volumes(tmp_path_factory):
     seqs = [res[off[i]:off[i + 1]] for i in range(n)]
     base = str(d / "nt3")
     blastdb.write_db(base, seqs, protein=False, volumes=3)
-    q = synth._random_residues(21, 1, 220, synth.residue_table_nucleotide())
+    q = synth._random_residues(21, 1, 1000, synth.residue_table_nucleotide())      # BASELINE config 4's shape: 16 lanes x 63 rows
     Mo = oracle.matrix_nucleotide(1, -3)
     cpus = os.cpu_count() or 1
     ref = (oracle.search_all63(res, off, q, Mo, 7, 2, threads=cpus), oracle.search_all63(res, off, blastdb.revcomp_nt16(q), Mo, 7, 2, threads=cpus))
     return {"base": base, "res": res, "off": off, "q": q, "ref": ref}
 
 
-NT_SLOW = dict(SWA_LOAD_PART=1 << 20, SWA_LOAD_CHUNK=1 << 19, SWA_LOAD_DELAY_MS=15)
+NT_SLOW = dict(SWA_LOAD_PART=1 << 18, SWA_LOAD_CHUNK=1 << 17, SWA_LOAD_DELAY_MS=15)
 
 
 @pytest.mark.late
@@ -289,6 +289,7 @@ def test_nucleotide_volumes_stream_in(nt_volumes):
             d.set_scoring(M, 5, 2)
         # every residue of a sample of sequences, ambiguity runs included (before anything else forces the load to end)
         s1, s2, c = new.search2(q, qr)
+        assert c["loading_parts"] >= 3, c                     # both strands in one pass, part by part behind the loader
         assert np.array_equal(s1, v["ref"][0]) and np.array_equal(s2, v["ref"][1])
         new.wait()
         rng = np.random.default_rng(9)
@@ -301,11 +302,50 @@ def test_nucleotide_volumes_stream_in(nt_volumes):
         assert a[:3] == b[:3]
         o1, o2, _ = old.search2(q, qr)
         assert np.array_equal(o1, s1) and np.array_equal(o2, s2)
-        # a single-strand search (pair stream built on demand) and end points on the streamed-in shard
+        # a short query takes chains of fewer than 16 lanes, which stream the pair format (built on demand): same answers
+        qs = np.ascontiguousarray(q[:200])
+        x, y = old.search2_topk(qs, blastdb.revcomp_nt16(qs), keep=40, minscore=18), new.search2_topk(qs, blastdb.revcomp_nt16(qs), keep=40, minscore=18)
+        assert x[:3] == y[:3]
+        # a single-strand search on the streamed-in shard
         assert np.array_equal(new.search(q)[0], v["ref"][0])
     finally:
         old.close()
         new.close()
+
+
+@pytest.mark.late
+def test_two_queries_per_pass_on_a_loading_protein_shard(volumes):
+    """swa_search_pair_topk / swa_search2 follow the loader too (chains of 2 / 4 / 8 lanes stream the parts' pair format); the
+    16-lane two-query builds (long queries) wait for the shard"""
+    res, off = volumes["res"], volumes["off"]
+    qa, qb = np.ascontiguousarray(Q[:230]), np.ascontiguousarray(Q[60:270])          # 8 lanes x 29 rows: the parts' own format
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    cpus = os.cpu_count() or 1
+    refa, refb = oracle.search_all63(res, off, qa, Mo, 12, 1, threads=cpus), oracle.search_all63(res, off, qb, Mo, 12, 1, threads=cpus)
+    with _Env(**SLOW):
+        db = swipe_amd.Database.open(volumes["one"], wait=False)
+    try:
+        db.set_scoring(_matrix(), 11, 1)
+        a, b, c = db.search_pair_topk(qa, qb, keep=(100, 60), minscore=(50, 45))
+        assert c["loading_parts"] >= 8, c
+        assert a[:2] == _expected_topk(refa, 100, 50) and b[:2] == _expected_topk(refb, 60, 45)
+        db.wait()
+        a2, b2, c2 = db.search_pair_topk(qa, qb, keep=(100, 60), minscore=(50, 45))
+        assert c2["loading_parts"] == 0 and a2[:2] == a[:2] and b2[:2] == b[:2]
+    finally:
+        db.close()
+    with _Env(**SLOW):
+        db = swipe_amd.Database.open(volumes["one"], wait=False)
+    try:
+        db.set_scoring(_matrix(), 11, 1)
+        s1, s2, c = db.search2(qa, np.ascontiguousarray(Q[100:330]))
+        assert c["loading_parts"] >= 8, c
+        assert np.array_equal(s1, refa) and np.array_equal(s2, oracle.search_all63(res, off, Q[100:330], Mo, 12, 1, threads=cpus))
+        # a pair of 375-row queries takes 16-lane chains (one sequence per row): not what the parts hold - it waits, same answers
+        a3 = db.search_pair_topk(Q, Q[::-1].copy(), keep=(50, 50), minscore=(60, 60))
+        assert a3[0][:2] == _expected_topk(volumes["ref"], 50, 60)
+    finally:
+        db.close()
 
 
 @pytest.mark.late
