@@ -381,6 +381,49 @@ def group_section(res, off, device, q, minscore, maxscore, want_sha1, steps=3):
     return out
 
 
+def nucleotide_cold_open(res, off, device, q, qm, minscore, nslice=5_000_000):
+    """disk -> HBM for nucleotide volumes (round 5: the pipelined open takes the .nsq as it lies - 2 bits per base, ambiguity
+    tables - and unpacks on the device): the first `nslice` sequences of the section's database written as a BLAST v4 volume,
+    swa_db_open warm, then swa_db_open_async + the first both-strand top-K search FOLLOWING the loader; its hit list must be the
+    resident handle's.  A slice, so that the default run stays inside its minutes; rates are per GB of .nsq."""
+    import swipe_amd
+    n = min(nslice, len(off) - 1)
+    d = tempfile.mkdtemp(prefix="swa_ntcold_")
+    try:
+        base = os.path.join(d, "nt")
+        t0 = time.time()
+        swipe_amd.write_blastdb(base, res, off[: n + 1], symtype=0, first_id=0)
+        t_write = time.time() - t0
+        gb = os.path.getsize(base + ".nsq") / 1e9
+        M = swipe_amd.matrix_nucleotide(1, -3)
+        t0 = time.time()
+        db = swipe_amd.Database.open(base, symtype=0, device=device)
+        warm = time.time() - t0
+        db.set_scoring(M, 5, 2)
+        want = db.search2_topk(q, qm, keep=KEEP, minscore=minscore)[:3]
+        db.close()
+        t0 = time.time()
+        db = swipe_amd.Database.open(base, symtype=0, device=device, wait=False)
+        t_ret = time.time() - t0
+        db.set_scoring(M, 5, 2)
+        hits, tot, obv, c = db.search2_topk(q, qm, keep=KEEP, minscore=minscore)
+        first_hits = time.time() - t0
+        db.wait()
+        resident = time.time() - t0
+        db.close()
+        if (hits, tot, obv) != want:
+            raise SystemExit("bench (nucleotide): the search that followed the loader disagrees with the resident shard's hit list")
+        return {"sequences": int(n), "bases": int(off[n] - off[0]), "nsq_gb": round(gb, 3), "write_s": round(t_write, 2),
+                "open_s": round(warm, 3), "warm_gb_per_s": round(gb / warm, 2), "async_open_returns_s": round(t_ret, 3),
+                "first_hits_s": round(first_hits, 3), "resident_s": round(resident, 3), "first_search_parts": int(c["loading_parts"]),
+                "what": "swa_db_open of a .nsq volume (2 bits per base) from the box's local disk, warm page cache: lengths out of the "
+                        "index + one byte per entry on 16 threads | reader threads -> page-locked ring -> copy engine -> swa_unpack_nt per "
+                        "chunk -> 4-bit parts; first_hits_s = swa_db_open_async + swa_set_scoring + the first both-strand top-250 search "
+                        "following the loader part by part (hit list identical to the resident handle's)"}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+
+
 def nucleotide_section(a, rank, local, world, nseq, steps, want_cpu):
     """BASELINE.json configs[3]: 1 kb DNA query vs a synthetic nucleotide db, +1/-3, gap 5+2, both strands in one pass of
     the two-query kernel (plus strand | reverse complement in the two halves of the packed lanes).  Single shard."""
@@ -453,6 +496,11 @@ def nucleotide_section(a, rank, local, world, nseq, steps, want_cpu):
         if bad:
             raise SystemExit(f"bench (nucleotide): {bad} mismatches against the oracle")
         out["verified_vs_oracle"] = int(len(pick))
+    if not a.no_cold:
+        try:
+            out["cold_open"] = nucleotide_cold_open(res, off, local, q, qm, st.scorethreshold)
+        except Exception as e:
+            out["cold_open"] = {"open_s": None, "what": f"failed: {e}"}
     if want_cpu:
         try:
             qtext = "".join("-ACMGRSVTWYHKDBN"[int(x)] for x in q)
