@@ -230,6 +230,16 @@ swa_endpoints_kernel(swa_seqs sq, const int32_t* __restrict__ ids, const uint8_t
 // POS = false: the score only (re-queue use) - no position bookkeeping in the inner loop
 // one sequence [o, o + len) against the query, by the 64 lanes of the calling wave (a block of its own: M and ring are
 // its LDS); returns the wave-wide best / first column / smallest row in every lane
+// x of lane g - 1 in lane g of a wave64, 0 in lane 0: row_bcast:15 gives the lanes of rows 1..3 lane 15 of the row before
+// (row 0 keeps the 0), row_shr:1 then overwrites every lane that has a left neighbour in its own row of 16 and leaves the
+// four row heads alone (bound_ctrl off: an invalid source lane keeps what is there).  Both controls are what rocPRIM's
+// warp scans use on every non-Navi target.
+__device__ __forceinline__ int lane_up1(int x)
+{
+  const int heads = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xe, 0xf, false);
+  return __builtin_amdgcn_update_dpp(heads, x, 0x111, 0xf, 0xf, false);
+}
+
 template <int K, bool POS>
 __device__ __forceinline__ void endpoints_wave_one(const int* M, uint8_t* ring, const swa_seqs& sq, int64_t o,
                                                    int len, bool rc, const uint8_t* __restrict__ qseq, int qlen, int Q, int R,
@@ -302,8 +312,10 @@ __device__ __forceinline__ void endpoints_wave_one(const int* M, uint8_t* ring, 
           __hip_atomic_store(mybf + c, fout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      const int hnext = __shfl_up(hout, 1), fnext = __shfl_up(fout, 1);
-      if (g > 0) { hin = hnext; fin = fnext; }
+      // lane g - 1's last row to lane g: two DPP moves each instead of a ds_bpermute through the LDS crossbar (whose round
+      // trip was a third of a step for the one wave that works on a sequence - the re-queue's tail)
+      hin = lane_up1(hout);
+      fin = lane_up1(fout);
     }
     if (pbest > best || (pbest == best && pbest > 0 && (pcol < bcol || (pcol == bcol && prow < brow)))) {
       best = pbest; bcol = pcol; brow = prow;
@@ -377,6 +389,98 @@ swa_requeue_wave_kernel(swa_seqs sq, const int32_t* __restrict__ list, const int
     int best, bcol, brow;
     endpoints_wave_one<K, false>(M, ring, sq, o, len, false, qseq, qlen, Q, R, nullptr, nullptr, best, bcol, brow);
     if (g == 0) scores[id] = best;
+  }
+}
+
+// The same list, one BLOCK of four waves per sequence (round 5: the re-queue's tail).  What a search waits for at the end is the
+// longest re-queued sequence on the ONE wave that works on it: steps x (rows per lane x the dependent chain of a cell).  Four
+// waves on the sequence make the systolic array 256 lanes long - K = ceil(qlen / 256) rows per lane instead of ceil(qlen / 64):
+// 2 instead of 6 for the 375-row bench query - at the price of one block barrier per step and 192 more steps of skew.  Lane
+// g - 1 hands its last row to lane g by DPP inside a wave and through a double-buffered LDS word pair across the three wave
+// boundaries (written before the step's barrier, read after it).  Same arithmetic, same queue head, same list as the wave
+// kernel; no kernel waits for another, nothing spins.  Score only (the alignment phase keeps the wave kernel).
+template <int K>
+__global__ void __launch_bounds__(256)
+swa_requeue_block_kernel(swa_seqs sq, const int32_t* __restrict__ list, const int32_t* __restrict__ count, int cap, int32_t* __restrict__ work,
+                         const uint8_t* __restrict__ qseq, int qlen, const int32_t* __restrict__ matrix, int Q, int R,
+                         int* __restrict__ scores)
+{
+  __shared__ int M[1024];
+  __shared__ uint8_t ring[512];
+  __shared__ int bnd[2][4][2];
+  __shared__ int wbest[4];
+  __shared__ int next;
+  const int g = threadIdx.x, lane = g & 63, wave = g >> 6;
+  int n = *count;
+  if (n > cap) n = cap;
+  if (n <= 0) return;
+  for (int i = g; i < 1024; i += 256) M[i] = matrix[i];
+  int qs[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int r = g * K + k;
+    qs[k] = r < qlen ? (int)qseq[r] : -1;
+  }
+  for (;;) {
+    // (the barrier at the head is also what keeps the lanes together from one entry to the next: see swa_requeue_wave_kernel)
+    __syncthreads();
+    if (g == 0) next = atomicAdd(work, 1);
+    __syncthreads();
+    const int w = next;
+    if (w >= n) break;
+    const int id = list[w];
+    int64_t o, len64;
+    seq_span(sq, id, o, len64);
+    const int len = (int)len64;
+    auto residue = [&](int c) -> u32 { return c < len ? seq_residue(sq, o + c) : 0u; };
+    int hp[K], ee[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { hp[k] = 0; ee[k] = 0; }
+    int pbest = 0, hin = 0, fin = 0, diag = 0;
+    u32 nextd = residue(g);
+    const int steps = len + 255;
+    for (int t = 0; t < steps; ++t) {
+      if ((t & 255) == 0) {
+        __syncthreads();
+        ring[(t + g) & 511] = (uint8_t)nextd;
+        nextd = residue(t + 256 + g);
+        __syncthreads();
+      }
+      const int c = t - g;
+      const bool active = c >= 0 && c < len;
+      int hout = 0, fout = 0;
+      if (active) {
+        const int* mrow = M + ((int)ring[c & 511] << 5);
+        int hd = diag, f = fin;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int n0 = hp[k];
+          int e = ee[k];
+          int h = hd + (qs[k] >= 0 ? mrow[qs[k]] : -1);
+          h = max(max(h, f), max(e, 0));
+          pbest = max(pbest, qs[k] >= 0 ? h : 0);
+          hp[k] = h;
+          const int tt = h - Q;
+          e = max(e - R, tt);
+          f = max(f - R, tt);
+          ee[k] = e;
+          hd = n0;
+        }
+        hout = hp[K - 1];
+        fout = f;
+        diag = hin;
+      }
+      int h1 = lane_up1(hout), f1 = lane_up1(fout);
+      if (lane == 63) { bnd[t & 1][wave][0] = hout; bnd[t & 1][wave][1] = fout; }
+      __syncthreads();
+      if (lane == 0 && wave > 0) { h1 = bnd[t & 1][wave - 1][0]; f1 = bnd[t & 1][wave - 1][1]; }
+      hin = h1;
+      fin = f1;
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) pbest = max(pbest, __shfl_down(pbest, sh));
+    if (lane == 0) wbest[wave] = pbest;
+    __syncthreads();
+    if (g == 0) scores[id] = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
   }
 }
 
@@ -619,6 +723,23 @@ extern "C" hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t*
     default: SWA_RQW(32); break;
   }
 #undef SWA_RQW
+  return hipGetLastError();
+}
+// rows per lane of the block form: qlen <= 256 K, K = 1 .. 4 (0: the query is too long for it - the wave kernel's passes take it)
+extern "C" int swa_requeue_block_rows_for(int qlen) { return qlen <= 1024 ? (qlen + 255) / 256 : 0; }
+extern "C" hipError_t swa_launch_requeue_block(const swa_seqs* sq, const int32_t* list, const int32_t* count, int cap, int32_t* work, const uint8_t* qseq, int qlen,
+                                               const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st)
+{
+#define SWA_RQB(KK) hipLaunchKernelGGL((swa_requeue_block_kernel<KK>), dim3(blocks), dim3(256), 0, st, *sq, list, count, \
+                                       cap, work, qseq, qlen, matrix, Q, R, scores)
+  switch (swa_requeue_block_rows_for(qlen)) {
+    case 1: SWA_RQB(1); break;
+    case 2: SWA_RQB(2); break;
+    case 3: SWA_RQB(3); break;
+    case 4: SWA_RQB(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef SWA_RQB
   return hipGetLastError();
 }
 extern "C" hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n, int which, long long minscore,

@@ -80,6 +80,9 @@ hipError_t swa_launch_filter(const int* scores, const long long* scores64, int n
 hipError_t swa_launch_rebase(const swa_batch* src, swa_batch* dst, int n, uint32_t delta, hipStream_t st);
 hipError_t swa_launch_fold(int* scores, long long* scores64, const int32_t* parents, const int32_t* wfirst, int nparents, int nseq,
                            hipStream_t st);
+int swa_requeue_block_rows_for(int qlen);
+hipError_t swa_launch_requeue_block(const swa_seqs* sq, const int32_t* list, const int32_t* count, int cap, int32_t* work, const uint8_t* qseq, int qlen,
+                                    const int32_t* matrix, int Q, int R, int* scores, int blocks, hipStream_t st);
 hipError_t swa_launch_requeue_wave(const swa_seqs* sq, const int32_t* list, const int32_t* count,
                                    int cap, int32_t* work, const uint8_t* qseq, int qlen, const int32_t* matrix, int Q, int R,
                                    int* scores, int blocks, hipStream_t st);
@@ -216,6 +219,7 @@ struct Options {
   int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
+  int64_t requeue_block = -1;    // device-driven re-queue, a BLOCK of four waves per sequence instead of one wave: -1 when the wave form would have 3+ rows per lane (129..1024 query rows), 0 never, 1 whenever the query fits (<= 1024 rows)
   int64_t requeue_follow = 0;    // (rounds 2-3: a re-queue kernel beside the first pass on a second stream; gone - the key is accepted and ignored)
   int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
   int64_t window_step = 0;       // distance between window starts; 0 = from the query (the overlap is never a knob: it is what makes it exact)
@@ -237,7 +241,7 @@ const OptionKey kOptionKeys[] = {
   {"mp_w", &Options::mp_w}, {"boundary_mb", &Options::boundary_mb}, {"wave_requeue", &Options::wave_requeue},
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
-  {"requeue_follow", &Options::requeue_follow}, {"window", &Options::window}, {"window_step", &Options::window_step},
+  {"requeue_follow", &Options::requeue_follow}, {"requeue_block", &Options::requeue_block}, {"window", &Options::window}, {"window_step", &Options::window_step},
   {"long_lanes", &Options::long_lanes}, {"watchdog_s", &Options::watchdog_s}, {"pipelined", &Options::pipelined},
   {"load_part", &Options::load_part}, {"load_chunk", &Options::load_chunk}, {"load_threads", &Options::load_threads},
   {"load_delay_ms", &Options::load_delay_ms}, {"load_trace", &Options::load_trace}, {"stream_reserve", &Options::stream_reserve},
@@ -1376,6 +1380,19 @@ bool device_requeue_ok(const swa_db* db, int64_t qlen)
   return wave_requeue_ok(db, qlen) && !db->opt.requeue_host && qlen <= 64 * swa_endpoints_rows_for(int(qlen));
 }
 
+// the device-driven re-queue behind a first pass: four waves per sequence where that shortens the chain of a step, else one
+hipError_t launch_requeue(const swa_db* db, const swa_seqs& sq, const int32_t* list, const int32_t* count, int32_t* work, const uint8_t* qseq,
+                          int64_t qlen, int* scores, hipStream_t st)
+{
+  const int kb = swa_requeue_block_rows_for(int(std::min<int64_t>(qlen, 1 << 20)));
+  const bool block = kb > 0 && (db->opt.requeue_block == 1 || (db->opt.requeue_block < 0 && qlen > 128));
+  if (block)
+    return swa_launch_requeue_block(&sq, list, count, REQUEUE_CAP, work, qseq, int(qlen), db->matrix.p, int(db->goe), int(db->ge), scores,
+                                    db->cus * 8, st);
+  return swa_launch_requeue_wave(&sq, list, count, REQUEUE_CAP, work, qseq, int(qlen), db->matrix.p, int(db->goe), int(db->ge), scores,
+                                 db->cus * 8, st);
+}
+
 // 32-bit then 64-bit kernels over a re-queue list the host holds, one query; results land in `scores`
 // (64-bit values in `s64` with the sentinel in `scores`).
 int run_wide(swa_db* db, std::vector<int32_t>& requeue, const uint8_t* qdev, int64_t qlen, int32_t* scores,
@@ -1718,8 +1735,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   pd.used_bound = used_bound;
   if (c.narrow && device_requeue_ok(db, qlen)) {
     // the list stays on the device: a persistent grid of waves takes entries off it until the count the first pass left
-    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
-                                    db->qseq_p, int(qlen), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
+    HIP_TRY(launch_requeue(db, sq, db->ovf_list.p, db->ctl.p + 1, db->ctl.p + 4, db->qseq_p, qlen, db->scores.p, st));
     pd.dev1 = true;
   } else {
     if (c.narrow) {
@@ -1950,10 +1966,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (!listed) { rc = reserve2(false); if (rc != SWA_OK) return rc; }
   const swa_seqs sq = db->seqs();
   if (listed && device_requeue_ok(db, qlen)) {
-    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list.p, db->ctl.p + 1, REQUEUE_CAP, db->ctl.p + 4,
-                                    db->qseq_p, int(qa), db->matrix.p, int(db->goe), int(db->ge), db->scores.p, db->cus * 8, st));
-    HIP_TRY(swa_launch_requeue_wave(&sq, db->ovf_list2.p, db->ctl.p + 3, REQUEUE_CAP, db->ctl.p + 5,
-                                    db->qseq2_p, int(qb), db->matrix.p, int(db->goe), int(db->ge), db->scores2.p, db->cus * 8, st));
+    HIP_TRY(launch_requeue(db, sq, db->ovf_list.p, db->ctl.p + 1, db->ctl.p + 4, db->qseq_p, qa, db->scores.p, st));
+    HIP_TRY(launch_requeue(db, sq, db->ovf_list2.p, db->ctl.p + 3, db->ctl.p + 5, db->qseq2_p, qb, db->scores2.p, st));
     pd.dev1 = pd.dev2 = true;
   } else {
     if (listed) {

@@ -245,6 +245,12 @@ static uint8_t parse_mask_list(const std::string& v) {      // "[1,0,1]" -> bit 
     return m;
 }
 
+static uint8_t parse_quad(const std::string& v) {            // "[a,b,c,d]" -> 2 bits each
+    uint8_t q = 0; int i = 0;
+    for (char ch : v) if (ch >= '0' && ch <= '3' && i < 4) { q |= (uint8_t)((ch - '0') << (2 * i)); i++; }
+    return q;
+}
+
 static bool parse_line(const std::string& line, Inst& in, std::string& err) {
     size_t cpos = line.find("//");
     std::string body = line.substr(0, cpos);
@@ -298,6 +304,12 @@ static bool parse_line(const std::string& line, Inst& in, std::string& err) {
             else if (k == "row_shl") { in.dpp_kind = 1; in.dpp_n = (uint8_t)iv; }
             else if (k == "row_shr") { in.dpp_kind = 2; in.dpp_n = (uint8_t)iv; }
             else if (k == "row_ror") { in.dpp_kind = 3; in.dpp_n = (uint8_t)iv; }
+            else if (k == "row_bcast") { in.dpp_kind = iv == 15 ? 4 : 5; in.dpp_n = (uint8_t)iv; }
+            else if (k == "wave_shl") { in.dpp_kind = 6; in.dpp_n = 1; }
+            else if (k == "wave_shr") { in.dpp_kind = 7; in.dpp_n = 1; }
+            else if (k == "wave_rol") { in.dpp_kind = 8; in.dpp_n = 1; }
+            else if (k == "wave_ror") { in.dpp_kind = 9; in.dpp_n = 1; }
+            else if (k == "quad_perm") { in.dpp_kind = 10; in.dpp_n = parse_quad(v); }
             else if (k == "row_mask") in.row_mask = (uint8_t)iv;
             else if (k == "bank_mask") in.bank_mask = (uint8_t)iv;
             else if (k == "bound_ctrl") in.bound_ctrl = true;      // both spellings (bound_ctrl:0 of old, :1 of new) mean "read 0"
@@ -615,6 +627,13 @@ static inline bool dpp_source(const Inst& in, int lane, uint64_t exec, int& srcl
         case 1: j = i + in.dpp_n; if (j > 15) return false; break;          // row_shl: lane i reads lane i + n
         case 2: j = i - in.dpp_n; if (j < 0) return false; break;           // row_shr: lane i reads lane i - n
         case 3: j = (i - in.dpp_n) & 15; break;                             // row_ror
+        case 4: if (row == 0) return false; srcl = row - 1; return (exec >> srcl) & 1;          // row_bcast:15: lane 15 of the row before
+        case 5: if (row < 32) return false; srcl = 31; return (exec >> srcl) & 1;               // row_bcast:31: lane 31 to rows 2 and 3
+        case 6: if (lane == 63) return false; srcl = lane + 1; return (exec >> srcl) & 1;       // wave_shl:1
+        case 7: if (lane == 0) return false; srcl = lane - 1; return (exec >> srcl) & 1;        // wave_shr:1
+        case 8: srcl = (lane + 1) & 63; return (exec >> srcl) & 1;                              // wave_rol:1
+        case 9: srcl = (lane - 1) & 63; return (exec >> srcl) & 1;                              // wave_ror:1
+        case 10: srcl = (lane & ~3) + ((in.dpp_n >> (2 * (lane & 3))) & 3); return (exec >> srcl) & 1;   // quad_perm
         default: throw Fault("dpp control not modelled");
     }
     srcl = row + j;
