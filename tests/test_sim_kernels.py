@@ -1,0 +1,134 @@
+"""The COMPILED gfx950 kernels, checked on a machine without a GPU (round 5: GPU access for this repository has been closed
+from outside the build since the middle of round 4).  tools/gfx950sim interprets the code objects inside
+swipe_amd/libswipe_amd.so - the binary that ships - behind a stand-in for the HIP runtime, bounds-checks every device
+access and counts wave instructions.  These tests run a bounded slice of the `-m gpu` parity suite that way (the whole
+suite under the interpreter is profiles/r05_sim_gpu_suite.txt), pin the interpreter against itself (scalar definitions vs
+the AVX-512 fast forms) and against a deliberate out-of-bounds kernel, and keep the settled drain experiment settled.
+
+Nothing here replaces hardware: `-m gpu` on an MI355X remains the parity gate; this is what can be shown meanwhile, and what
+let items 4-8 of VERDICT r4 be developed against real kernel executions instead of blind."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+SIM = os.path.join(ROOT, "tools", "gfx950sim")
+RUN = os.path.join(SIM, "run.sh")
+HIPCC = "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")),
+                                reason="tools/gfx950sim needs ROCm's clang++ and llvm-objdump")
+
+
+def _sim(cmd, timeout, **env):
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    e.pop("LD_PRELOAD", None)
+    return subprocess.run([RUN] + cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+GOLDEN_SLICE = ("scores_equal_reference_for_every_sequence or hit_list_equals_reference_cli or width_escalation or "
+                "cli_output_equals_reference_cli or alignment_end_points_equal or translated_scores_equal or "
+                "dual_query_kernel_both_strands or empty_inputs")
+
+
+def test_shipped_kernels_reproduce_the_reference_goldens_under_the_interpreter():
+    """every sequence of the reference's goldens (P07327 vs 1 k + planted homologs, edge lengths, the 75 000 score,
+    the asymmetric matrix, nucleotide both strands, three volumes), the width escalation 16 -> 32 -> 64, end points vs
+    search16s, translated searches, and the CLI's bytes - computed by the gfx950 code objects of libswipe_amd.so"""
+    r = _sim([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", GOLDEN_SLICE], 1500)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 40 and "failed" not in r.stdout, tail
+
+
+_SMOKE = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+np.seterr(over="ignore")
+import oracle, swipe_amd
+from swipe_amd import blastdb, synth
+q = blastdb.encode_protein(synth.QUERY_P07327)
+res, off = swipe_amd.synth_db(1, 1500, query=q)
+db = swipe_amd.Database.from_arrays(res, off)
+db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+s, c = db.search(q)
+db.set_option("bound", "1")
+hits = db.search_topk(q, keep=50, minscore=60)[:2]
+ref = oracle.search_all63(res, off, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=4)
+print(json.dumps({"equal": bool((s == ref).all()), "sum": int(s.sum()), "hits": hits, "form": c["narrow_shifted"]}))
+"""
+
+
+def test_scalar_definitions_and_avx512_forms_of_the_interpreter_agree(tmp_path):
+    """sim_fast.cpp (AVX-512 FP16 / BW / VBMI) must be an optimisation of sim_isa.cpp's scalar semantics, nothing else; both
+    must give the oracle's scores; and the per-kernel instruction counts come out"""
+    outs = []
+    for fast in ("0", "1"):
+        stats = str(tmp_path / f"stats{fast}.jsonl")
+        r = _sim([sys.executable, "-c", _SMOKE % ROOT], 600, HIPSIM_FAST=fast, HIPSIM_STATS=stats)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        rows = [json.loads(l) for l in open(stats)]
+        first = max((d for d in rows if d["vop3p"] > 0), key=lambda d: d["vop3p"])
+        # the first-pass kernels are packed-f16 code: that is where the instructions are
+        assert first["vop3p"] > 3 * first["valu"] > 0, first
+    assert outs[0]["equal"] and outs[0] == outs[1], outs
+
+
+_OOB = r"""
+#include <hip/hip_runtime.h>
+#include <cstdio>
+__global__ void touch(int* p, int n, int at) { if ((int)threadIdx.x == 0) p[at] = n; }
+int main(int argc, char** argv) {
+  int* d = nullptr;
+  if (hipMalloc(&d, 100 * sizeof(int)) != hipSuccess) return 2;
+  hipLaunchKernelGGL(touch, dim3(1), dim3(64), 0, 0, d, 7, argc > 1 ? atoi(argv[1]) : 0);
+  hipError_t e = hipDeviceSynchronize();
+  std::printf("%s\n", e == hipSuccess ? "clean" : hipGetErrorString(e));
+  return e == hipSuccess ? 0 : 1;
+}
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_interpreter_faults_on_the_first_byte_outside_an_allocation(tmp_path):
+    """device memory is checked against the exact byte range of every live allocation - what red zones and compute-sanitizer
+    approximate on hardware (device code had never run under a memory checker)"""
+    src = tmp_path / "oob.hip"
+    src.write_text("#include <cstdlib>\n" + _OOB)
+    exe = str(tmp_path / "oob")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", str(src), "-o", exe], check=True, capture_output=True, timeout=300)
+    ok = _sim([exe, "99"], 120)
+    assert ok.returncode == 0 and "clean" in ok.stdout, ok.stdout + ok.stderr
+    bad = _sim([exe, "100"], 120)
+    assert bad.returncode == 1 and "out of bounds" in bad.stdout + bad.stderr and "0 bytes past the end of the 400-byte allocation" in bad.stdout + bad.stderr, bad.stdout + bad.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_drain_experiment_root_cause_stays_settled(tmp_path):
+    """tools/ubench/drain_test.hip.  The wrong scores of the in-kernel re-queue drain are DETERMINISTIC
+    under the interpreter (one wave at a time, single-wave mode included), i.e. not a race: hipcc threads the divergent
+    lane-0 branch at the end of the claim loop across the back-edge and lanes 1..63 leave the loop after the first
+    sequence (sw_wave_dp_experiment.cuh has the ISA).  With no divergent branch at the latch (-DSWA_DRAIN_FIXED) the same
+    inlined drain is right.  Pinned: FIXED must be right; what the unfixed inline build does is reported, not asserted -
+    another compiler may well not thread it."""
+    inc = ["-I" + os.path.join(ROOT, "swipe_amd", "csrc"), "-I" + os.path.join(ROOT, "tools", "ubench")]
+    src = os.path.join(ROOT, "tools", "ubench", "drain_test.hip")
+    res = {}
+    for name, flags in (("fixed", ["-DSWA_DRAIN_INLINE", "-DSWA_DRAIN_FIXED"]), ("inline", ["-DSWA_DRAIN_INLINE"])):
+        exe = str(tmp_path / ("drain_" + name))
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3"] + inc + flags + [src, "-o", exe], check=True, capture_output=True, timeout=600)
+        for mode in ("0", "3"):
+            r = _sim([exe, "750", mode], 300, HIPSIM_THREADS=1)
+            m = re.search(r"wrong (\d+) of 64", r.stdout)
+            assert m, r.stdout + r.stderr
+            res[(name, mode)] = int(m.group(1))
+    print("drain experiment under the interpreter (wrong of 64):", res)
+    assert res[("fixed", "0")] == 0 and res[("fixed", "3")] == 0, res
+    assert res[("inline", "0")] == res[("inline", "3")], res        # whatever it is, it does not depend on how many waves take part
