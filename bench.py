@@ -137,7 +137,8 @@ def live_traffic(nseq, device, budget_s=45):
                                    os.path.join(ROOT, "bench.py"), "--traffic-child", "--nseq", str(nseq), "--device", str(device)],
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd="/tmp", env=env, start_new_session=True)
             try:
-                so, se = pr.communicate(timeout=max(15, budget_s - (time.time() - t0)))
+                # both passes together stay inside 60 s whatever happens: 45 s shared, the second at least 15 s
+                so, se = pr.communicate(timeout=max(1.0, min(max(15.0, budget_s - (time.time() - t0)), 60.0 - (time.time() - t0))))
             except subprocess.TimeoutExpired:
                 os.killpg(pr.pid, 9)
                 pr.communicate()
@@ -667,6 +668,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-first-pass, nucleotide and cold-open sections")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-open (disk -> HBM) section")
+    ap.add_argument("--traffic-only", action="store_true", help="the headline step + roofline.traffic measured in the run, nothing else (tests)")
     ap.add_argument("--verify-sample", type=int, default=10_000)
     ap.add_argument("--quick", action="store_true", help="secondary sections at reduced size: nucleotide 10 M sequences, no 100 M-protein section")
     ap.add_argument("--secondary-nt-nseq", type=int, default=0, help="sequences of the nucleotide secondary section (default 50 M; --quick 10 M)")
@@ -681,6 +683,8 @@ def main():
     if a.traffic_child:
         traffic_child(a.nseq or 10_000_000, a.device)
         return
+    if a.traffic_only:
+        a.no_secondary = a.no_cpu_baseline = a.no_verify = a.no_cold = True
 
     # `python bench.py --gpus N` without a launcher: become the launcher the driver uses (one rank per GPU over RCCL).  Under
     # torch.distributed.run WORLD_SIZE is set and is what counts; --gpus is then only the caller's statement of it.
@@ -847,12 +851,19 @@ def main():
         value = cells_per_step * a.steps / elapsed / 1e9
         form = c["narrow_shifted"]
         traffic, tsrc = committed_traffic("protein", n_local)
-        if world == 1 and a.workload == "protein" and not a.no_secondary and not a.no_live_traffic:
-            live, why = live_traffic(n_local, local)             # after the timed region, in a child process under rocprofv3
+        if world == 1 and a.workload == "protein" and (a.traffic_only or not a.no_secondary) and not a.no_live_traffic:
+            try:
+                live, why = live_traffic(n_local, local)         # after the timed region, in a child process under rocprofv3
+            except BaseException as e:                           # whatever it is, the line and the sections after it survive
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                live, why = None, "live traffic raised %s: %s" % (type(e).__name__, e)
             if live:
                 traffic, tsrc = live, why
             elif tsrc:
                 tsrc += " (live pass not available: %s)" % why
+            else:
+                tsrc = "not measured: %s" % why
         roof, valu = roofline_blocks(nsym, n_local, nsym * len(q), k_ms, form, c["narrow_rows"], traffic=traffic, traffic_source=tsrc)
         what = "top-%d search, bound first pass" % KEEP if form in (8, 9, 10) else "top-%d search, exact first pass" % KEEP
         out = {

@@ -1666,6 +1666,22 @@ def test_bench_default_line_carries_configs_3_and_4_as_secondary_sections():
     assert line["cpu_baseline"]["value"] and line["roofline"]["achieved"] > 0
 
 
+@pytest.mark.late
+def test_bench_traffic_source_is_measured_or_an_explicit_fallback():
+    """roofline.traffic of the default line comes from `rocprofv3 --pmc` passes run inside bench.py itself; whatever
+    happens to them - no rocprofv3, a csv it cannot read, an overrun - the line must come out with a traffic_source that
+    says which of the two it is, and a measured figure must be in the neighbourhood of the algorithmic bytes"""
+    line = _bench_line({}, "--nseq", "400000", "--steps", "2", "--warmup", "1", "--traffic-only")
+    roof = line["roofline"]
+    src = roof.get("traffic_source") or ""
+    measured = src.startswith("measured in this run")
+    assert measured or "live pass not available" in src or src.startswith("not measured"), src
+    if measured:
+        algo = 400000 * 12 + line["config"]["residues_rank0"]
+        assert 0.8 * algo < roof["traffic"] < 3.0 * algo, (roof["traffic"], algo)
+    assert roof["achieved"] > 0 and line["value"] > 0
+
+
 def test_bench_predicts_the_scaling_curve_from_one_gpu():
     """--predict-scaling: shards of N = 1, 2, 4, 8 timed one by one; merged lists identical at every N; efficiencies sane"""
     r = _bench_line({}, "--predict-scaling", "--nseq", "400000", "--steps", "2")
