@@ -228,8 +228,21 @@ static void protein_shard(int device, std::mt19937_64& rng)
       swa_counters_t c;
       EXPECT(swa_search_pair_topk(str, q.data(), 200, q2.data(), 150, 50, 40, 1000000, 20, 35, 1000000, h1.data(), &n1, &t1, &o1, h2.data(), &n2, &t2, &o2, &c) == SWA_OK);
       EXPECT(same_hits(top_of(a, 0, 50, 40, 1000000, &wt, &wo), h1.data(), n1) && t1 == wt);
-      int64_t one = 0, x;
-      EXPECT(swa_search_endpoints(str, q.data(), 200, &one, 1, &x, &x, &x) == SWA_ESTATE);   // a streamed handle answers searches only
+      // a streamed handle answers the entry points that name sequences too (round 4: the owning part is bound to a slot)
+      int64_t ids[3] = {0, nb / 2, nb - 1}, s1[3], p1[3], q1[3], s2[3], p2[3], q2x[3];
+      EXPECT(swa_search_endpoints(res, q.data(), 200, ids, 3, s1, p1, q1) == SWA_OK);
+      EXPECT(swa_search_endpoints(str, q.data(), 200, ids, 3, s2, p2, q2x) == SWA_OK);
+      for (int k = 0; k < 3; ++k) EXPECT(s1[k] == s2[k] && p1[k] == p2[k] && q1[k] == q2x[k]);
+      // ... and takes an inclusion set (round 5): the even sequences only
+      std::vector<uint8_t> inc(static_cast<size_t>(nb));
+      for (int64_t k = 0; k < nb; ++k) inc[size_t(k)] = uint8_t(k % 2 == 0);
+      EXPECT(swa_db_set_inclusion(res, inc.data(), nb) == SWA_OK && swa_db_set_inclusion(str, inc.data(), nb) == SWA_OK);
+      std::vector<swa_hit_t> g1(40), g2(40);
+      int64_t m1 = 0, m2 = 0, u1 = 0, u2 = 0, v1 = 0, v2 = 0;
+      EXPECT(swa_search_topk(res, q.data(), 200, 40, 35, 1000000, g1.data(), &m1, &u1, &v1, &c) == SWA_OK);
+      EXPECT(swa_search_topk(str, q.data(), 200, 40, 35, 1000000, g2.data(), &m2, &u2, &v2, &c) == SWA_OK);
+      EXPECT(m1 == m2 && u1 == u2 && same_hits(std::vector<swa_hit_t>(g1.begin(), g1.begin() + m1), g2.data(), m2));
+      for (int64_t k = 0; k < m2; ++k) EXPECT(g2[size_t(k)].seqno % 2 == 0);
     }
     swa_db_close(res);
     swa_db_close(str);
