@@ -381,7 +381,7 @@ def test_cli_and_group_over_shards_with_an_hbm_budget(tmp_path, nt):
         common = [EXE, "-d", base, "-i", qf, "-m", view, "-b", "25", "-v", "30"] + extra + shard_args(3)
         body = lambda text: text[text.index("Sequences producing"):] if view == "0" else text      # (-m 0 starts with the time of day)
         outs[view] = body(subprocess.run(common, capture_output=True, text=True, check=True).stdout)
-        assert outs[view].count("\n") > 20
+        assert outs[view].count("\n") > (5 if nt else 20)              # (a random 400-nt query has a handful of hits with E <= 10)
         for frac in (0.55, 0.3):
             budget = max(int(frac * shard_bytes), 20 << 20)
             r = subprocess.run(common + ["--hbm-budget", str(budget)], capture_output=True, text=True)
