@@ -126,8 +126,10 @@ SWA_API int swa_db_open(const char* basename, int symtype, int device,
    the loader (same results as on the resident shard; counters.loading_parts > 0 says it happened), everything else
    waits for the load.  A load error (unreadable file, residue code out of range) is returned by the first call that needs
    the data and by swa_db_wait; the handle can then only be closed.  swa_db_open is this call + swa_db_wait.
-   Pipelined for protein volumes without an OID mask; other databases are read by the old reader and are complete on
-   return.  Options (environment, read when the open begins): SWA_PIPELINED=0 old reader always; SWA_LOAD_PART /
+   Pipelined for every regular database (round 5): protein volumes ([residues NUL]* entries), nucleotide volumes (.nsq entries
+   [packed bases | ambiguity data], unpacked on the device, database.cc:1237-1323), with or without the OID mask of a MEMB_BIT
+   alias (the excluded sequences are marked; the adopted tables hold the members).  Only an index whose entries overlap or
+   run backwards is left to the old reader, which reports it.  Options (environment, read when the open begins): SWA_PIPELINED=0 old reader always; SWA_LOAD_PART /
    SWA_LOAD_CHUNK bytes per part / per page-locked staging chunk; SWA_LOAD_THREADS reader threads; SWA_LOAD_TRACE=1. */
 SWA_API int swa_db_open_async(const char* basename, int symtype, int device,
                       int64_t first_seqno, int64_t last_seqno, swa_db** out);
