@@ -313,6 +313,94 @@ def test_nucleotide_volumes_stream_in(nt_volumes):
         new.close()
 
 
+_PACK_OLD = blastdb.pack_nucleotide
+
+
+def _pack_nucleotide_new_format(codes):
+    """blastdb.pack_nucleotide with the ambiguity table in the 64-bit form (header bit 31; entries code:4 | run-1:12 | pad:4 |
+    position:44, database.cc:1284-1305) - runs of up to 4 096 bases in one entry"""
+    import struct
+    body, _ = _PACK_OLD(codes)
+    codes = np.asarray(codes, dtype=np.uint8)
+    amb = ~np.isin(codes, (1, 2, 4, 8))
+    entries, i, n = [], 0, len(codes)
+    while i < n:
+        if amb[i]:
+            j = i
+            while j + 1 < n and amb[j + 1] and codes[j + 1] == codes[i] and j + 1 - i < 4096:
+                j += 1
+            entries.append((int(codes[i]) << 60) | ((j - i) << 48) | i)
+            i = j + 1
+        else:
+            i += 1
+    table = b"" if not entries else struct.pack(">I", 0x80000000 | (2 * len(entries))) + b"".join(struct.pack(">Q", e) for e in entries)
+    return body, table
+
+
+@pytest.mark.late
+def test_nucleotide_loader_edge_cases(tmp_path, monkeypatch):
+    """what the .nsq format can hold and the unpack kernel must survive: empty and 1..3-base sequences (up to eight sequences
+    share an output dword), ambiguity codes at the first and the last base, whole sequences of N, runs in both table forms
+    (32-bit entries of at most 16 bases, 64-bit entries of up to 4 096), an entry several times larger than a staging chunk,
+    a range that starts and ends inside volumes, and an OID mask on top.  Every base of every sequence, and both strands'
+    scores, against the old reader and the source arrays"""
+    rng = np.random.default_rng(17)
+    acgt = np.array([1, 2, 4, 8], np.uint8)
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 9, 0, 1, 15, 16, 17, 31, 32, 33, 2, 2, 2, 1, 1, 1, 1, 3, 0, 0, 6] + [int(x) for x in rng.integers(0, 40, 600)] + \
+           [int(x) for x in rng.integers(40, 900, 900)] + [50_000, 3, 0, 12_345]
+    seqs = [acgt[rng.integers(0, 4, n)] for n in lens]
+    for k, sq in enumerate(seqs):
+        n = len(sq)
+        if n == 0:
+            continue
+        if k % 5 == 0:
+            sq[0] = 15
+        if k % 7 == 0:
+            sq[-1] = int(rng.choice([5, 10, 14]))
+        if k % 41 == 0:
+            sq[:] = 15                                             # all N
+        if n > 200 and k % 3 == 0:
+            a = int(rng.integers(0, n - 150))
+            sq[a:a + int(rng.integers(17, 140))] = int(rng.choice([3, 6, 9, 12, 15]))     # longer than one 32-bit entry holds
+    seqs[-4][20_000:23_500] = 15                                  # 3 500 N: one 64-bit entry, 219 32-bit ones
+    half = len(seqs) // 2
+    a, b = str(tmp_path / "va"), str(tmp_path / "vb")
+    blastdb.write_volume(a, seqs[:half], protein=False, ids=[f"s{i}" for i in range(half)])
+    monkeypatch.setattr(blastdb, "pack_nucleotide", _pack_nucleotide_new_format)
+    blastdb.write_volume(b, seqs[half:], protein=False, ids=[f"s{i}" for i in range(half, len(seqs))])
+    monkeypatch.undo()
+    base = str(tmp_path / "edge")
+    blastdb.write_alias(base, [a, b], protein=False)
+    inc = rng.random(half) < 0.6
+    blastdb.write_mask_alias(str(tmp_path / "edgemask"), a, inc, memb_bit=1, length=int(sum(len(x) for x, k in zip(seqs[:half], inc) if k)), protein=False)
+    q = acgt[rng.integers(0, 4, 1000)]
+    qr = blastdb.revcomp_nt16(q)
+    M = swipe_amd.matrix_nucleotide(1, -3)
+    tiny = dict(SWA_LOAD_PART=1 << 14, SWA_LOAD_CHUNK=1 << 12, SWA_LOAD_THREADS=3)      # (a 50 000-base entry is 12.5 KiB: three chunks' worth)
+    for name, first, last, count in ((base, 0, -1, len(seqs)), (base, 11, len(seqs) - 3, len(seqs) - 13), (str(tmp_path / "edgemask"), 0, -1, half)):
+        with _Env(SWA_PIPELINED=0):
+            old = swipe_amd.Database.open(name, symtype=0, first_seqno=first, last_seqno=last)
+        with _Env(**tiny):
+            new = swipe_amd.Database.open(name, symtype=0, first_seqno=first, last_seqno=last, wait=False)
+        try:
+            for d in (old, new):
+                d.set_scoring(M, 5, 2)
+            s1, s2, c = new.search2(q, qr)                         # follows the loader (16 x 63 rows)
+            o1, o2, _ = old.search2(q, qr)
+            assert np.array_equal(s1, o1) and np.array_equal(s2, o2), name
+            new.wait()
+            assert new.info() == dict(old.info(), hbm_bytes=new.info()["hbm_bytes"])
+            for k in range(count):
+                want = seqs[first + k]
+                got = new.sequence(first + k)
+                assert np.array_equal(got, want), (name, first + k, len(want))
+            t1, t2 = old.search2_topk(q, qr, keep=30, minscore=12), new.search2_topk(q, qr, keep=30, minscore=12)
+            assert t1[:3] == t2[:3]
+        finally:
+            old.close()
+            new.close()
+
+
 @pytest.mark.late
 def test_two_queries_per_pass_on_a_loading_protein_shard(volumes):
     """swa_search_pair_topk / swa_search2 follow the loader too (chains of 2 / 4 / 8 lanes stream the parts' pair format); the
