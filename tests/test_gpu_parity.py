@@ -1598,8 +1598,14 @@ def test_streamed_shard_answers_every_entry_point():
         assert [list(map(int, a)) for a in db.search_endpoints(q, top)] == [list(map(int, a)) for a in resident.search_endpoints(q, top)]
         assert db.align(q, top) == resident.align(q, top)
         assert all(np.array_equal(db.sequence(s), resident.sequence(s)) for s in top[:5])
-        with pytest.raises(swipe_amd.SwaError):
-            db.set_inclusion(np.ones(40_000, np.uint8))
+        # ... and, since round 5, inclusion sets (every part re-plans its tables): the odd sequences only, then all again
+        odd = (np.arange(40_000) % 2).astype(np.uint8)
+        db.set_inclusion(odd)
+        resident.set_inclusion(odd)
+        assert db.search_topk(q, keep=25, minscore=40)[:3] == resident.search_topk(q, keep=25, minscore=40)[:3]
+        db.set_inclusion(None)
+        resident.set_inclusion(None)
+        assert db.search_topk(q, keep=25, minscore=40)[:3] == resident.search_topk(q, keep=25, minscore=40)[:3]
         db.close()
     resident.close()
 

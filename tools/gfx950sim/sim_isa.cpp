@@ -451,6 +451,7 @@ struct Wave {
 struct Ctx {
     Kernel* k;
     std::vector<uint8_t> lds;
+    std::vector<uint8_t> lds_def;      // HIPSIM_LDS_UNDEF=1: 1 = some lane of this workgroup has written the byte
     uint32_t scratch_bytes = 0;
     uint64_t steps = 0;
     int cur = -1;                      // the wave being stepped (fault attribution)
@@ -640,7 +641,22 @@ static inline bool dpp_source(const Inst& in, int lane, uint64_t exec, int& srcl
     return (exec >> srcl) & 1;         // gfx9 has no fetch-inactive bit: a disabled source lane is invalid
 }
 
+static bool g_lds_undef = false;
 static uint8_t* lds_at(Ctx& c, uint64_t a, uint32_t n, const Inst& in, int lane) {
+    if (g_lds_undef && a + n <= c.lds.size()) {
+        const char* nm = op_name[in.op];
+        const bool wr = strstr(nm, "write") != nullptr || !strncmp(nm, "flat_store", 10);
+        const bool rmw = !strncmp(nm, "ds_add", 6) || !strncmp(nm, "ds_max", 6) || !strncmp(nm, "ds_or", 5);
+        if (wr) memset(&c.lds_def[a], 1, n);
+        else {
+            for (uint32_t i = 0; i < n; i++) if (!c.lds_def[a + i]) {
+                char buf[256];
+                snprintf(buf, sizeof buf, "read of LDS byte %llu that no lane of the workgroup has written (%s, %u bytes at %llu, lane %d)", (unsigned long long)(a + i), nm, n, (unsigned long long)a, lane);
+                throw Fault(buf);
+            }
+            if (rmw) memset(&c.lds_def[a], 1, n);
+        }
+    }
     if (a + n > c.lds.size()) {
         char buf[256];
         snprintf(buf, sizeof buf, "LDS access out of range: address %llu + %u > %zu bytes (%s, lane %d)", (unsigned long long)a, n, c.lds.size(), op_name[in.op], lane);
@@ -1291,6 +1307,7 @@ static void run_workgroup(Worker& W, Kernel& k, Dim3 block, const uint8_t* kerna
     auto& waves = W.waves;
     W.wgs++;
     c.lds.resize((size_t)k.lds + dyn_lds);
+    if (g_lds_undef) c.lds_def.assign(c.lds.size(), 0);
     for (size_t i = 0; i + 4 <= c.lds.size(); i += 4) memcpy(&c.lds[i], &g_poison, 4);
     const uint32_t nv = std::min<uint32_t>(512, (((k.rsrc1 & 0x3f) + 1) * 8) + 8);        // arch VGPRs of the kernel (+ margin); AGPRs start at 256
     for (uint32_t wi = 0; wi < nw; wi++) {
@@ -1387,6 +1404,7 @@ std::string run_kernel(Kernel& k, Dim3 grid, Dim3 block, const uint8_t* kernarg,
         if (const char* e = getenv("HIPSIM_POISON")) g_poison = (uint32_t)strtoul(e, nullptr, 0);
         if (const char* e = getenv("HIPSIM_SWITCH")) g_switch = strtoull(e, nullptr, 0);
         if (const char* e = getenv("HIPSIM_TRACE_INSN")) g_trace = strtoull(e, nullptr, 0);
+        if (const char* e = getenv("HIPSIM_LDS_UNDEF")) g_lds_undef = atoi(e) != 0;
         if (const char* e = getenv("HIPSIM_MAX_STEPS")) g_max_steps = strtoull(e, nullptr, 0);
         const char* f = getenv("HIPSIM_FAST");
         g_fast = (!f || atoi(f) != 0) && simfast::available();
@@ -1399,6 +1417,15 @@ std::string run_kernel(Kernel& k, Dim3 grid, Dim3 block, const uint8_t* kernarg,
     if (k.preload) return "kernarg preload is not modelled";
     const uint32_t threads = block.x * block.y * block.z, nw = (threads + 63) / 64;
     if (threads == 0 || threads > 1024) return "block of " + std::to_string(threads) + " threads";
+    // what the hardware would refuse: more LDS than a workgroup can have (160 KiB on gfx950), or more registers than the waves
+    // of one workgroup get on a SIMD (512 VGPRs per lane, the block's waves spread over 4 SIMDs; AGPRs share the file)
+    if ((uint64_t)k.lds + dyn_lds > 160u * 1024u)
+        return "launch needs " + std::to_string((uint64_t)k.lds + dyn_lds) + " bytes of LDS per workgroup (gfx950: 163840)";
+    {
+        const uint32_t vg = ((k.rsrc1 & 0x3f) + 1) * 8, waves_per_simd = (nw + 3) / 4;
+        if (vg * waves_per_simd > 512)
+            return "launch needs " + std::to_string(vg) + " VGPRs x " + std::to_string(waves_per_simd) + " waves of the workgroup per SIMD (512 per lane)";
+    }
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
     const int T = (int)std::min<uint64_t>((uint64_t)g_threads, total);
     static std::vector<std::unique_ptr<Worker>> pool;          // (launches are serialised by the runtime's lock)

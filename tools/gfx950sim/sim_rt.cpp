@@ -7,7 +7,10 @@
 // reported (persistent grids scale with it); HIPSIM_MEM_GB (default 16); HIPSIM_STATS=<file> per-kernel wave-instruction
 // counts appended at exit and at every hipDeviceSynchronize; HIPSIM_ABORT=1 abort() on the first device fault;
 // HIPSIM_POISON=<u32> initial register / LDS / allocation pattern; HIPSIM_SWITCH=<n> waves of a workgroup take turns every
-// <= n instructions in a seeded random order (race hunting); HIPSIM_TRACE=1 one line per launch.
+// <= n instructions in a seeded random order (race hunting); HIPSIM_TRACE=1 one line per launch; HIPSIM_TRACE_INSN=<n> the first
+// n instructions of wave 0 with EXEC / VCC / operands; HIPSIM_LDS_UNDEF=1 a read of an LDS byte no lane of the workgroup has
+// written is a fault; HIPSIM_BACKTRACE=1 host stack on SIGSEGV.  A launch that asks for more LDS per workgroup or VGPRs per
+// SIMD than gfx950 has is refused, as the hardware would.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
