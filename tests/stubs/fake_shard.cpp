@@ -53,6 +53,16 @@ int swa_db_from_memory_translated(const uint8_t* r, const int64_t* o, int64_t n,
 }
 int swa_db_open(const char*, int, int, int64_t, int64_t, swa_db**) { return swa::fail(SWA_EIO, "stand-in: no files"); }
 int swa_db_open_async(const char*, int, int, int64_t, int64_t, swa_db**) { return swa::fail(SWA_EIO, "stand-in: no files"); }
+int swa_db_wait(swa_db* d) { return d ? SWA_OK : swa::fail(SWA_EINVAL, "null database handle"); }          // a stand-in shard is resident
+int swa_db_load_progress(swa_db* d, int64_t* a, int64_t* b, int32_t* r, int32_t* t)
+{
+  if (!d) return swa::fail(SWA_EINVAL, "null database handle");
+  if (a) *a = 0;
+  if (b) *b = 0;
+  if (r) *r = 0;
+  if (t) *t = 0;
+  return SWA_OK;
+}
 int swa_db_open_streamed(const char*, int, int, int64_t, int64_t, int64_t, swa_db**) { return swa::fail(SWA_EIO, "stand-in: no files"); }
 int swa_db_open_translated(const char*, int, int, int64_t, int64_t, swa_db**) { return swa::fail(SWA_EIO, "stand-in: no files"); }
 void swa_db_close(swa_db* d) { delete d; }

@@ -32,6 +32,12 @@ static void run(int nseq, int nshards, int gencode, unsigned seed)
   int64_t M[1024] = {3};
   EXPECT(swa_group_set_scoring(g, M, 12, 1) == SWA_OK && swa_group_set_scoring(ref, M, 12, 1) == SWA_OK);
   EXPECT(swa_group_set_option(g, "no_such_option", "1") == SWA_EINVAL);
+  {
+    int64_t a = -1, b = -1;
+    int32_t r = -1, t = -1;
+    EXPECT(swa_group_wait(g) == SWA_OK && swa_group_load_progress(g, &a, &b, &r, &t) == SWA_OK && a == 0 && b == 0 && r == 0 && t == 0);
+    EXPECT(swa_group_wait(nullptr) == SWA_EINVAL);
+  }
   const int frames = gencode ? 6 : 1;
   for (int round = 0; round < 6; ++round) {
     std::vector<uint8_t> q(size_t(5 + rng() % 40)), q2(size_t(5 + rng() % 40));
