@@ -64,5 +64,8 @@ int parse_function_at(Kernel& k, uint64_t addr, std::string& err);   // index of
 // memory map of the stand-in runtime (every device access is checked against it)
 bool mem_ok(uint64_t addr, uint64_t n);
 std::string mem_describe(uint64_t addr);
+// HIPSIM_MEM_UNDEF=1: one shadow byte per byte of device memory (1 = written by a host copy, a memset or a kernel); nullptr when
+// the mode is off or the range is page-locked host memory.  Call after mem_ok(addr, n) said yes.
+uint8_t* mem_shadow(uint64_t addr);
 
 }  // namespace sim

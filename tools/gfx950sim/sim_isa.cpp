@@ -671,6 +671,15 @@ static uint8_t* glob_at(uint64_t a, uint32_t n, const Inst& in, int lane, bool w
                  mem_describe(a).c_str());
         throw Fault(buf);
     }
+    if (uint8_t* sh = mem_shadow(a)) {
+        if (write) memset(sh, 1, n);
+        else for (uint32_t i = 0; i < n; i++) if (!sh[i]) {
+            char buf[512];
+            snprintf(buf, sizeof buf, "load of device memory nothing has written: byte %u of %u at 0x%llx (%s, lane %d): %s", i, n, (unsigned long long)a, op_name[in.op], lane,
+                     mem_describe(a).c_str());
+            throw Fault(buf);
+        }
+    }
     return (uint8_t*)(uintptr_t)a;
 }
 static uint8_t* scratch_at(Ctx& c, Wave& w, uint64_t a, uint32_t n, const Inst& in, int lane) {
@@ -922,6 +931,13 @@ static void exec_smem(Wave& w, const Inst& in) {
         char buf[384];
         snprintf(buf, sizeof buf, "scalar load out of bounds: %d bytes at 0x%llx: %s", 4 * nd, (unsigned long long)a, mem_describe(a).c_str());
         throw Fault(buf);
+    }
+    if (const uint8_t* sh = mem_shadow(a)) {
+        for (int i = 0; i < 4 * nd; i++) if (!sh[i]) {
+            char buf[384];
+            snprintf(buf, sizeof buf, "scalar load of device memory nothing has written: byte %d of %d at 0x%llx: %s", i, 4 * nd, (unsigned long long)a, mem_describe(a).c_str());
+            throw Fault(buf);
+        }
     }
     uint32_t tmp[16];
     memcpy(tmp, (const void*)(uintptr_t)a, 4u * nd);

@@ -33,7 +33,7 @@ namespace {
 
 using Lock = std::lock_guard<std::recursive_mutex>;
 
-struct Alloc { uint64_t size; void* raw; bool host; };
+struct Alloc { uint64_t size; void* raw; bool host; uint8_t* shadow; };
 struct FatBin;
 struct Registered { FatBin* fb; std::string name; };
 // Everything with a constructor lives in ONE object made on first use and never destroyed: a program that links
@@ -53,6 +53,7 @@ State& S() { static State* s = new State; return *s; }
 uint64_t g_allocated = 0;
 std::atomic<uint64_t> g_gen{1};                // bumped by every allocation / free: invalidates the per-thread range caches
 thread_local uint64_t t_lo = 1, t_hi = 0, t_gen = 0;    // last range that answered mem_ok
+thread_local uint8_t* t_shadow = nullptr;               // ... and its shadow bytes (HIPSIM_MEM_UNDEF)
 
 struct FatBin {
     const uint8_t* bundle = nullptr;
@@ -190,9 +191,10 @@ bool mem_ok(uint64_t a, uint64_t n) {
     if (it == g_allocs.begin()) return false;
     --it;
     if (a + n > it->first + it->second.size) return false;
-    t_lo = it->first; t_hi = it->first + it->second.size; t_gen = gen;
+    t_lo = it->first; t_hi = it->first + it->second.size; t_gen = gen; t_shadow = it->second.shadow;
     return true;
 }
+uint8_t* mem_shadow(uint64_t a) { return t_shadow ? t_shadow + (a - t_lo) : nullptr; }
 std::string mem_describe(uint64_t a) {
     char buf[256];
     auto it = g_allocs.upper_bound(a);
@@ -217,7 +219,8 @@ static void* dev_alloc(size_t size, bool host) {
     uint32_t p = poison();
     if (n <= (64u << 20)) for (size_t i = 0; i + 4 <= n + 2 * guard; i += 4) memcpy(raw + i, &p, 4);     // big buffers stay untouched (lazy pages)
     void* user = raw + guard;
-    g_allocs[(uint64_t)(uintptr_t)user] = Alloc{n, raw, host};
+    static const bool undef = env_int("HIPSIM_MEM_UNDEF", 0) != 0;
+    g_allocs[(uint64_t)(uintptr_t)user] = Alloc{n, raw, host, undef && !host ? (uint8_t*)calloc(n, 1) : nullptr};
     g_allocated += n;
     g_gen++;
     return user;
@@ -228,6 +231,7 @@ static hipError_t dev_free(void* p) {
     if (it == g_allocs.end()) { fprintf(stderr, "gfx950sim: free of %p which is not a live allocation\n", p); return fail(hipErrorInvalidValue); }
     g_allocated -= it->second.size;
     free(it->second.raw);
+    free(it->second.shadow);
     g_allocs.erase(it);
     g_gen++;
     return hipSuccess;
@@ -386,6 +390,13 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
     if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) ok &= check_dev(src, n, "copy source");
     if (!ok) return fail(hipErrorInvalidValue);
     if (n) memmove(dst, src, n);
+    if (n) {       // defined-ness travels with the bytes
+        uint8_t* ds = sim::mem_ok((uint64_t)(uintptr_t)dst, n) ? sim::mem_shadow((uint64_t)(uintptr_t)dst) : nullptr;
+        if (ds) {
+            uint8_t* ss = sim::mem_ok((uint64_t)(uintptr_t)src, n) ? sim::mem_shadow((uint64_t)(uintptr_t)src) : nullptr;
+            if (ss) memmove(ds, ss, n); else memset(ds, 1, n);
+        }
+    }
     return sync_status();
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t) { return hipMemcpy(dst, src, n, kind); }
@@ -393,6 +404,7 @@ hipError_t hipMemset(void* dst, int v, size_t n) {
     Lock lk(g_mu);
     if (!check_dev(dst, n, "memset")) return fail(hipErrorInvalidValue);
     if (n) memset(dst, v, n);
+    if (n) { uint8_t* ds = sim::mem_shadow((uint64_t)(uintptr_t)dst); if (ds) memset(ds, 1, n); }
     return sync_status();
 }
 hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { return hipMemset(dst, v, n); }
