@@ -46,6 +46,27 @@ def test_shipped_kernels_reproduce_the_reference_goldens_under_the_interpreter()
     assert m and int(m.group(1)) >= 40 and "failed" not in r.stdout, tail
 
 
+ROUND5_SLICE = [
+    # nucleotide volumes and masked aliases through the pipelined open, searched while they load
+    ("tests/test_gpu_loading.py", "nucleotide_loader_edge_cases or masked_alias_streams_in or search_before_wait_on_a_corrupt_volume"),
+    # inclusion sets on shards over their HBM budget: the reference's masked / taxid goldens through the CLI
+    ("tests/test_gpu_group.py", "masks_and_taxid_lists_with_an_hbm_budget and (masked_taxlist or plain_taxid)"),
+    # the re-queue behind the first pass, a wave and a block of four waves per sequence
+    ("tests/test_gpu_parity.py", "requeue_by_batches_and_by_wave and 600"),
+]
+
+
+def test_round_5_paths_under_the_interpreter():
+    """what round 5 added, on the shipped kernels without a GPU: .nsq entries unpacked on the device (empty sequences, both
+    ambiguity table forms, an entry larger than a staging chunk), an OID mask through the loader, a corrupt volume refused
+    by a search that follows the loader, taxid lists and masks on budgeted shards byte for byte against the reference's
+    goldens, and both forms of the device-driven re-queue"""
+    for path, expr in ROUND5_SLICE:
+        r = _sim([sys.executable, "-m", "pytest", path, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", expr], 1500)
+        tail = (r.stdout + r.stderr)[-1500:]
+        assert r.returncode == 0 and re.search(r"\d+ passed", r.stdout) and "failed" not in r.stdout, (path, expr, tail)
+
+
 _SMOKE = r"""
 import sys, json
 sys.path.insert(0, %r)
