@@ -1673,6 +1673,39 @@ def test_bench_default_line_carries_configs_3_and_4_as_secondary_sections():
 
 
 @pytest.mark.late
+@pytest.mark.parametrize("how", ["resident", "streaming in", "budget"])
+def test_cli_nucleotide_ambiguity_tables_equal_reference_cli(tmp_path, how):
+    """tests/golden/ntamb.json (make_ntamb_golden.py): .nsq ambiguity tables in both forms of the format (32-bit entries in one
+    volume, 64-bit entries in the other; database.cc:1284-1323), the query planted on both strands across the ambiguous runs -
+    the unmodified reference's -m 8 / -m 0 / -m 7 output, byte for byte, from the old reader, from the pipelined open with the
+    device-side unpack (chunks of 4 KiB: entries cut everywhere a chunk may end) and from a shard over its HBM budget"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_ntamb_golden as G
+    g = load_golden("ntamb")
+    base, qf, sha = G.build(str(tmp_path))
+    assert sha == g["sha1_of_volumes"]                              # the same bytes the reference searched
+    env = dict(os.environ)
+    extra = []
+    if how == "resident":
+        env["SWA_PIPELINED"] = "0"
+    elif how == "streaming in":
+        env.update(SWA_LOAD_PART="16384", SWA_LOAD_CHUNK="4096")
+    else:
+        env["SWA_STREAM_RESERVE"] = "4096"
+        extra = ["--hbm-budget", "140000"]
+    exe = os.path.join(ROOT, "swipe_amd", "swipe_amd_cli")
+    for m in ("8", "0", "7"):
+        r = subprocess.run([exe, "-d", base, "-i", qf, "-m", m] + g["args"] + extra, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-600:]
+        text = r.stdout
+        if m == "0":
+            text = text[text.index("Sequences producing"):]
+        assert text == g["m" + m], (how, m)
+
+
+@pytest.mark.late
 def test_bench_traffic_source_is_measured_or_an_explicit_fallback():
     """roofline.traffic of the default line comes from `rocprofv3 --pmc` passes run inside bench.py itself; whatever
     happens to them - no rocprofv3, a csv it cannot read, an overrun - the line must come out with a traffic_source that

@@ -53,6 +53,8 @@ ROUND5_SLICE = [
     ("tests/test_gpu_group.py", "masks_and_taxid_lists_with_an_hbm_budget and (masked_taxlist or plain_taxid)"),
     # the re-queue behind the first pass, a wave and a block of four waves per sequence
     ("tests/test_gpu_parity.py", "requeue_by_batches_and_by_wave and 600"),
+    # .nsq ambiguity tables in both forms against the reference's own output (tests/golden/ntamb.json): old reader, loader, budget
+    ("tests/test_gpu_parity.py", "cli_nucleotide_ambiguity_tables_equal_reference_cli"),
 ]
 
 
