@@ -382,7 +382,7 @@ def group_section(res, off, device, q, minscore, maxscore, want_sha1, steps=3):
     return out
 
 
-def nucleotide_cold_open(res, off, device, q, qm, minscore, nslice=5_000_000):
+def nucleotide_cold_open(res, off, device, q, qm, minscore, nslice=2_000_000):
     """disk -> HBM for nucleotide volumes (round 5: the pipelined open takes the .nsq as it lies - 2 bits per base, ambiguity
     tables - and unpacks on the device): the first `nslice` sequences of the section's database written as a BLAST v4 volume,
     swa_db_open warm, then swa_db_open_async + the first both-strand top-K search FOLLOWING the loader; its hit list must be the
