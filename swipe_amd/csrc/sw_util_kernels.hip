@@ -78,10 +78,13 @@ swa_format_stream4(swa_seqs sq, const int32_t* __restrict__ slots, const swa_bat
 #define SWA_TR_TILE 4096
 #define SWA_TR_WIN 2048
 extern "C" __global__ void __launch_bounds__(256)
-swa_translate_frames(const uint8_t* __restrict__ nt, const int64_t* __restrict__ ntoff,
+swa_translate_frames(const uint8_t* __restrict__ nt, int packed, const int64_t* __restrict__ ntoff,
                      const int64_t* __restrict__ voff, int64_t nv, const uint8_t* __restrict__ table,
                      uint8_t* __restrict__ prot, int64_t total)
 {
+  // packed: the nucleotide shard's own 4-bit form, two bases per byte, low nibble first (what the pipelined open leaves on the
+  // device); else one base per byte
+  auto base = [&](int64_t i) -> u32 { return packed ? ((u32)nt[i >> 1] >> ((int)(i & 1) * 4)) & 15u : (u32)nt[i] & 15u; };
   __shared__ uint8_t tab[4096];
   __shared__ int64_t win[SWA_TR_WIN + 1];
   __shared__ int64_t s_v0;
@@ -126,11 +129,11 @@ swa_translate_frames(const uint8_t* __restrict__ nt, const int64_t* __restrict__
       const int64_t o = ntoff[sq], len = ntoff[sq + 1] - o;
       u32 a, b, c;
       if (t < 3) {
-        const uint8_t* p = nt + o + f + 3 * k;
-        a = p[0] & 15; b = p[1] & 15; c = p[2] & 15;
+        const int64_t p = o + f + 3 * k;
+        a = base(p); b = base(p + 1); c = base(p + 2);
       } else {                                            // complement of a nibble = its 4 bits reversed
-        const uint8_t* p = nt + o + len - 1 - f - 3 * k;
-        a = __brev((u32)p[0]) >> 28; b = __brev((u32)p[-1]) >> 28; c = __brev((u32)p[-2]) >> 28;
+        const int64_t p = o + len - 1 - f - 3 * k;
+        a = __brev(base(p)) >> 28; b = __brev(base(p - 1)) >> 28; c = __brev(base(p - 2)) >> 28;
       }
       prot[r] = tab[256 * a + 16 * b + c];
     }
@@ -658,13 +661,13 @@ extern "C" hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int 
   hipLaunchKernelGGL(swa_mark_excluded, dim3((n + 255) / 256), dim3(256), 0, st, scores, ids, n);
   return hipGetLastError();
 }
-extern "C" hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
+extern "C" hipError_t swa_launch_translate(const uint8_t* nt, int packed, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                            const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st)
 {
   if (total <= 0) return hipSuccess;
   const int64_t want = (total + SWA_TR_TILE - 1) / SWA_TR_TILE;
   const int blocks = (int)(want < 8192 ? want : 8192);
-  hipLaunchKernelGGL(swa_translate_frames, dim3(blocks), dim3(256), 0, st, nt, ntoff, voff, nv, table, prot, total);
+  hipLaunchKernelGGL(swa_translate_frames, dim3(blocks), dim3(256), 0, st, nt, packed, ntoff, voff, nv, table, prot, total);
   return hipGetLastError();
 }
 extern "C" hipError_t swa_launch_endpoints(const swa_seqs* sq, const int32_t* ids, const uint8_t* minus, int n,

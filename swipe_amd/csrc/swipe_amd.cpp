@@ -63,7 +63,7 @@ hipError_t swa_launch_endpoints_wave(const swa_seqs* sq, const int32_t* ids,
                                      int Q, int R, int* bh, int* bf, const int64_t* boff, long long* out, int* scores,
                                      hipStream_t st);
 hipError_t swa_launch_mark_excluded(int* scores, const int* ids, int n, hipStream_t st);
-hipError_t swa_launch_translate(const uint8_t* nt, const int64_t* ntoff, const int64_t* voff, int64_t nv,
+hipError_t swa_launch_translate(const uint8_t* nt, int packed, const int64_t* ntoff, const int64_t* voff, int64_t nv,
                                 const uint8_t* table, uint8_t* prot, int64_t total, hipStream_t st);
 hipError_t swa_launch_dual(int K, int nres, int G, const swa_mp_params* p, int cus, hipStream_t st);
 hipError_t swa_launch_dual_one(int K, int nres, const swa_mp_params* p, int cus, hipStream_t st);
@@ -2159,13 +2159,15 @@ static int open_resident(const char* basename, int symtype, int device, int64_t 
   return rc;
 }
 
-extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
-                                             int db_gencode, int device, int64_t first_seqno,
-                                             int64_t total_seqcount, int64_t total_symcount, swa_db** out)
-try {
+namespace {
+// a nucleotide shard as its six translations.  The nucleotide residues come from the host (one base per byte, at offsets[0])
+// or are on the device already (dev_nt: the 4-bit form a pipelined open leaves there, offsets counted from 0)
+int translated_shard(const uint8_t* nt_residues, const uint8_t* dev_nt, const int64_t* offsets, int64_t nseq, int db_gencode, int device,
+                     int64_t first_seqno, int64_t total_seqcount, int64_t total_symcount, swa_db** out)
+{
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
-  if (nseq < 0 || !offsets || (!nt_residues && nseq > 0 && offsets[nseq] > offsets[0]))
+  if (nseq < 0 || !offsets || (!nt_residues && !dev_nt && nseq > 0 && offsets[nseq] > offsets[0]))
     return fail(SWA_EINVAL, "bad database arrays");
   if (nseq > 0x7ffffff0 / 6) return fail(SWA_EINVAL, "too many sequences for one translated shard; shard the database");
   uint8_t table[4096];
@@ -2210,16 +2212,16 @@ try {
     // the nucleotide form lives on the device only for the duration of the translation pre-pass
     DevBuf<uint8_t> d_nt, d_table;
     DevBuf<int64_t> d_ntoff, d_voff;
-    HIP_TRY(d_nt.reserve(size_t(db->nt_sym) + 16));
+    if (!dev_nt) HIP_TRY(d_nt.reserve(size_t(db->nt_sym) + 16));
     HIP_TRY(d_table.reserve(4096));
     HIP_TRY(d_ntoff.reserve(ntoff.size()));
     HIP_TRY(d_voff.reserve(voff.size()));
     HIP_TRY(db->residues.reserve(size_t(total) + 16));
-    if (db->nt_sym) HIP_TRY(hipMemcpyAsync(d_nt.p, nt_residues + base, size_t(db->nt_sym), hipMemcpyHostToDevice, db->stream));
+    if (db->nt_sym && !dev_nt) HIP_TRY(hipMemcpyAsync(d_nt.p, nt_residues + base, size_t(db->nt_sym), hipMemcpyHostToDevice, db->stream));
     HIP_TRY(hipMemcpyAsync(d_table.p, table, 4096, hipMemcpyHostToDevice, db->stream));
     HIP_TRY(hipMemcpyAsync(d_ntoff.p, ntoff.data(), ntoff.size() * sizeof(int64_t), hipMemcpyHostToDevice, db->stream));
     HIP_TRY(hipMemcpyAsync(d_voff.p, voff.data(), voff.size() * sizeof(int64_t), hipMemcpyHostToDevice, db->stream));
-    HIP_TRY(swa_launch_translate(d_nt.p, d_ntoff.p, d_voff.p, 6 * nseq, d_table.p, db->residues.p, total, db->stream));
+    HIP_TRY(swa_launch_translate(dev_nt ? dev_nt : d_nt.p, dev_nt ? 1 : 0, d_ntoff.p, d_voff.p, 6 * nseq, d_table.p, db->residues.p, total, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));
   }
   rc = ingest(db, nullptr, voff.data(), 6 * nseq);
@@ -2229,6 +2231,14 @@ try {
   guard.d = nullptr;
   *out = db;
   return SWA_OK;
+}
+}  // namespace
+
+extern "C" int swa_db_from_memory_translated(const uint8_t* nt_residues, const int64_t* offsets, int64_t nseq,
+                                             int db_gencode, int device, int64_t first_seqno,
+                                             int64_t total_seqcount, int64_t total_symcount, swa_db** out)
+try {
+  return translated_shard(nt_residues, nullptr, offsets, nseq, db_gencode, device, first_seqno, total_seqcount, total_symcount, out);
 } SWA_CATCH
 
 extern "C" int swa_db_open_translated(const char* basename, int db_gencode, int device, int64_t first_seqno,
@@ -2236,6 +2246,24 @@ extern "C" int swa_db_open_translated(const char* basename, int db_gencode, int 
 try {
   if (!out) return fail(SWA_EINVAL, "null output handle");
   *out = nullptr;
+  {
+    // the nucleotide volumes through the pipelined open (round 5), translated out of the 4-bit residues it leaves on the
+    // device; a masked alias keeps the old reader (its OID mask is wanted on the host below)
+    uint8_t table[4096];
+    if (swa_translate_table(db_gencode, table) != SWA_OK) return fail(SWA_EINVAL, "Illegal database genetic code specified.");
+    swa_db* nt = nullptr;
+    int prc = open_pipelined(basename, SWA_SYMTYPE_NUCLEOTIDE, device, first_seqno, last_seqno, &nt);
+    if (prc != SWA_OK) return prc;
+    if (nt && nt->loading && nt->loading->masked) { swa_db_close(nt); nt = nullptr; }
+    if (nt) {
+      prc = settle_loading(nt, true, nullptr, true);
+      if (prc == SWA_OK)
+        prc = translated_shard(nullptr, nt->residues.p, nt->h_offsets.data(), nt->nseq, db_gencode, device, nt->first_seqno, nt->total_seq,
+                               nt->total_sym, out);
+      swa_db_close(nt);
+      return prc;
+    }
+  }
   swa::HostDb h;
   int rc = swa::read_blast_db(basename, SWA_SYMTYPE_NUCLEOTIDE, first_seqno, last_seqno, h);
   if (rc != SWA_OK) return rc;
