@@ -104,6 +104,43 @@ def test_scalar_definitions_and_avx512_forms_of_the_interpreter_agree(tmp_path):
     assert outs[0]["equal"] and outs[0] == outs[1], outs
 
 
+def test_interpreter_binary16_arithmetic_equals_numpy():
+    """the interpreter's own ground: IEEE binary16 add / mul / fma rounded once and the 754-2019 maximum of three, scalar
+    definitions and AVX-512 forms, on two million random bit patterns plus every pair of the special values (zeros of both
+    signs, infinities, NaN, smallest and largest subnormal, smallest normal, largest finite) - against numpy's float16"""
+    import ctypes
+    import numpy as np
+    subprocess.run(["make", "-s", "-C", SIM, "libhipsim.so"], check=True, capture_output=True, timeout=600)
+    L = ctypes.CDLL(os.path.join(SIM, "libhipsim.so"))
+    P = ctypes.POINTER(ctypes.c_uint16)
+    L.hipsim_f16_op.argtypes = [ctypes.c_int, ctypes.c_int, P, P, P, P, ctypes.c_long]
+    rng = np.random.default_rng(1)
+    n = 1 << 21
+    a, b, c = (rng.integers(0, 65536, n).astype(np.uint16) for _ in range(3))
+    sp = np.array([0, 0x8000, 0x7c00, 0xfc00, 0x7e00, 0x0001, 0x8001, 0x03ff, 0x0400, 0x7bff, 0xfbff, 0x3c00, 0xbc00, 0x6800, 0x6801], np.uint16)
+    k = len(sp)
+    a[:k * k], b[:k * k], c[:k * k] = np.repeat(sp, k), np.tile(sp, k), np.tile(sp[::-1], k)
+    af, bf, cf = (x.view(np.float16).astype(np.float64) for x in (a, b, c))
+    with np.errstate(all="ignore"):
+        want = {0: (af + bf).astype(np.float16).view(np.uint16), 1: (af * bf).astype(np.float16).view(np.uint16),
+                2: (af * bf + cf).astype(np.float16).view(np.uint16)}
+    key = lambda h: np.where(h & 0x8000, (~h) & 0xffff, h | 0x8000).astype(np.int64)          # sign-magnitude -> ordered, -0 below +0
+    ka, kb, kc = key(a), key(b), key(c)
+    best = np.where(ka >= kb, a, b)
+    best = np.where(np.maximum(ka, kb) >= kc, best, c)
+    anynan = ((a & 0x7fff) > 0x7c00) | ((b & 0x7fff) > 0x7c00) | ((c & 0x7fff) > 0x7c00)
+    want[3] = np.where(anynan, 0x7e00, best).astype(np.uint16)
+    for op in (0, 1, 2, 3):
+        wnan = (want[op] & 0x7fff) > 0x7c00
+        for fast in (0, 1):
+            out = np.zeros(n, np.uint16)
+            rc = L.hipsim_f16_op(op, fast, a.ctypes.data_as(P), b.ctypes.data_as(P), c.ctypes.data_as(P), out.ctypes.data_as(P), n)
+            if rc:
+                continue                                         # no AVX-512 FP16 on this host: the scalar form is all there is
+            onan = (out & 0x7fff) > 0x7c00
+            assert np.array_equal(onan, wnan) and np.array_equal(out[~wnan], want[op][~wnan]), (op, fast, int((out != want[op]).sum()))
+
+
 _OOB = r"""
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -157,6 +157,36 @@ static inline uint16_t h_fma(uint16_t a, uint16_t b, uint16_t c) {
 }
 static inline uint16_t h_mul(uint16_t a, uint16_t b) { return d2h((double)g_h2f[a] * (double)g_h2f[b]); }
 
+}  // namespace sim
+// the interpreter's binary16 arithmetic, for tests/test_sim_kernels.py (checked against numpy's float16): op 0 add, 1 mul, 2 fma,
+// 3 IEEE-754-2019 maximum of three; fast != 0: the AVX-512 form of the packed instruction (low halves of the operands)
+extern "C" int hipsim_f16_op(int op, int fast, const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, long n) {
+    using namespace sim;
+    init_tables();
+    if (fast && !simfast::available()) return 1;
+    for (long i = 0; i < n; i += 64) {
+        uint32_t A[64] = {0}, B[64] = {0}, C[64] = {0}, D[64] = {0};
+        const long m = n - i < 64 ? n - i : 64;
+        for (long l = 0; l < m; l++) { A[l] = a[i + l]; B[l] = b[i + l]; C[l] = c[i + l]; }
+        if (fast) {
+            const uint64_t exec = m == 64 ? ~0ull : ((1ull << m) - 1);
+            if (op == 0) simfast::pk_add_f16(D, A, 1, 0, B, 1, 0, exec);
+            else if (op == 1) simfast::pk_mul_f16(D, A, 1, 0, B, 1, 0, exec);
+            else if (op == 2) simfast::pk_fma_f16(D, A, 1, 0, B, 1, 0, C, 1, 0, exec);
+            else if (!simfast::pk_maximum3_f16(D, A, 1, 0, B, 1, 0, C, 1, 0, exec))
+                for (long l = 0; l < m; l++) D[l] = h_maximum(h_maximum((uint16_t)A[l], (uint16_t)B[l]), (uint16_t)C[l]);      // NaN operands: the scalar form, as exec_vop3p does
+        } else {
+            for (long l = 0; l < m; l++) {
+                const uint16_t x = (uint16_t)A[l], y = (uint16_t)B[l], z = (uint16_t)C[l];
+                D[l] = op == 0 ? h_add(x, y) : op == 1 ? h_mul(x, y) : op == 2 ? h_fma(x, y, z) : h_maximum(h_maximum(x, y), z);
+            }
+        }
+        for (long l = 0; l < m; l++) out[i + l] = (uint16_t)D[l];
+    }
+    return 0;
+}
+namespace sim {
+
 // ------------------------------------------------------------------------------------------------ parsing
 static bool parse_int(const std::string& t, int64_t& v) {
     if (t.empty()) return false;
