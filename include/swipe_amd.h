@@ -97,7 +97,11 @@ typedef struct {
                             12: two-query kernel, ONE lane per sequence (at most 48 nucleotide / 32 other rows) */
   int32_t loading_parts; /* > 0: the shard was still loading (swa_db_open_async) and the first pass ran part by part, one launch
                             per part as the parts arrived; kernel_ms then includes waiting for them.  0: one resident shard */
-  int32_t reserved;
+  int32_t requeue_form;  /* how the sequences that left the packed range were recomputed (search16's role, search16.cc:320-546):
+                            0 nothing was launched for them (no first pass); 1 on the device behind the first pass, one wave per
+                            sequence; 2 the same with a block of four waves per sequence (option requeue_block); 3 by the host-driven
+                            32/64-bit kernels after the synchronisation.  A list the device kernel could not finish (more than
+                            65 536 entries, scores beyond 32 bits) is completed by form 3 and still reports 1 or 2 */
 } swa_counters_t;
 
 typedef struct { int64_t seqno; int64_t score; } swa_hit_t;

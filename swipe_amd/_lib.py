@@ -22,7 +22,7 @@ class DbInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("narrow", "wide", "full", "cells")] + \
                [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("narrow_rows", C.c_int32),
-                ("narrow_shifted", C.c_int32), ("loading_parts", C.c_int32), ("reserved", C.c_int32)]
+                ("narrow_shifted", C.c_int32), ("loading_parts", C.c_int32), ("requeue_form", C.c_int32)]
 
 
 class Hit(C.Structure):

@@ -138,6 +138,7 @@ void sum_counters(const std::vector<swa_counters_t>& c, swa_counters_t* out)
     out->total_ms = std::max(out->total_ms, c[i].total_ms);
     if (i == 0 || c[i].narrow_rows > out->narrow_rows) { out->narrow_rows = c[i].narrow_rows; out->narrow_shifted = c[i].narrow_shifted; }
     out->loading_parts += c[i].loading_parts;
+    out->requeue_form = std::max(out->requeue_form, c[i].requeue_form);
   }
 }
 

@@ -219,7 +219,7 @@ struct Options {
   int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
-  int64_t requeue_block = -1;    // device-driven re-queue, a BLOCK of four waves per sequence instead of one wave: -1 when the wave form would have 3+ rows per lane (129..1024 query rows), 0 never, 1 whenever the query fits (<= 1024 rows)
+  int64_t requeue_block = 0;     // device-driven re-queue, a BLOCK of four waves per sequence instead of one wave: 1 whenever the query fits (<= 1024 rows), else never. Off until tools/rq_probe.py has priced its barrier per DP step on hardware
   int64_t requeue_follow = 0;    // (rounds 2-3: a re-queue kernel beside the first pass on a second stream; gone - the key is accepted and ignored)
   int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
   int64_t window_step = 0;       // distance between window starts; 0 = from the query (the overlap is never a knob: it is what makes it exact)
@@ -1382,10 +1382,11 @@ bool device_requeue_ok(const swa_db* db, int64_t qlen)
 
 // the device-driven re-queue behind a first pass: four waves per sequence where that shortens the chain of a step, else one
 hipError_t launch_requeue(const swa_db* db, const swa_seqs& sq, const int32_t* list, const int32_t* count, int32_t* work, const uint8_t* qseq,
-                          int64_t qlen, int* scores, hipStream_t st)
+                          int64_t qlen, int* scores, hipStream_t st, swa_counters_t& c)
 {
   const int kb = swa_requeue_block_rows_for(int(std::min<int64_t>(qlen, 1 << 20)));
-  const bool block = kb > 0 && (db->opt.requeue_block == 1 || (db->opt.requeue_block < 0 && qlen > 128));
+  const bool block = kb > 0 && db->opt.requeue_block == 1;
+  c.requeue_form = block ? 2 : 1;
   if (block)
     return swa_launch_requeue_block(&sq, list, count, REQUEUE_CAP, work, qseq, int(qlen), db->matrix.p, int(db->goe), int(db->ge), scores,
                                     db->cus * 8, st);
@@ -1735,7 +1736,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
   pd.used_bound = used_bound;
   if (c.narrow && device_requeue_ok(db, qlen)) {
     // the list stays on the device: a persistent grid of waves takes entries off it until the count the first pass left
-    HIP_TRY(launch_requeue(db, sq, db->ovf_list.p, db->ctl.p + 1, db->ctl.p + 4, db->qseq_p, qlen, db->scores.p, st));
+    HIP_TRY(launch_requeue(db, sq, db->ovf_list.p, db->ctl.p + 1, db->ctl.p + 4, db->qseq_p, qlen, db->scores.p, st, c));
     pd.dev1 = true;
   } else {
     if (c.narrow) {
@@ -1750,6 +1751,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     }
     rc = run_wide(db, requeue, db->qseq_p, qlen, db->scores.p, db->scores64, &c.wide, &c.full, st);
     if (rc != SWA_OK) return rc;
+    c.requeue_form = 3;
   }
   pd.windows = c.narrow && bsp != &db->main;
   if (pd.windows) { rc = fold_windows(db, false, st); if (rc != SWA_OK) return rc; }
@@ -1966,8 +1968,8 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
   if (!listed) { rc = reserve2(false); if (rc != SWA_OK) return rc; }
   const swa_seqs sq = db->seqs();
   if (listed && device_requeue_ok(db, qlen)) {
-    HIP_TRY(launch_requeue(db, sq, db->ovf_list.p, db->ctl.p + 1, db->ctl.p + 4, db->qseq_p, qa, db->scores.p, st));
-    HIP_TRY(launch_requeue(db, sq, db->ovf_list2.p, db->ctl.p + 3, db->ctl.p + 5, db->qseq2_p, qb, db->scores2.p, st));
+    HIP_TRY(launch_requeue(db, sq, db->ovf_list.p, db->ctl.p + 1, db->ctl.p + 4, db->qseq_p, qa, db->scores.p, st, c));
+    HIP_TRY(launch_requeue(db, sq, db->ovf_list2.p, db->ctl.p + 3, db->ctl.p + 5, db->qseq2_p, qb, db->scores2.p, st, c));
     pd.dev1 = pd.dev2 = true;
   } else {
     if (listed) {
@@ -1987,6 +1989,7 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     if (rc == SWA_OK) rc = run_wide(db, rq2, db->qseq2_p, qb, db->scores2.p, db->scores64b, &c.wide, &full2, st);
     if (rc != SWA_OK) return rc;
     c.full += full2;
+    c.requeue_form = 3;
   }
   pd.windows = listed && windows;
   if (pd.windows) { rc = fold_windows(db, true, st); if (rc != SWA_OK) return rc; }

@@ -353,6 +353,96 @@ def test_requeue_by_batches_and_by_wave(qlen, wave, monkeypatch):
     db.close()
 
 
+def _requeue_heavy_protein(qlen):
+    """a database with 130 relatives of the query that leave the packed range under BLOSUM62 x 5 whatever the query length
+    (so that the re-queue has a real list), a subject of more than 6 000 columns that carries one more, and an empty one"""
+    rtab = synth.residue_table_protein()
+    q = synth._random_residues(9100 + qlen, 1, qlen, rtab)
+    res, off = swipe_amd.synth_db(14, 500, query=q)
+    seqs = [res[off[i]:off[i + 1]] for i in range(500)]
+    rng = np.random.default_rng(qlen)
+    for k in range(130):                                    # 2..10 % of the residues replaced, random flanks of random length
+        rel = q.copy()
+        m = rng.random(qlen) < 0.02 * (1 + k % 5)
+        rel[m] = rtab[rng.integers(0, len(rtab), int(m.sum()))]
+        seqs.insert(int(rng.integers(0, len(seqs))), np.concatenate([synth._random_residues(k, 1, int(rng.integers(0, 120)), rtab), rel,
+                                                                     synth._random_residues(k + 300, 1, int(rng.integers(0, 120)), rtab)]))
+    rel = q.copy()
+    rel[::7] = rtab[(np.arange(len(rel[::7])) * 131) % len(rtab)]
+    long_one = np.concatenate([synth._random_residues(6, 1, 3100, rtab), rel, synth._random_residues(7, 1, 3100, rtab)])
+    seqs += [q, q[::-1].copy(), np.concatenate([q, q]), q[: qlen // 2].copy(), long_one, np.zeros(0, np.uint8), q[:1].copy()]
+    return q, oracle.pack(seqs)
+
+
+@pytest.mark.late
+@pytest.mark.parametrize("qlen", [128, 129, 256, 257, 512, 513, 768, 769, 1024, 1025])
+def test_both_device_requeue_forms_by_name(qlen):
+    """VERDICT r5 item 3 / ADVICE r5: the two forms of the device-driven re-queue (search16's role, search16.cc:320-546, behind
+    the escalation of swipe.cc:1492-1538) pinned by the option that selects them: requeue_block = 0 is
+    swa_requeue_wave_kernel (one wave per re-queued sequence), requeue_block = 1 swa_requeue_block_kernel (four waves,
+    queries of at most 1 024 rows; beyond that the wave form whatever the option says).  Every boundary of both kernels'
+    rows-per-lane tables, at least 100 entries on the list, a subject of 6 000+ columns and an empty one: scores equal the
+    oracle's, the two forms' hit lists are identical, and counters.requeue_form says which kernel ran."""
+    q, (r2, o2) = _requeue_heavy_protein(qlen)
+    M5 = swipe_amd.matrix_builtin("BLOSUM62") * 5
+    want = oracle.search_all63(r2, o2, q, oracle.matrix_builtin("BLOSUM62") * 5, 12, 1, threads=THREADS)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    db.set_scoring(M5, 11, 1)
+    lists = []
+    for form in (0, 1):
+        db.set_option("requeue_block", form)
+        scores, c = db.search(q)
+        assert c["requeue_form"] == (2 if form == 1 and qlen <= 1024 else 1), (qlen, form, c)
+        assert c["wide"] >= 100 and c["full"] == 0, (qlen, form, c)
+        assert np.array_equal(scores, want), (qlen, form, np.flatnonzero(scores != want)[:10])
+        hits, tot, obv, ct = db.search_topk(q, keep=60, minscore=200, maxscore=int(want.max()) - 1)
+        assert ct["requeue_form"] == c["requeue_form"]
+        assert (hits, tot, obv) == _expected_topk(want, 60, 200, int(want.max()) - 1), (qlen, form)
+        lists.append((hits, tot, obv))
+    assert lists[0] == lists[1]
+    db.set_option("requeue_block", None)
+    assert db.search(q)[1]["requeue_form"] == 1          # the default is the form that has been measured on hardware
+    db.close()
+
+
+@pytest.mark.late
+@pytest.mark.parametrize("qlen", [129, 1000, 1024])
+def test_both_device_requeue_forms_two_query_path(qlen):
+    """the same pin for the two-query path (both strands of a nucleotide query, swipe.cc:1403): each strand has a list of its
+    own and a re-queue launch of its own - both lists at least 100 entries long, both forms, scores of both strands equal
+    the oracle's"""
+    rtab = synth.residue_table_nucleotide()
+    q = synth._random_residues(77 + qlen, 1, qlen, rtab)
+    qm = blastdb.revcomp_nt16(q)
+    res, off = swipe_amd.synth_db(4, 300, protein=False)
+    seqs = [res[off[i]:off[i + 1]] for i in range(300)]
+    rng = np.random.default_rng(qlen)
+    for k in range(220):                                    # relatives of either strand, inside random flanks of random length
+        rel = (q if k % 2 == 0 else qm).copy()
+        m = rng.random(qlen) < 0.01 * (1 + k % 5)
+        rel[m] = rtab[rng.integers(0, 4, int(m.sum()))]
+        seqs.append(np.concatenate([synth._random_residues(k, 1, int(rng.integers(0, 150)), rtab), rel, synth._random_residues(k + 500, 1, int(rng.integers(0, 150)), rtab)]))
+    seqs += [np.concatenate([synth._random_residues(3, 1, 3000, rtab), q, synth._random_residues(4, 1, 3200, rtab)]), np.zeros(0, np.uint8), q[:1].copy()]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2, symtype=0)
+    db.set_scoring(swipe_amd.matrix_nucleotide(19, -20), 30, 8)        # a match of 19 takes a relative out of the packed range at 129 rows already
+    Mo = oracle.matrix_nucleotide(19, -20)
+    w1 = oracle.search_all63(r2, o2, q, Mo, 38, 8, threads=THREADS)
+    w2 = oracle.search_all63(r2, o2, qm, Mo, 38, 8, threads=THREADS)
+    want = sorted([(int(s), i, 0) for i, s in enumerate(w1) if s >= 300] + [(int(s), i, 1) for i, s in enumerate(w2) if s >= 300], key=lambda t: (-t[0], -t[1], t[2]))[:80]
+    got = []
+    for form in (0, 1):
+        db.set_option("requeue_block", form)
+        s1, s2, c = db.search2(q, qm)
+        assert c["requeue_form"] == (2 if form == 1 else 1) and c["wide"] >= 200 and c["full"] == 0, (qlen, form, c)
+        assert np.array_equal(s1, w1) and np.array_equal(s2, w2), (qlen, form)
+        hits, tot, obv, _ = db.search2_topk(q, qm, keep=80, minscore=300)
+        assert hits == [(i, s, w) for s, i, w in want], (qlen, form)
+        got.append((hits, tot, obv))
+    assert got[0] == got[1]
+    db.close()
+
+
 def test_bound_build_is_dropped_when_too_much_comes_back(monkeypatch):
     """auto mode: the bound build runs only for thresholds well above its slack, and a search that sends more than 2 % of
     the sequences back switches it off for that query length at thresholds up to that one, until the scoring system

@@ -55,6 +55,8 @@ ROUND5_SLICE = [
     ("tests/test_gpu_parity.py", "requeue_by_batches_and_by_wave and 600"),
     # .nsq ambiguity tables in both forms against the reference's own output (tests/golden/ntamb.json): old reader, loader, budget
     ("tests/test_gpu_parity.py", "cli_nucleotide_ambiguity_tables_equal_reference_cli"),
+    # round 6: both forms of the device-driven re-queue pinned by the option that selects them
+    ("tests/test_gpu_parity.py", "both_device_requeue_forms and (129 or 256 or 257 or 1024 or 1025)"),
 ]
 
 
@@ -192,3 +194,73 @@ def test_drain_experiment_root_cause_stays_settled(tmp_path):
     print("drain experiment under the interpreter (wrong of 64):", res)
     assert res[("fixed", "0")] == 0 and res[("fixed", "3")] == 0, res
     assert res[("inline", "0")] == res[("inline", "3")], res        # whatever it is, it does not depend on how many waves take part
+
+
+_STREAM_ORDER = r"""
+import ctypes, sys
+H = ctypes.CDLL(sys.argv[1])
+edge = sys.argv[2] == "edge"
+N = 4096
+vp = ctypes.c_void_p
+for f in ("hipMalloc", "hipHostMalloc", "hipStreamCreateWithFlags", "hipEventCreate", "hipMemsetAsync", "hipMemcpyAsync", "hipEventRecord",
+          "hipStreamWaitEvent", "hipStreamSynchronize", "hipDeviceSynchronize", "hipMemset", "hipMemcpy"):
+    getattr(H, f).restype = ctypes.c_int
+H.hipMemsetAsync.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
+H.hipMemcpyAsync.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, vp]
+H.hipMemcpy.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int]
+H.hipMemset.argtypes = [vp, ctypes.c_int, ctypes.c_size_t]
+H.hipEventRecord.argtypes = [vp, vp]
+H.hipStreamWaitEvent.argtypes = [vp, vp, ctypes.c_uint]
+H.hipStreamSynchronize.argtypes = [vp]
+dev, out, a, b, ev = vp(), vp(), vp(), vp(), vp()
+assert H.hipMalloc(ctypes.byref(dev), N) == 0 and H.hipHostMalloc(ctypes.byref(out), N, 0) == 0
+assert H.hipStreamCreateWithFlags(ctypes.byref(a), 1) == 0 and H.hipStreamCreateWithFlags(ctypes.byref(b), 1) == 0      # hipStreamNonBlocking
+assert H.hipEventCreate(ctypes.byref(ev)) == 0
+assert H.hipMemset(dev, 0x22, N) == 0
+ctypes.memset(out, 0, N)
+# producer on stream a, consumer on stream b: without the event edge nothing orders the copy behind the memset
+H.hipMemsetAsync(dev, 0x11, N, a)
+if edge:
+    H.hipEventRecord(ev, a)
+    H.hipStreamWaitEvent(b, ev, 0)
+H.hipMemcpyAsync(out, dev, N, 2, b)          # device to host
+assert H.hipStreamSynchronize(b) == 0
+first = ctypes.string_at(out, N)
+H.hipDeviceSynchronize()
+# a host source is read when the copy EXECUTES: rewriting it before the synchronisation changes what arrives
+src = ctypes.create_string_buffer(b"\x33" * N, N)
+H.hipMemcpyAsync(dev, src, N, 1, a)          # host to device
+ctypes.memset(src, 0x44, N)
+H.hipStreamSynchronize(a)
+H.hipMemcpy(out, dev, N, 2)
+second = ctypes.string_at(out, N)
+print("consumer", "fresh" if first == b"\x11" * N else "stale", "source", "call" if second == b"\x33" * N else "execution")
+"""
+
+
+def test_interpreter_async_mode_shows_a_missing_event_edge(tmp_path):
+    """HIPSIM_ASYNC=<seed> defers launches, memsets and async copies and runs them in a seeded order that
+    only HIP's own ordering promises constrain.  A consumer stream that does not wait for the producer's event reads stale
+    data under at least one policy (the lazy one leaves the producer's stream untouched); with hipEventRecord +
+    hipStreamWaitEvent every policy sees the producer's bytes; an async copy reads its host source at execution time.
+    Without HIPSIM_ASYNC everything runs at the call, as before."""
+    subprocess.run(["make", "-s", "-C", SIM, "libhipsim.so"], check=True, timeout=600)
+    lib = os.path.join(SIM, "libhipsim.so")
+    script = tmp_path / "order.py"
+    script.write_text(_STREAM_ORDER)
+
+    def run(mode, seed):
+        env = dict(os.environ)
+        env.pop("LD_PRELOAD", None)
+        env.pop("HIPSIM_ASYNC", None)
+        if seed is not None:
+            env["HIPSIM_ASYNC"] = str(seed)
+        r = subprocess.run([sys.executable, str(script), lib, mode], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout.split()
+
+    assert run("noedge", None) == ["consumer", "fresh", "source", "call"]          # synchronous streams hide both
+    with_edge = [run("edge", s) for s in (0, 1, 2, 3, 4, 5)]
+    assert all(w[1] == "fresh" and w[3] == "execution" for w in with_edge), with_edge
+    without = [run("noedge", s)[1] for s in (0, 1, 2, 3, 4, 5)]
+    assert "stale" in without and without[1] == "stale", without                   # seed % 3 == 1: the lazy policy

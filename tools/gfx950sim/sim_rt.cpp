@@ -11,6 +11,13 @@
 // n instructions of wave 0 with EXEC / VCC / operands; HIPSIM_LDS_UNDEF=1 a read of an LDS byte no lane of the workgroup has
 // written is a fault; HIPSIM_BACKTRACE=1 host stack on SIGSEGV.  A launch that asks for more LDS per workgroup or VGPRs per
 // SIMD than gfx950 has is refused, as the hardware would.
+// HIPSIM_ASYNC=<seed>: streams become queues. Launches, memsets and async copies are deferred until the host synchronises with
+// something, and are then executed in a seeded order among the streams that only the edges HIP promises constrain: program order
+// inside a stream, hipEventRecord -> hipStreamWaitEvent, the legacy null stream against blocking streams, hipFree as a device
+// synchronisation. hipMemcpyAsync reads its host source (and writes its host destination) when it EXECUTES. seed % 3 picks the
+// policy: 0 uniformly random stream, 1 lazy (only what the wait needs - every other stream is as late as it may be),
+// 2 everything else first. A missing event edge, a host buffer reused under an in-flight copy or a result read before its
+// synchronisation shows as wrong data under at least one policy. Still invisible: the memory model, co-residency, timing.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
@@ -22,10 +29,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <map>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <random>
+#include <set>
 #include <sstream>
 #include "sim_core.h"
 
@@ -65,6 +76,26 @@ struct FatBin {
 hipError_t g_last = hipSuccess;
 
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
+
+// streams and events; with HIPSIM_ASYNC a stream is a queue of operations (see the head of this file)
+struct SimEvent { std::chrono::steady_clock::time_point t; bool recorded; uint64_t ticket; };
+struct Op {
+    enum Kind : uint8_t { LAUNCH, COPY, SET, REC, WAIT } kind = WAIT;
+    sim::Kernel* k = nullptr; uint8_t* ka = nullptr; dim3 grid, block; size_t shmem = 0;                      // LAUNCH
+    void* dst = nullptr; const void* src = nullptr; size_t n = 0; hipMemcpyKind ck = hipMemcpyDefault; int val = 0;   // COPY, SET
+    SimEvent* ev = nullptr; uint64_t ticket = 0;                                                              // REC, WAIT
+};
+struct SimStream { bool blocking; std::deque<Op> q; };
+struct Async {
+    bool on = getenv("HIPSIM_ASYNC") != nullptr;
+    uint64_t seed = on ? strtoull(getenv("HIPSIM_ASYNC"), nullptr, 0) : 0;
+    int policy = (int)(seed % 3);
+    std::mt19937_64 rng{seed * 0x9E3779B97F4A7C15ull + 1};
+    std::set<SimStream*> streams;
+    std::map<uint64_t, SimStream*> pending;   // ticket of a record that has not executed -> the stream it is queued on
+    uint64_t next_ticket = 0;
+};
+Async& A() { static Async* a = new Async; return *a; }
 thread_local std::vector<CallCfg> t_cfg;
 
 uint32_t poison() { static uint32_t p = getenv("HIPSIM_POISON") ? (uint32_t)strtoul(getenv("HIPSIM_POISON"), nullptr, 0) : 0xBAD0BAD1u; return p; }
@@ -263,8 +294,10 @@ hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hip
     return hipSuccess;
 }
 
-hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t) {
-    Lock lk(g_mu);
+}  // extern "C"
+
+// Resolve the kernel and snapshot its arguments (HIP copies them at the launch call, whenever the kernel runs).
+static hipError_t prepare_launch(const void* func, dim3 grid, dim3 block, void** args, size_t shmem, Op& op) {
     if (!g_fault.empty()) return fail(hipErrorLaunchFailure);
     auto it = g_funcs.find(func);
     if (it == g_funcs.end()) { fprintf(stderr, "gfx950sim: launch of an unregistered function %p\n", func); return fail(hipErrorInvalidDeviceFunction); }
@@ -295,17 +328,131 @@ hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args,
         else if (a.kind == "hidden_shared_base") put(0x00010000u);
         // remainders, global offsets, printf / hostcall / heap / queue pointers: zero
     }
-    if (env_int("HIPSIM_TRACE", 0))
-        fprintf(stderr, "gfx950sim: launch %s grid (%u,%u,%u) block (%u,%u,%u) lds %u+%zu\n", k.name.c_str(), grid.x, grid.y, grid.z, block.x, block.y, block.z, k.lds, shmem);
-    std::string f = sim::run_kernel(k, sim::Dim3{grid.x, grid.y, grid.z}, sim::Dim3{block.x, block.y, block.z}, ka, (uint32_t)shmem);
-    dev_free(ka);
-    if (!f.empty()) {
-        g_fault = f;
-        fprintf(stderr, "gfx950sim: DEVICE FAULT: %s\n", f.c_str());
-        if (env_int("HIPSIM_ABORT", 0)) abort();
-        return fail(hipErrorLaunchFailure);
-    }
+    op.kind = Op::LAUNCH; op.k = &k; op.ka = ka; op.grid = grid; op.block = block; op.shmem = shmem;
     return hipSuccess;
+}
+
+static void copy_now(void* dst, const void* src, size_t n) {
+    if (!n) return;
+    memmove(dst, src, n);
+    // defined-ness travels with the bytes
+    uint8_t* ds = sim::mem_ok((uint64_t)(uintptr_t)dst, n) ? sim::mem_shadow((uint64_t)(uintptr_t)dst) : nullptr;
+    if (ds) {
+        uint8_t* ss = sim::mem_ok((uint64_t)(uintptr_t)src, n) ? sim::mem_shadow((uint64_t)(uintptr_t)src) : nullptr;
+        if (ss) memmove(ds, ss, n); else memset(ds, 1, n);
+    }
+}
+static bool copy_ranges_ok(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    bool ok = true;
+    if (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice) ok &= check_dev(dst, n, "copy destination");
+    if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) ok &= check_dev(src, n, "copy source");
+    return ok;
+}
+
+static void exec_op(Op& op) {
+    switch (op.kind) {
+    case Op::LAUNCH: {
+        sim::Kernel& k = *op.k;
+        if (g_fault.empty()) {
+            if (env_int("HIPSIM_TRACE", 0))
+                fprintf(stderr, "gfx950sim: launch %s grid (%u,%u,%u) block (%u,%u,%u) lds %u+%zu\n", k.name.c_str(), op.grid.x, op.grid.y, op.grid.z, op.block.x, op.block.y,
+                        op.block.z, k.lds, op.shmem);
+            std::string f = sim::run_kernel(k, sim::Dim3{op.grid.x, op.grid.y, op.grid.z}, sim::Dim3{op.block.x, op.block.y, op.block.z}, op.ka, (uint32_t)op.shmem);
+            if (!f.empty()) {
+                g_fault = f;
+                fprintf(stderr, "gfx950sim: DEVICE FAULT: %s\n", f.c_str());
+                if (env_int("HIPSIM_ABORT", 0)) abort();
+            }
+        }
+        (void)dev_free(op.ka);
+        break;
+    }
+    case Op::COPY:      // ranges were live at the call; a buffer freed under a queued copy is a fault of its own
+        if (!copy_ranges_ok(op.dst, op.src, op.n, op.ck)) { if (g_fault.empty()) g_fault = "a queued copy ran after its device buffer was freed"; break; }
+        copy_now(op.dst, op.src, op.n);
+        break;
+    case Op::SET:
+        if (!check_dev(op.dst, op.n, "memset")) { if (g_fault.empty()) g_fault = "a queued memset ran after its buffer was freed"; break; }
+        if (op.n) { memset(op.dst, op.val, op.n); uint8_t* ds = sim::mem_shadow((uint64_t)(uintptr_t)op.dst); if (ds) memset(ds, 1, op.n); }
+        break;
+    case Op::REC:
+        if (op.ev) { op.ev->t = std::chrono::steady_clock::now(); op.ev->recorded = true; }
+        A().pending.erase(op.ticket);
+        break;
+    case Op::WAIT: break;
+    }
+}
+
+// ---- HIPSIM_ASYNC: the scheduler ----
+static bool runnable(SimStream* s) { return !s->q.empty() && !(s->q.front().kind == Op::WAIT && A().pending.count(s->q.front().ticket)); }
+static void step(SimStream* s) { Op op = s->q.front(); s->q.pop_front(); exec_op(op); }
+// One scheduling decision. `goal`: the stream whose progress the caller waits for (nullptr: any). false = nothing can run.
+static bool advance(SimStream* goal, int policy) {
+    std::vector<SimStream*> run;
+    for (SimStream* s : A().streams) if (runnable(s)) run.push_back(s);
+    if (run.empty()) return false;
+    SimStream* need = goal;                       // follow the event edges to the stream that can make the goal move
+    for (int hop = 0; need && !runnable(need) && hop < 64; hop++) {
+        if (need->q.empty()) { need = nullptr; break; }
+        auto it = A().pending.find(need->q.front().ticket);
+        need = it == A().pending.end() ? nullptr : it->second;
+    }
+    if (need && !runnable(need)) need = nullptr;
+    auto any = [&](std::vector<SimStream*>& v) { return v[A().rng() % v.size()]; };
+    SimStream* pick;
+    if (policy == 1 && need) pick = need;
+    else if (policy == 2 && need) {
+        std::vector<SimStream*> others;
+        for (SimStream* s : run) if (s != need) others.push_back(s);
+        pick = others.empty() ? need : any(others);
+    } else pick = any(run);
+    step(pick);
+    return true;
+}
+static void stuck(const char* what) {
+    if (g_fault.empty()) g_fault = std::string("gfx950sim: deadlock: ") + what + " waits on an event whose record can never run";
+    fprintf(stderr, "%s\n", g_fault.c_str());
+    for (SimStream* s : A().streams) s->q.clear();
+    A().pending.clear();
+}
+static void drain_stream(SimStream* s) { while (!s->q.empty()) if (!advance(s, A().policy)) { stuck("a stream"); break; } }
+static void wait_ticket(uint64_t t) {
+    for (;;) {
+        auto it = A().pending.find(t);
+        if (it == A().pending.end()) break;
+        if (!advance(it->second, A().policy)) { stuck("an event synchronisation"); break; }
+    }
+}
+static void drain_all() {
+    for (;;) {
+        bool left = false;
+        for (SimStream* s : A().streams) left |= !s->q.empty();
+        if (!left) break;
+        if (!advance(nullptr, 0)) { stuck("a device synchronisation"); break; }
+    }
+}
+// the legacy null stream: an operation on it starts after everything already queued on the blocking streams
+static void drain_blocking() {
+    std::vector<SimStream*> b;
+    for (SimStream* s : A().streams) if (s->blocking) b.push_back(s);
+    std::shuffle(b.begin(), b.end(), A().rng);
+    for (SimStream* s : b) drain_stream(s);
+}
+static hipError_t submit(hipStream_t h, Op& op) {
+    if (!A().on) { exec_op(op); return sync_status(); }
+    if (!h) { drain_blocking(); exec_op(op); return sync_status(); }
+    ((SimStream*)h)->q.push_back(op);
+    return hipSuccess;
+}
+
+extern "C" {
+
+hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t stream) {
+    Lock lk(g_mu);
+    Op op;
+    hipError_t e = prepare_launch(func, grid, block, args, shmem, op);
+    if (e != hipSuccess) return e;
+    return submit(stream, op);
 }
 
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
@@ -369,10 +516,11 @@ hipError_t hipMalloc(void** p, size_t n) {
     *p = dev_alloc(n, false);
     return *p ? hipSuccess : fail(hipErrorOutOfMemory);
 }
-hipError_t hipFree(void* p) { Lock lk(g_mu); return dev_free(p); }
+hipError_t hipFree(void* p) { Lock lk(g_mu); if (A().on && p) drain_all(); return dev_free(p); }      // hipFree synchronises the device
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { Lock lk(g_mu); *p = dev_alloc(n, true); g_allocated -= n ? n : 1; return *p ? hipSuccess : fail(hipErrorOutOfMemory); }
 hipError_t hipHostFree(void* p) {
     Lock lk(g_mu);
+    if (A().on && p) drain_all();
     auto it = g_allocs.find((uint64_t)(uintptr_t)p);
     if (it != g_allocs.end()) g_allocated += it->second.size;
     return dev_free(p);
@@ -383,51 +531,91 @@ hipError_t hipMemGetInfo(size_t* fr, size_t* tot) {
     *tot = cap; *fr = cap > g_allocated ? cap - g_allocated : 0;
     return hipSuccess;
 }
-hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t stream) {
     Lock lk(g_mu);
-    bool ok = true;
-    if (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice) ok &= check_dev(dst, n, "copy destination");
-    if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) ok &= check_dev(src, n, "copy source");
-    if (!ok) return fail(hipErrorInvalidValue);
-    if (n) memmove(dst, src, n);
-    if (n) {       // defined-ness travels with the bytes
-        uint8_t* ds = sim::mem_ok((uint64_t)(uintptr_t)dst, n) ? sim::mem_shadow((uint64_t)(uintptr_t)dst) : nullptr;
-        if (ds) {
-            uint8_t* ss = sim::mem_ok((uint64_t)(uintptr_t)src, n) ? sim::mem_shadow((uint64_t)(uintptr_t)src) : nullptr;
-            if (ss) memmove(ds, ss, n); else memset(ds, 1, n);
-        }
-    }
-    return sync_status();
+    if (!copy_ranges_ok(dst, src, n, kind)) return fail(hipErrorInvalidValue);
+    Op op; op.kind = Op::COPY; op.dst = dst; op.src = src; op.n = n; op.ck = kind;
+    return submit(stream, op);
 }
-hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t) { return hipMemcpy(dst, src, n, kind); }
-hipError_t hipMemset(void* dst, int v, size_t n) {
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) { return hipMemcpyAsync(dst, src, n, kind, nullptr); }   // null stream, and the host waits
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t stream) {
     Lock lk(g_mu);
     if (!check_dev(dst, n, "memset")) return fail(hipErrorInvalidValue);
-    if (n) memset(dst, v, n);
-    if (n) { uint8_t* ds = sim::mem_shadow((uint64_t)(uintptr_t)dst); if (ds) memset(ds, 1, n); }
+    Op op; op.kind = Op::SET; op.dst = dst; op.val = v; op.n = n;
+    return submit(stream, op);
+}
+hipError_t hipMemset(void* dst, int v, size_t n) { return hipMemsetAsync(dst, v, n, nullptr); }
+
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags) {
+    Lock lk(g_mu);
+    SimStream* st = new SimStream{(flags & hipStreamNonBlocking) == 0, {}};
+    A().streams.insert(st);
+    *s = (hipStream_t)st;
+    return hipSuccess;
+}
+hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
+hipError_t hipStreamDestroy(hipStream_t s) {
+    Lock lk(g_mu);
+    SimStream* st = (SimStream*)s;
+    if (!st || !A().streams.count(st)) return fail(hipErrorInvalidValue);
+    drain_stream(st);                        // queued work completes; the handle is gone at once
+    A().streams.erase(st);
+    delete st;
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) {
+    Lock lk(g_mu);
+    if (A().on) { if (s) drain_stream((SimStream*)s); else drain_blocking(); }
     return sync_status();
 }
-hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { return hipMemset(dst, v, n); }
-
-hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
-hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
-hipError_t hipStreamDestroy(hipStream_t s) { free((void*)s); return hipSuccess; }
-hipError_t hipStreamQuery(hipStream_t) { Lock lk(g_mu); return sync_status(); }
-hipError_t hipStreamSynchronize(hipStream_t) { Lock lk(g_mu); return sync_status(); }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipDeviceSynchronize() { dump_stats(); Lock lk(g_mu); return sync_status(); }
+hipError_t hipStreamQuery(hipStream_t s) {
+    Lock lk(g_mu);
+    if (A().on && s && !((SimStream*)s)->q.empty()) { advance(nullptr, 0); if (!((SimStream*)s)->q.empty()) return hipErrorNotReady; }
+    return sync_status();
+}
+hipError_t hipDeviceSynchronize() { dump_stats(); Lock lk(g_mu); if (A().on) drain_all(); return sync_status(); }
 hipError_t hipDeviceReset() { return hipSuccess; }
 
-struct SimEvent { std::chrono::steady_clock::time_point t; bool recorded; };
-hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t) new SimEvent{std::chrono::steady_clock::now(), false}; return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t) new SimEvent{std::chrono::steady_clock::now(), false, 0}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
-hipError_t hipEventDestroy(hipEvent_t e) { delete (SimEvent*)e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { auto* s = (SimEvent*)e; s->t = std::chrono::steady_clock::now(); s->recorded = true; return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { Lock lk(g_mu); return sync_status(); }
-hipError_t hipEventQuery(hipEvent_t) { Lock lk(g_mu); return sync_status(); }
+hipError_t hipEventDestroy(hipEvent_t e) {
+    Lock lk(g_mu);
+    for (SimStream* s : A().streams) for (Op& op : s->q) if (op.ev == (SimEvent*)e) op.ev = nullptr;     // a queued record still completes its ticket
+    delete (SimEvent*)e;
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t stream) {
+    Lock lk(g_mu);
+    Op op; op.kind = Op::REC; op.ev = (SimEvent*)e;
+    if (A().on) {
+        op.ticket = op.ev->ticket = ++A().next_ticket;
+        if (stream) A().pending[op.ticket] = (SimStream*)stream;
+    }
+    (void)submit(stream, op);
+    return hipSuccess;
+}
+// the wait is for the record that was the event's latest when this call was made (none yet: no wait)
+hipError_t hipStreamWaitEvent(hipStream_t stream, hipEvent_t e, unsigned) {
+    Lock lk(g_mu);
+    if (!A().on) return hipSuccess;
+    uint64_t t = ((SimEvent*)e)->ticket;
+    if (!t || !A().pending.count(t)) return hipSuccess;
+    if (!stream) { drain_blocking(); wait_ticket(t); return hipSuccess; }
+    Op op; op.kind = Op::WAIT; op.ticket = t;
+    ((SimStream*)stream)->q.push_back(op);
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) { Lock lk(g_mu); if (A().on) wait_ticket(((SimEvent*)e)->ticket); return sync_status(); }
+hipError_t hipEventQuery(hipEvent_t e) {
+    Lock lk(g_mu);
+    if (A().on && A().pending.count(((SimEvent*)e)->ticket)) { advance(nullptr, 0); if (A().pending.count(((SimEvent*)e)->ticket)) return hipErrorNotReady; }
+    return sync_status();
+}
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    Lock lk(g_mu);
     auto* x = (SimEvent*)a; auto* y = (SimEvent*)b;
+    if (A().on && (A().pending.count(x->ticket) || A().pending.count(y->ticket))) return hipErrorNotReady;
     double d = std::chrono::duration<double, std::milli>(y->t - x->t).count();
     *ms = (float)(d > 1e-6 ? d : 1e-6);
     return hipSuccess;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything that wants an MI355X, in one gpurun call, most important first; every step under its own timeout (a hang costs one
-# step, not the call):   bash tools/round5_gpu.sh [steps...]     steps: tests bench stats pmc first redzones rq dropin dasan (default: all)
-# Output under gpurun_out/r05/ (merged back by gpurun); copy what is to be judged into profiles/r05_*.
+# step, not the call):   bash tools/round6_gpu.sh [steps...]     steps: tests bench stats pmc first redzones rq dropin dasan (default: all)
+# Output under gpurun_out/r06/ (merged back by gpurun); copy what is to be judged into profiles/r06_*.
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/r06; mkdir -p $O
 export SWA_WATCHDOG_S=60
 STEPS="${*:-tests bench stats pmc first redzones rq dropin dasan}"
 for s in $STEPS; do

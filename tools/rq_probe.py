@@ -2,7 +2,7 @@
 own time (HIP events), for the builds the verdict names - the 47-row bound build (375 aa), the 52-row build (416 aa) and the
 63-row two-query nucleotide build (1 kb, both strands) - on the 10 M-sequence database and on a 1.25 M-sequence shard (what one
 of 8 GPUs holds), with the re-queue worked off a wave per sequence (requeue_block=0) and a block of four waves per sequence
-(requeue_block=1).  Hit lists of the two forms must be identical.  Run by tools/round5_gpu.sh rq.
+(requeue_block=1).  Hit lists of the two forms must be identical.  Run by tools/round6_gpu.sh rq.
 
     python tools/rq_probe.py [--quick]        (--quick: 1 M / 125 k sequences, for a first look)
 """
