@@ -526,7 +526,8 @@ swa_unterminate(const uint8_t* __restrict__ chunk, long long c0, long long c1, c
 // bases.  Output: the shard's 4-bit residue array (one-hot A=1 C=2 G=4 T=8, or the ambiguity code), residue i in byte i >> 1,
 // low nibble first, whatever sequence it belongs to.  One wave per sequence; a lane takes one output dword (8 bases).  The
 // first and the last dword of a sequence may be shared with its neighbours: those are OR-ed into the array, which the loader
-// zeroed; the dwords in between are stored.  Ambiguity runs follow behind a fence, nibble by nibble (AND out, OR in).
+// zeroed; the dwords in between are stored.  Ambiguity runs follow behind a fence, nibble by nibble (AND out, OR in), with the
+// reference's last-writer-wins order where runs overlap.
 extern "C" __global__ void __launch_bounds__(256)
 swa_unpack_nt(const uint8_t* __restrict__ chunk, long long c0, const int64_t* __restrict__ raw, const int64_t* __restrict__ offsets,
               int s0, int n, uint8_t* __restrict__ residues)
@@ -558,19 +559,45 @@ swa_unpack_nt(const uint8_t* __restrict__ chunk, long long c0, const int64_t* __
       const unsigned hdr = ((unsigned)a[0] << 24) | ((unsigned)a[1] << 16) | ((unsigned)a[2] << 8) | a[3];
       const int esize = (hdr >> 31) ? 8 : 4;
       const int64_t nent = (abytes - 4) / esize;
-      for (int64_t e = lane; e < nent; e += 64) {
+      auto entry = [&](int64_t e, unsigned& code, int64_t& run, int64_t& off) {
         const uint8_t* q = a + 4 + e * esize;
         unsigned long long v = 0;
         for (int b = 0; b < esize; ++b) v = (v << 8) | q[b];
-        unsigned code;
-        int64_t run, off;
         if (esize == 8) { code = (unsigned)(v >> 60); run = (int64_t)((v >> 48) & 0xfff) + 1; off = (int64_t)(v & 0x0000fffffffffffULL); }
         else { code = (unsigned)(v >> 28) & 15u; run = (int64_t)((v >> 24) & 0xf) + 1; off = (int64_t)(v & 0x00ffffff); }
+      };
+      auto apply = [&](unsigned code, int64_t run, int64_t off) {
         for (int64_t r = 0; r < run && off + r < len; ++r) {
           const int64_t g = o + off + r;
           const int sh = 4 * (int)(g & 7);
           atomicAnd(out + (g >> 3), ~(15u << sh));
           atomicOr(out + (g >> 3), code << sh);
+        }
+      };
+      // The reference applies the entries one after the other, so where runs overlap the last one in the file wins
+      // (database.cc:1296-1321).  Formatters write them ascending and disjoint, and then the order does not matter: a lane per
+      // entry.  A table that is not (an entry that starts before its predecessor ends) is applied by ONE lane, in file order.
+      bool disorder = false;
+      for (int64_t e = lane + 1; e < nent; e += 64) {
+        unsigned c0_, c1_;
+        int64_t r0, o0, r1, o1;
+        entry(e - 1, c0_, r0, o0);
+        entry(e, c1_, r1, o1);
+        disorder |= o1 < o0 + r0;
+      }
+      if (__ballot(disorder) == 0) {
+        for (int64_t e = lane; e < nent; e += 64) {
+          unsigned code;
+          int64_t run, off;
+          entry(e, code, run, off);
+          apply(code, run, off);
+        }
+      } else if (lane == 0) {
+        for (int64_t e = 0; e < nent; ++e) {
+          unsigned code;
+          int64_t run, off;
+          entry(e, code, run, off);
+          apply(code, run, off);
         }
       }
     }

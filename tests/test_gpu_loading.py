@@ -7,6 +7,8 @@ Every test drives the C ABI (through swipe_amd/_lib.py); the loader is slowed do
 (SWA_LOAD_PART / SWA_LOAD_CHUNK / SWA_LOAD_DELAY_MS, read when the open begins) so that the searches provably start while
 parts are still missing."""
 import os
+import struct
+import sys
 
 import numpy as np
 import pytest
@@ -14,6 +16,7 @@ import pytest
 import oracle
 import swipe_amd
 from swipe_amd import blastdb, synth
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -335,6 +338,70 @@ def _pack_nucleotide_new_format(codes):
             i += 1
     table = b"" if not entries else struct.pack(">I", 0x80000000 | (2 * len(entries))) + b"".join(struct.pack(">Q", e) for e in entries)
     return body, table
+
+
+def _apply_table_in_file_order(codes, table):
+    """the residues a .nsq entry stands for: its one-hot bases with the ambiguity entries applied one after the other, the last
+    writer wins (database.cc:1296-1321); runs are cut at the end of the sequence"""
+    out = np.asarray(codes, dtype=np.uint8).copy()
+    out[~np.isin(out, (1, 2, 4, 8))] = 1                      # what the 2-bit body holds under an ambiguity code: A
+    if table:
+        big = (struct.unpack(">I", table[:4])[0] >> 31) != 0
+        es = 8 if big else 4
+        for i in range(4, len(table), es):
+            v = int.from_bytes(table[i:i + es], "big")
+            code, run, pos = (v >> 60, ((v >> 48) & 0xfff) + 1, v & 0xfffffffffff) if big else (v >> 28, ((v >> 24) & 15) + 1, v & 0xffffff)
+            out[pos:pos + run] = code
+    return out
+
+
+@pytest.mark.late
+def test_nucleotide_ambiguity_runs_that_overlap_are_applied_in_file_order(tmp_path, monkeypatch):
+    """VERDICT r5 item 6 / ADVICE r5: the reference applies a sequence's ambiguity entries in file order, so where runs overlap the
+    last one wins (database.cc:1296-1321).  Tables written back to front, with runs that overlap each other, in both table
+    forms: every base from the old reader (host), from the pipelined open (swa_unpack_nt on the device) and from a shard over
+    its HBM budget equals the entries applied one after the other.  (tests/golden/ntamb_overlap.json is the same thing through
+    the reference's own output.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_ntamb_golden as G
+    rng = np.random.default_rng(29)
+    acgt = np.array([1, 2, 4, 8], np.uint8)
+    seqs = []
+    for k in range(700):
+        n = int(rng.integers(30, 900))
+        sq = acgt[rng.integers(0, 4, n)]
+        for _ in range(int(rng.integers(0, 4))):                   # a few ambiguous runs; the wrapper adds the overlapping ones
+            a = int(rng.integers(2, n - 20))
+            sq[a:a + int(rng.integers(1, 18))] = int(rng.choice([3, 5, 6, 9, 10, 12, 14, 15]))
+        seqs.append(sq)
+    packs = {"old": G.disordered(blastdb.pack_nucleotide), "new": G.disordered(lambda c: _pack_nucleotide_new_format(c))}
+    half = len(seqs) // 2
+    want = [_apply_table_in_file_order(sq, packs["old" if k < half else "new"](sq)[1]) for k, sq in enumerate(seqs)]
+    assert sum(1 for w, sq in zip(want, seqs) if not np.array_equal(w, sq)) > 100        # the overlaps do change bases
+    a, b = str(tmp_path / "va"), str(tmp_path / "vb")
+    monkeypatch.setattr(blastdb, "pack_nucleotide", packs["old"])
+    blastdb.write_volume(a, seqs[:half], protein=False, ids=[f"s{i}" for i in range(half)])
+    monkeypatch.setattr(blastdb, "pack_nucleotide", packs["new"])
+    blastdb.write_volume(b, seqs[half:], protein=False, ids=[f"s{i}" for i in range(half, len(seqs))])
+    monkeypatch.undo()
+    base = str(tmp_path / "ovl")
+    blastdb.write_alias(base, [a, b], protein=False)
+    tiny = dict(SWA_LOAD_PART=1 << 14, SWA_LOAD_CHUNK=1 << 12, SWA_LOAD_THREADS=3)
+    for how in ("old reader", "loader", "budget"):
+        if how == "old reader":
+            with _Env(SWA_PIPELINED=0):
+                d = swipe_amd.Database.open(base, symtype=0)
+        elif how == "loader":
+            with _Env(**tiny):
+                d = swipe_amd.Database.open(base, symtype=0)
+        else:
+            with _Env(SWA_STREAM_RESERVE=4096):
+                d = swipe_amd.Database.open(base, symtype=0, hbm_budget=150_000)
+        try:
+            for k in range(len(seqs)):
+                assert np.array_equal(d.sequence(k), want[k]), (how, k)
+        finally:
+            d.close()
 
 
 @pytest.mark.late

@@ -1763,18 +1763,21 @@ def test_bench_default_line_carries_configs_3_and_4_as_secondary_sections():
 
 
 @pytest.mark.late
+@pytest.mark.parametrize("golden", ["ntamb", "ntamb_overlap"])
 @pytest.mark.parametrize("how", ["resident", "streaming in", "budget"])
-def test_cli_nucleotide_ambiguity_tables_equal_reference_cli(tmp_path, how):
+def test_cli_nucleotide_ambiguity_tables_equal_reference_cli(tmp_path, how, golden):
     """tests/golden/ntamb.json (make_ntamb_golden.py): .nsq ambiguity tables in both forms of the format (32-bit entries in one
     volume, 64-bit entries in the other; database.cc:1284-1323), the query planted on both strands across the ambiguous runs -
     the unmodified reference's -m 8 / -m 0 / -m 7 output, byte for byte, from the old reader, from the pipelined open with the
-    device-side unpack (chunks of 4 KiB: entries cut everywhere a chunk may end) and from a shard over its HBM budget"""
+    device-side unpack (chunks of 4 KiB: entries cut everywhere a chunk may end) and from a shard over its HBM budget.
+    ntamb_overlap (round 6): the same database with its tables written back to front and runs that overlap inside the planted
+    query - the reference applies entries in file order, the last writer wins (database.cc:1296-1321)"""
     import subprocess
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_ntamb_golden as G
-    g = load_golden("ntamb")
-    base, qf, sha = G.build(str(tmp_path))
+    g = load_golden(golden)
+    base, qf, sha = G.build(str(tmp_path), overlap=golden == "ntamb_overlap")
     assert sha == g["sha1_of_volumes"]                              # the same bytes the reference searched
     env = dict(os.environ)
     extra = []
