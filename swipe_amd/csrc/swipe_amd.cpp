@@ -410,7 +410,7 @@ int streamed_all_scores(swa_db* front, const uint8_t* query, int64_t qlen, int64
 int streamed_by_owner(swa_db* front, const int64_t* seqnos, int64_t n, const std::function<int(swa_db*, const std::vector<int64_t>&)>& fn);
 int settle_loading(swa_db* db, bool wait, bool* still, bool explicit_wait = false);
 void release_loader_leftovers(swa_db* db);
-int apply_inclusion(swa_db* db, const uint8_t* include, int64_t n);
+int apply_inclusion(swa_db* db, const uint8_t* include, int64_t n, bool release_now = true);
 size_t loading_hbm(const swa_db* db);
 // entry points that want ONE resident shard: not for streamed handles; a shard that is still loading is waited for
 int loaded(swa_db* db)
@@ -2350,12 +2350,12 @@ try {
 } SWA_CATCH
 
 namespace {
-int apply_inclusion(swa_db* db, const uint8_t* include, int64_t n)
+int apply_inclusion(swa_db* db, const uint8_t* include, int64_t n, bool release_now)
 {
   const int64_t real = db->nseq / db->frames;
   if (include && n != real) return fail(SWA_EINVAL, "inclusion array must have one entry per sequence of the shard");
   HIP_TRY(hipSetDevice(db->device));
-  release_loader_leftovers(db);
+  if (release_now) release_loader_leftovers(db);      // not from a search that adopts a masked shard on its way (sw_loading.inc)
   std::vector<int32_t> in, ex;
   db->active_sym = 0;
   for (int64_t v = 0; v < db->nseq; ++v) {
