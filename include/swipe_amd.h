@@ -139,7 +139,9 @@ SWA_API int swa_db_open_async(const char* basename, int symtype, int device,
                       int64_t first_seqno, int64_t last_seqno, swa_db** out);
 SWA_API int swa_db_wait(swa_db* db);      /* blocks until the shard is resident; the load's status */
 /* how far the load is: bytes of sequence file handed to the copy engine / in all, parts searchable / in all (all zero on a
-   handle that is not loading, or no longer) */
+   handle that is not loading, or no longer).  A shard over its HBM budget (swa_db_open_streamed, whose parts are filled behind
+   the open): page-locked bytes of the parts that are in place / of all parts, parts in place / in all - these stay when the
+   load is through, the parts do.  swa_db_wait on such a handle blocks until every part is in place. */
 SWA_API int swa_db_load_progress(swa_db* db, int64_t* bytes_loaded, int64_t* bytes_total, int32_t* parts_ready, int32_t* parts_total);
 /* Same from host arrays: sequence s = residues[offsets[s] .. offsets[s+1]) in reference symbol
    codes.  total_* describe the whole database when this is one shard of it (pass 0 to use
@@ -169,7 +171,13 @@ SWA_API int swa_db_from_memory_translated(const uint8_t* nt_residues, const int6
    The budget covers what the default searches use: the two slots with their residues, tables and first-pass stream.  What a
    part does not carry is built per part and search OUTSIDE it: the pair stream of a nucleotide part for a single-strand
    search, the 16-bit stream for a matrix that scores the padding symbol, window views of very long sequences, 64-bit
-   score arrays.  Opening holds the database twice in host memory for a moment (the caller's arrays + the page-locked parts). */
+   score arrays.  swa_db_from_memory_streamed holds the database twice in host memory for a moment (the caller's arrays + the
+   page-locked parts).  swa_db_open_streamed does not (round 6; the reference maps only what it is about to search,
+   db_mapsequences, database.cc:1082-1131): it returns once the index is read and the parts are planned, and a loader thread
+   fills the parts' page-locked blocks behind it, in the order the first search walks them, straight out of the sequence
+   files (nucleotide entries unpacked and their ambiguity runs applied on its reader threads) - no copy of the database in
+   ordinary host memory.  A search that arrives early binds each part when it is in place; swa_db_wait /
+   swa_db_load_progress report the load; a load error is returned by the call that needs the part. */
 SWA_API int swa_db_from_memory_streamed(const uint8_t* residues, const int64_t* offsets, int64_t nseq, int symtype, int device,
                                 int64_t first_seqno, int64_t total_seqcount, int64_t total_symcount,
                                 int64_t hbm_budget_bytes, swa_db** out);

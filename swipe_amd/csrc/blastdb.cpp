@@ -267,55 +267,60 @@ struct BlastDb {
 };
 }  // namespace
 
-int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out)
-{
+// ---------------------------------------------------------------------------------------------------------------------
+// A range of a database opened for reading piece by piece.  read_blast_db takes the whole range in one go; a shard over its
+// HBM budget (swa_db_open_streamed) takes it a part at a time, straight into the part's page-locked block - the reference
+// maps what it is about to search and nothing else (db_mapsequences, database.cc:1082-1131).
+struct swa::RangeReader::Impl {
   BlastDb bd;
-  const int rc_open = bd.open(basename, symtype, nullptr, false);
-  if (rc_open != SWA_OK) return rc_open;
-  const bool protein = bd.protein;
-  const std::vector<Volume>& V = bd.vols;
-  const int64_t nseq = bd.nseq, nsym = bd.nsym, longest = bd.longest;
-  const std::string& title = bd.title;
-  out.masked = bd.memb_bit != 0;
-  out.masked_seqcount = bd.masked_nseq;
-  out.masked_symcount = bd.masked_nsym;
-  out.total_seqcount = nseq;
-  out.total_symcount = nsym;
-  out.longest = longest;
-  out.title = title.empty() ? V[0].title : title;
-  if (first_seqno < 0) first_seqno = 0;
-  if (last_seqno < 0 || last_seqno >= nseq) last_seqno = nseq - 1;
-  out.first_seqno = first_seqno;
-  out.offsets.assign(1, 0);
-  out.residues.clear();
-  out.included.clear();
-  if (last_seqno < first_seqno) return SWA_OK;
-  out.offsets.reserve(size_t(last_seqno - first_seqno + 2));
-
-  // pass 1: lengths -> offsets (and the OID mask), a few threads per volume, each sequence's own slot, then one running sum;
-  // pass 2: the residues, copied / unpacked by a few threads.  Which volume holds the i-th sequence of the range: `first_of`
   struct Span { const Volume* v; int64_t lo, first; };        // volume, its first local sequence in the range, range index of that
   std::vector<Span> spans;
-  const int64_t count = last_seqno - first_seqno + 1;
-  out.offsets.assign(size_t(count) + 1, 0);
-  if (out.masked) out.included.assign(size_t(count), 0);
+};
+swa::RangeReader::RangeReader() : impl(new Impl) {}
+swa::RangeReader::~RangeReader() { delete impl; }
+
+int swa::RangeReader::open(const char* basename, int symtype, int64_t first, int64_t last)
+{
+  BlastDb& bd = impl->bd;
+  const int rc_open = bd.open(basename, symtype, nullptr, false);
+  if (rc_open != SWA_OK) return rc_open;
+  protein = bd.protein;
+  const std::vector<Volume>& V = bd.vols;
+  masked = bd.memb_bit != 0;
+  masked_seqcount = bd.masked_nseq;
+  masked_symcount = bd.masked_nsym;
+  total_seqcount = bd.nseq;
+  total_symcount = bd.nsym;
+  longest = bd.longest;
+  title = bd.title.empty() ? V[0].title : bd.title;
+  if (first < 0) first = 0;
+  if (last < 0 || last >= bd.nseq) last = bd.nseq - 1;
+  first_seqno = first;
+  offsets.assign(1, 0);
+  included.clear();
+  impl->spans.clear();
+  if (last < first) return SWA_OK;
+  // lengths -> offsets (and the OID mask), a few threads per volume, each sequence's own slot, then one running sum
+  const int64_t count = last - first + 1;
+  offsets.assign(size_t(count) + 1, 0);
+  if (masked) included.assign(size_t(count), 0);
   int64_t vbase = 0, done = 0;
   for (const Volume& v : V) {
-    const int64_t lo = first_seqno > vbase ? first_seqno - vbase : 0;
-    const int64_t hi = last_seqno - vbase < v.nseq - 1 ? last_seqno - vbase : v.nseq - 1;
+    const int64_t lo = first > vbase ? first - vbase : 0;
+    const int64_t hi = last - vbase < v.nseq - 1 ? last - vbase : v.nseq - 1;
     vbase += v.nseq;
     if (hi < lo) continue;
     const int64_t cnt = hi - lo + 1;
-    spans.push_back({&v, lo, done});
+    impl->spans.push_back({&v, lo, done});
     const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 16, cnt >> 16}));
     std::vector<int> rcs(size_t(nthreads), SWA_OK);
     std::vector<std::string> errs(static_cast<size_t>(nthreads));
     const size_t vol = size_t(&v - V.data());
     auto walk = [&](int64_t t) {
       for (int64_t k = cnt * t / nthreads; k < cnt * (t + 1) / nthreads; ++k) {
-        const int rc_len = sequence_length(v, protein, lo + k, &out.offsets[size_t(done + k) + 1]);
+        const int rc_len = sequence_length(v, protein, lo + k, &offsets[size_t(done + k) + 1]);
         if (rc_len != SWA_OK) { rcs[size_t(t)] = rc_len; errs[size_t(t)] = swa_last_error(); return; }
-        if (out.masked) out.included[size_t(done + k)] = bd.in_mask(vol, lo + k) ? 1 : 0;
+        if (masked) included[size_t(done + k)] = bd.in_mask(vol, lo + k) ? 1 : 0;
       }
     };
     if (nthreads == 1) walk(0);
@@ -327,27 +332,47 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
     for (int64_t t = 0; t < nthreads; ++t) if (rcs[size_t(t)] != SWA_OK) return swa::fail(rcs[size_t(t)], errs[size_t(t)]);
     done += cnt;
   }
-  for (int64_t i = 0; i < count; ++i) out.offsets[size_t(i) + 1] += out.offsets[size_t(i)];
-  out.residues.resize(size_t(out.offsets.back()));
-  auto fill = [&](size_t from, size_t to) {
-    size_t sp = 0;
-    while (sp + 1 < spans.size() && size_t(spans[sp + 1].first) <= from) ++sp;
-    for (size_t i = from; i < to; ++i) {
-      while (sp + 1 < spans.size() && size_t(spans[sp + 1].first) <= i) ++sp;
-      const Volume& v = *spans[sp].v;
-      const int64_t s = spans[sp].lo + (int64_t(i) - spans[sp].first);
-      const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
-      uint8_t* dst = out.residues.data() + out.offsets[i];
-      const size_t n = size_t(out.offsets[i + 1] - out.offsets[i]);
-      if (protein) {
-        if (n) std::memcpy(dst, v.seq.p + o1, n);
+  for (int64_t i = 0; i < count; ++i) offsets[size_t(i) + 1] += offsets[size_t(i)];
+  return SWA_OK;
+}
+
+// Residues of the sequences [from, to) of the range, back to back, residue k of the span at dst[k] - or, nibbles, in the low
+// (k even) / high (k odd) half of dst[k >> 1], which is how nucleotide shards are held.  One thread per call; calls on disjoint
+// spans may run side by side if, with nibbles, each span starts on an even residue of the buffer they share.  *or_codes
+// collects the OR of every residue code (the caller validates: codes index the LDS profile).
+int swa::RangeReader::fill(int64_t from, int64_t to, uint8_t* dst, bool nibbles, unsigned* or_codes) const
+{
+  const std::vector<Impl::Span>& spans = impl->spans;
+  if (from >= to) return SWA_OK;
+  size_t sp = 0;
+  while (sp + 1 < spans.size() && spans[sp + 1].first <= from) ++sp;
+  const int64_t base = offsets[size_t(from)];
+  unsigned acc = 0;
+  std::vector<uint8_t> tmp;
+  for (int64_t i = from; i < to; ++i) {
+    while (sp + 1 < spans.size() && spans[sp + 1].first <= i) ++sp;
+    const Volume& v = *spans[sp].v;
+    const int64_t s = spans[sp].lo + (i - spans[sp].first);
+    const uint64_t o1 = be32(v.seq_off + 4 * s), o2 = be32(v.seq_off + 4 * (s + 1));
+    const int64_t at = offsets[size_t(i)] - base;
+    const size_t n = size_t(offsets[size_t(i) + 1] - offsets[size_t(i)]);
+    if (protein) {
+      if (!n) continue;
+      const uint8_t* src = v.seq.p + o1;
+      if (!nibbles) {
+        std::memcpy(dst + at, src, n);
+        if (or_codes) for (size_t k = 0; k < n; ++k) acc |= src[k];
         continue;
       }
+      tmp.assign(src, src + n);
+    } else {
       const uint64_t o3 = be32(v.amb_off + 4 * s);
       const uint8_t* body = v.seq.p + o1;
+      uint8_t* out = dst + at;
+      if (nibbles) { tmp.resize(n); out = tmp.data(); }
       for (size_t k = 0; k < n; ++k)
-        dst[k] = uint8_t(1u << ((body[k >> 2] >> ((3 - (k & 3)) << 1)) & 3));  // A=1 C=2 G=4 T=8
-      if (o2 > o3) {                                                 // ambiguity runs, database.cc:1284-1323
+        out[k] = uint8_t(1u << ((body[k >> 2] >> ((3 - (k & 3)) << 1)) & 3));  // A=1 C=2 G=4 T=8
+      if (o2 > o3) {                                                 // ambiguity runs in file order, database.cc:1284-1323
         const uint8_t* a = v.seq.p + o3;
         const size_t bytes = size_t(o2 - o3);
         if (bytes >= 4) {
@@ -356,37 +381,82 @@ int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, i
             for (size_t k = 0; k + 8 <= bytes - 4; k += 8) {
               const uint64_t e = be64(a + 4 + k);
               const uint64_t code = e >> 60, run = ((e >> 48) & 0xfff) + 1, off = e & 0x0000fffffffffffULL;
-              for (uint64_t r = 0; r < run && off + r < n; ++r) dst[off + r] = uint8_t(code);
+              for (uint64_t r = 0; r < run && off + r < n; ++r) out[off + r] = uint8_t(code);
             }
           } else {
             for (size_t k = 0; k + 4 <= bytes - 4; k += 4) {
               const uint32_t e = be32(a + 4 + k);
               const uint32_t code = e >> 28, run = ((e >> 24) & 0xf) + 1, off = e & 0x00ffffff;
-              for (uint32_t r = 0; r < run && size_t(off) + r < n; ++r) dst[off + r] = uint8_t(code);
+              for (uint32_t r = 0; r < run && size_t(off) + r < n; ++r) out[off + r] = uint8_t(code);
             }
           }
         }
       }
+      if (!nibbles) continue;                                        // (one-hot or 4-bit codes: always in range)
     }
-  };
-  const size_t total = size_t(count);
+    // two residues per byte: a byte's low half is written first (and clears the high half), its high half is OR-ed in
+    for (size_t k = 0; k < n; ++k) {
+      const int64_t g = at + int64_t(k);
+      const uint8_t c = uint8_t(tmp[k] & 15);
+      acc |= tmp[k];
+      if (g & 1) dst[g >> 1] = uint8_t(dst[g >> 1] | (c << 4));
+      else dst[g >> 1] = c;
+    }
+  }
+  if (or_codes) *or_codes |= acc;
+  return SWA_OK;
+}
+
+// The mapped pages of the sequence files behind [from, to) leave this process's resident set (they stay in the page cache):
+// a shard that is read once into page-locked memory should not be counted twice.
+void swa::RangeReader::forget(int64_t from, int64_t to) const
+{
+  const std::vector<Impl::Span>& spans = impl->spans;
+  const int64_t page = 4096;
+  for (size_t sp = 0; sp < spans.size(); ++sp) {
+    const int64_t first = spans[sp].first, next = sp + 1 < spans.size() ? spans[sp + 1].first : int64_t(offsets.size()) - 1;
+    const int64_t a = std::max(from, first), b = std::min(to, next);
+    if (a >= b) continue;
+    const Volume& v = *spans[sp].v;
+    const int64_t o1 = int64_t(be32(v.seq_off + 4 * (spans[sp].lo + a - first))), o2 = int64_t(be32(v.seq_off + 4 * (spans[sp].lo + b - first)));
+    const int64_t lo = (o1 + page - 1) / page * page, hi = o2 / page * page;      // whole pages inside the byte range only
+    if (hi > lo) (void)madvise(const_cast<uint8_t*>(v.seq.p) + lo, size_t(hi - lo), MADV_DONTNEED);
+  }
+}
+
+int swa::read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out)
+{
+  RangeReader rd;
+  const int rc_open = rd.open(basename, symtype, first_seqno, last_seqno);
+  if (rc_open != SWA_OK) return rc_open;
+  out.masked = rd.masked;
+  out.masked_seqcount = rd.masked_seqcount;
+  out.masked_symcount = rd.masked_symcount;
+  out.total_seqcount = rd.total_seqcount;
+  out.total_symcount = rd.total_symcount;
+  out.longest = rd.longest;
+  out.title = rd.title;
+  out.first_seqno = rd.first_seqno;
+  out.offsets = rd.offsets;
+  out.included = rd.included;
+  out.residues.clear();
+  const size_t total = out.offsets.size() - 1;
+  if (!total) return SWA_OK;
+  out.residues.resize(size_t(out.offsets.back()));
   const size_t nthreads = std::max<size_t>(1, std::min<size_t>({size_t(std::thread::hardware_concurrency()), size_t(32),
                                                                  size_t(out.residues.size() >> 24) + 1}));
-  if (nthreads == 1) {
-    fill(0, total);
-  } else {                                                           // split by residues, not by sequence count
-    std::vector<std::thread> pool;
-    size_t from = 0;
-    for (size_t t = 0; t < nthreads; ++t) {
-      const int64_t target = out.offsets.back() * int64_t(t + 1) / int64_t(nthreads);
-      const size_t to = t + 1 == nthreads ? total
-                                          : size_t(std::lower_bound(out.offsets.begin(), out.offsets.end(), target) - out.offsets.begin());
-      const size_t end = std::min(std::max(to, from), total);
-      pool.emplace_back(fill, from, end);
-      from = end;
-    }
-    for (std::thread& th : pool) th.join();
+  if (nthreads == 1) return rd.fill(0, int64_t(total), out.residues.data(), false, nullptr);
+  std::vector<std::thread> pool;                                     // split by residues, not by sequence count
+  size_t from = 0;
+  for (size_t t = 0; t < nthreads; ++t) {
+    const int64_t target = out.offsets.back() * int64_t(t + 1) / int64_t(nthreads);
+    const size_t to = t + 1 == nthreads ? total
+                                        : size_t(std::lower_bound(out.offsets.begin(), out.offsets.end(), target) - out.offsets.begin());
+    const size_t end = std::min(std::max(to, from), total);
+    pool.emplace_back([&rd, &out, from, end]() { (void)rd.fill(int64_t(from), int64_t(end), out.residues.data() + out.offsets[from], false, nullptr); });
+    from = end;
   }
+  for (std::thread& th : pool) th.join();
   return SWA_OK;
 }
 

@@ -49,6 +49,26 @@ struct HostDb {
 // Mirrors db_open (alias + volumes, database.cc:775-925) and db_getsequence
 // (database.cc:1237-1401) for symtype 0 and 1.  Returns SWA_OK or records an error.
 int read_blast_db(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno, HostDb& out);
+// The same range, opened for reading piece by piece (blastdb.cpp): open() reads the index (lengths as prefix sums, the OID
+// mask), fill() delivers the residues of any run of sequences into the caller's buffer.
+struct RangeReader {
+  RangeReader();
+  ~RangeReader();
+  RangeReader(const RangeReader&) = delete;
+  RangeReader& operator=(const RangeReader&) = delete;
+  int open(const char* basename, int symtype, int64_t first_seqno, int64_t last_seqno);
+  int fill(int64_t from, int64_t to, uint8_t* dst, bool nibbles, unsigned* or_codes) const;
+  void forget(int64_t from, int64_t to) const;
+  std::vector<int64_t> offsets;       // nseq + 1 prefix sums of the lengths
+  int64_t first_seqno = 0, total_seqcount = 0, total_symcount = 0, longest = 0;
+  std::string title;
+  bool protein = true, masked = false;
+  std::vector<uint8_t> included;
+  int64_t masked_seqcount = 0, masked_symcount = 0;
+ private:
+  struct Impl;
+  Impl* impl;
+};
 // What a pipelined open needs before the first residue is read (db_open + the index half of db_mapsequences,
 // database.cc:775-925, 1082-1131): the lengths of the sequences [first_seqno, last_seqno] out of the index files, and the
 // byte ranges of the sequence files that hold them.  `regular` says the loader may take the files as they lie: protein

@@ -402,6 +402,8 @@ namespace {
 int streamed_set_scoring(swa_db* front, const int64_t* matrix, int64_t goe, int64_t ge);
 int streamed_set_inclusion(swa_db* front, const uint8_t* include, int64_t n);
 size_t streamed_hbm(const swa_db* front);
+int streamed_wait(swa_db* front);
+int streamed_progress(swa_db* front, int64_t* done, int64_t* total, int32_t* ready, int32_t* nparts);
 int streamed_candidates(swa_db* front, const uint8_t* query, int64_t qlen, int64_t keep, int64_t minscore, int64_t maxscore,
                         std::vector<struct Cand>& cand, int64_t* tot, int64_t* obv, swa_counters_t* counters,
                         const uint8_t* query2 = nullptr, int32_t tag1 = 0, struct Pair* pair = nullptr, int32_t tag0 = 0);

@@ -340,6 +340,95 @@ def _pack_nucleotide_new_format(codes):
     return body, table
 
 
+_BUDGET_OPEN = r"""
+import json, os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+np.seterr(over="ignore")
+import swipe_amd
+from swipe_amd import blastdb, synth
+
+def status(key):
+    for line in open("/proc/self/status"):
+        if line.startswith(key + ":"):
+            return int(line.split()[1]) * 1024
+
+base, budget, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+q = blastdb.encode_protein(synth.QUERY_P07327)
+M = swipe_amd.matrix_builtin("BLOSUM62")
+warm = swipe_amd.Database.from_arrays(np.array([1, 2, 3], np.uint8), np.array([0, 3], np.int64))      # the runtime's own allocations
+warm.set_scoring(M, 11, 1); warm.search(q[:20]); warm.close()
+out = {"rss_before": status("VmRSS")}
+t0 = time.perf_counter()
+db = swipe_amd.Database.open(base, hbm_budget=budget)
+out["open_s"] = time.perf_counter() - t0
+out["progress_at_open"] = db.load_progress()
+if mode == "rss":
+    db.wait()
+    out["wait_s"] = time.perf_counter() - t0
+    out["progress_after"] = db.load_progress()
+    out["hwm_after"] = status("VmHWM")
+    out["hbm_bytes"] = db.info()["hbm_bytes"]
+    out["first"] = [int(x) for x in db.sequence(0)[:8]]
+else:
+    db.set_scoring(M, 11, 1)
+    hits, tot, obv, c = db.search_topk(q, keep=30, minscore=55)        # binds every part as the loader delivers it
+    out["search_s"] = time.perf_counter() - t0
+    out["hits"], out["tot"] = hits, tot
+    out["progress_after"] = db.load_progress()
+db.close()
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.late
+def test_budgeted_open_fills_the_parts_straight_from_the_files(tmp_path):
+    """swa_db_open_streamed no longer reads the database into a host vector and copies that into the parts
+    (2 x the database in host memory, a serial open): the call returns when the index is read and the parts are planned, a
+    loader fills each part's page-locked block out of the sequence files (database.cc:1082-1131: the reference maps what it
+    is about to search), and the first search binds the parts as they arrive.  Asserted on /proc/self/status of a fresh
+    process: open + wait raise the resident set by at most 1.15 x the page-locked footprint (under the interpreter the
+    device slots are host memory too and are allowed for)."""
+    import json
+    import subprocess
+    from conftest import under_interpreter
+    nseq = 300_000 if under_interpreter() else 3_000_000
+    res, off = swipe_amd.synth_db(31, nseq, query=Q, threads=os.cpu_count() or 1)
+    base = str(tmp_path / "big")
+    swipe_amd.write_blastdb(base, res, off)
+    want = oracle.search_all63(res[:off[40_000]], off[:40_001], Q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=os.cpu_count() or 1)
+    nsym = int(off[-1])
+    first8 = [int(x) for x in res[:8]]
+    budget = int((2.04 * nsym + 77 * nseq) / 4)                     # a quarter of what the shard would take resident
+    # the whole database's expected hit list: from a resident shard in this process (itself checked against the oracle on a slice)
+    db = swipe_amd.Database.from_arrays(res, off)
+    db.set_scoring(_matrix(), 11, 1)
+    scores, _ = db.search(Q)
+    assert np.array_equal(scores[:40_000], want)
+    exp_hits, exp_tot = _expected_topk(scores, 30, 55)
+    db.close()
+    del res, off, scores
+    script = tmp_path / "budget_open.py"
+    script.write_text(_BUDGET_OPEN % ROOT)
+
+    def run(mode):
+        r = subprocess.run([sys.executable, str(script), base, str(budget), mode], capture_output=True, text=True, timeout=3000)
+        assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    a = run("rss")
+    pinned = a["progress_after"]["bytes_total"]
+    assert a["progress_after"]["parts_ready"] == a["progress_after"]["parts_total"] >= 7 and a["first"] == first8
+    assert nsym < pinned < 1.1 * nsym + 64 * nseq
+    grown = a["hwm_after"] - a["rss_before"] - (a["hbm_bytes"] if under_interpreter() else 0)
+    assert grown <= 1.15 * pinned, (grown, pinned, a)
+    assert a["progress_at_open"]["parts_ready"] < a["progress_at_open"]["parts_total"], a      # the open did not wait for the residues
+    b = run("search")
+    assert ([tuple(h) for h in b["hits"]], b["tot"]) == (exp_hits, exp_tot)
+    print("budgeted open: %.3f s to return, %.3f s until every part is in place (%.2f GB page-locked); first search done %.3f s after the open began"
+          % (a["open_s"], a["wait_s"], pinned / 1e9, b["search_s"]))
+
+
 def _apply_table_in_file_order(codes, table):
     """the residues a .nsq entry stands for: its one-hot bases with the ambiguity entries applied one after the other, the last
     writer wins (database.cc:1296-1321); runs are cut at the end of the sequence"""
