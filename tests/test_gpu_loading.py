@@ -689,9 +689,9 @@ def test_kernels_stay_inside_their_buffers(tmp_path):
     is Valgrind, CHANGES:54).  A child process: the switch is read when the library is first used."""
     import subprocess
     import sys
-    from conftest import ROOT
+    from conftest import ROOT, under_interpreter
     env = dict(os.environ, SWA_REDZONES="1", SWA_WATCHDOG_S="60")
-    r = subprocess.run([sys.executable, "-c", _REDZONE_SCRIPT % (ROOT, str(tmp_path))], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, "-c", _REDZONE_SCRIPT % (ROOT, str(tmp_path))], capture_output=True, text=True, timeout=2400 if under_interpreter() else 600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("REDZONES")][-1]
     f = dict(kv.split("=") for kv in line.split()[1:5])
