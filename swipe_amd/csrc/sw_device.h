@@ -65,6 +65,10 @@ struct swa_narrow_params {
   long long boundary_base;     /* stream chunk (swa_batch.offset units) that boundary[0] belongs to */
   int32_t row0;                /* first query row of the pass */
   int32_t pass, last;          /* pass index; 1 when no pass follows */
+  /* bound builds, single pass (sw_cb_kernel.inc, round 6) */
+  int32_t concat;              /* batches a chain works through back to back, without draining or resetting in between
+                                  (an item of the work queue = concat x 16 / G batches); <= 1: one, the round-3 kernel */
+  int32_t concat_items;        /* items of that size at the head of the queue; the batches behind them go one set of 16 / G at a time */
 };
 
 /* generic multi-pass kernel (sw_mp_kernel.inc) */

@@ -219,6 +219,7 @@ struct Options {
   int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
+  int64_t concat = -1;           // bound builds on chains of lanes: sets of batches a chain works through back to back without draining (sw_cb_kernel.inc); -1 = 8, the last four sets per resident wave singly; N > 1 = N, the last quarter of the sets singly (tests); 1 or 0 = every set on its own (the round-3 kernel)
   int64_t requeue_block = 0;     // device-driven re-queue, a BLOCK of four waves per sequence instead of one wave: 1 whenever the query fits (<= 1024 rows), else never. Off until tools/rq_probe.py has priced its barrier per DP step on hardware
   int64_t requeue_follow = 0;    // (rounds 2-3: a re-queue kernel beside the first pass on a second stream; gone - the key is accepted and ignored)
   int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
@@ -241,7 +242,7 @@ const OptionKey kOptionKeys[] = {
   {"mp_w", &Options::mp_w}, {"boundary_mb", &Options::boundary_mb}, {"wave_requeue", &Options::wave_requeue},
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
-  {"requeue_follow", &Options::requeue_follow}, {"requeue_block", &Options::requeue_block}, {"window", &Options::window}, {"window_step", &Options::window_step},
+  {"requeue_follow", &Options::requeue_follow}, {"requeue_block", &Options::requeue_block}, {"concat", &Options::concat}, {"window", &Options::window}, {"window_step", &Options::window_step},
   {"long_lanes", &Options::long_lanes}, {"watchdog_s", &Options::watchdog_s}, {"pipelined", &Options::pipelined},
   {"load_part", &Options::load_part}, {"load_chunk", &Options::load_chunk}, {"load_threads", &Options::load_threads},
   {"load_delay_ms", &Options::load_delay_ms}, {"load_trace", &Options::load_trace}, {"stream_reserve", &Options::stream_reserve},
@@ -1625,8 +1626,24 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
     for (int r = 0; r <= K + 1; ++r) p.rowc[r] = f16_pair(float(int64_t(r) * db->ge));
     c.narrow_rows = K;
     c.narrow_shifted = G == 8 ? 2 : G == 4 ? 3 : G == 2 ? 7 : G == 1 ? 11 : 1;
-    const int per_wave = 16 / G;                                    // a wave takes 16 / G batches at a time
-    const int items = (p.nbatches + per_wave - 1) / per_wave;
+    const int per_wave = 16 / G;                                    // a wave takes 16 / G batches at a time ...
+    // ... and the bound builds on chains of lanes take `concat` such sets one behind the other without draining in between
+    // (sw_cb_kernel.inc), except at the tail of the queue: the last four sets per resident wave - the shortest sequences, which
+    // decide when the last wave finishes - are handed out one at a time.  Returns the number of items of the queue.
+    auto plan_items = [&](swa_narrow_params& q) -> int {
+      const int sets = (q.nbatches + per_wave - 1) / per_wave;
+      q.concat = 1;
+      q.concat_items = 0;
+      if (pick.bound && G > 1 && db->opt.concat != 1 && db->opt.concat != 0) {
+        const int M = db->opt.concat > 0 ? int(std::min<int64_t>(db->opt.concat, 64)) : 8;
+        const int64_t resident = int64_t(db->cus) * 4 * waves_for_rows(K, true);
+        const int tail = db->opt.concat > 0 ? sets / 4 : int(std::min<int64_t>(sets, 4 * resident));
+        q.concat_items = (sets - tail) / M;
+        if (q.concat_items > 0) q.concat = M;
+      }
+      return q.concat_items + (sets - q.concat_items * q.concat);
+    };
+    const int items = plan_items(p);
     int blocks = persistent_blocks(db, items);
     p.pipe = int32_t(db->opt.pipe);
     if (db->opt.blocks_per_cu > 0) blocks = std::max(1, std::min((items + 3) / 4, db->cus * int(db->opt.blocks_per_cu)));
@@ -1676,7 +1693,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
         q.nbatches = int32_t(part.plan.batches.size());
         q.counter = LD->heads.p + i;
         if (q.nbatches == 0) continue;
-        const int pitems = (q.nbatches + per_wave - 1) / per_wave;
+        const int pitems = plan_items(q);
         int pblocks = persistent_blocks(db, pitems);
         if (db->opt.blocks_per_cu > 0) pblocks = std::max(1, std::min((pitems + 3) / 4, db->cus * int(db->opt.blocks_per_cu)));
         HIP_TRY(launch_first(q, pblocks, ps));

@@ -215,6 +215,55 @@ def test_bound_build_of_the_first_pass_gives_the_same_hits(lanes, monkeypatch):
     db.close()
 
 
+@pytest.mark.late
+@pytest.mark.parametrize("concat", [2, 5, 8])
+@pytest.mark.parametrize("lanes", [16, 8, 4, 2])
+def test_bound_build_with_sequences_back_to_back(lanes, concat, monkeypatch):
+    """round 6: the bound build works through `concat` sets of batches per chain WITHOUT draining the chain or resetting its
+    state in between (sw_cb_kernel.inc: what flows across a junction can only raise a bound, and what a bound sends back is
+    recomputed exactly) - the skew of a chain is paid once per item instead of once per batch.  Hits, totalhits and obvious
+    must be the exact ones at every threshold, for the shortest, a middle and the longest build of every chain length, with
+    hits planted in front of ordinary sequences, sequences shorter than a period, empty ones, and a tail of the queue that
+    is handed out one set at a time (the last quarter under the option)"""
+    monkeypatch.setenv("SWA_LANES", str(lanes))
+    monkeypatch.setenv("SWA_BOUND", "1")
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(99, 1, 1000, rtab)
+    rng = np.random.default_rng(100 * lanes + concat)
+    res, off = swipe_amd.synth_db(6, 1300, query=full)
+    seqs = [res[off[i]:off[i + 1]] for i in range(1300)]
+    for k in range(150):                                   # pieces of the query: scores across every threshold, hits of every size
+        a = int(rng.integers(0, 700))
+        piece = full[a:a + int(rng.integers(8, 200))].copy()
+        mut = rng.random(len(piece)) < rng.random() * 0.4
+        piece[mut] = rtab[rng.integers(0, len(rtab), int(mut.sum()))]
+        seqs.append(np.concatenate([seqs[k][:int(rng.integers(0, 60))], piece, seqs[k + 1][:int(rng.integers(0, 3))]]))    # the hit ends at the junction
+    seqs += [synth._random_residues(k, 1, int(rng.integers(1, 16)), rtab) for k in range(200)]     # shorter than a period
+    seqs += [full, full[::2].copy(), np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    lo, hi = {16: (25, 58), 8: (25, 62), 4: (11, 62), 2: (5, 62)}[lanes]
+    back = single = 0
+    for K in (lo, (lo + hi) // 2 | 1, hi):
+        go, ge = ((11, 1), (10, 2), (9, 3))[K % 3]
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
+        q = full[:lanes * K - (K % lanes)]
+        want = oracle.search_all63(r2, o2, q, Mo, go + ge, ge, threads=THREADS)
+        for minscore, maxscore in ((1, 1 << 62), (35, 90), (60, 1 << 62), (100, 300), (400, 1 << 62)):
+            got = {}
+            for m in (1, concat):
+                db.set_option("concat", m)
+                hits, tot, obv, c = db.search_topk(q, keep=40, minscore=minscore, maxscore=maxscore)
+                assert c["narrow_rows"] == K and c["narrow_shifted"] == 8, (K, c)
+                assert (hits, tot, obv) == _expected_topk(want, 40, minscore, maxscore), (K, minscore, m)
+                got[m] = c["wide"]
+            back += got[concat]
+            single += got[1]
+    assert back >= single > 0            # what crosses a junction can only send MORE sequences back
+    db.close()
+
+
 def test_one_lane_bound_build_is_the_default_up_to_60_rows():
     """top-K searches of 49..60-row queries take the one-lane bound build by themselves (no option set), 61 rows and
     exact searches of the same queries go to 2-lane chains; same hits either way"""

@@ -64,10 +64,10 @@ print(json.dumps({"requeued": int(c["wide"]), "columns": int(lens.sum()), "nseq"
 """
 
 
-def run(code, args):
+def run(code, args, extra_env=None):
     with tempfile.TemporaryDirectory() as d:
         stats = os.path.join(d, "s.jsonl")
-        env = dict(os.environ, HIPSIM_STATS=stats)
+        env = dict(os.environ, HIPSIM_STATS=stats, **(extra_env or {}))
         r = subprocess.run([sys.executable, "-c", code % ROOT] + [str(a) for a in args], capture_output=True, text=True, env=env)
         if r.returncode:
             raise SystemExit(r.stderr[-2000:])
@@ -85,23 +85,30 @@ def main():
         raise SystemExit("run under tools/gfx950sim/run.sh")
     print("Wave-instruction counts of the kernels in swipe_amd/libswipe_amd.so, interpreted by tools/gfx950sim (tools/sim_counts.py).")
     print("Per cell pair = per (database residue x query row) / 2 of the 20 000-sequence synthetic shard, padding and skew charged.\n")
-    print("%-34s %4s %4s | %6s %6s %6s %6s %6s %6s | %6s %8s %9s | %s" % ("first pass", "rows", "form", "vop3p", "valu", "salu", "lds", "nop/w", "branch", "VALU", "if bound", "r03 meas.", "kernel"))
+    print("%-40s %4s %4s | %6s %6s %6s %6s %6s %6s | %6s %8s %9s | %s" % ("first pass", "rows", "form", "vop3p", "valu", "salu", "lds", "nop/w", "branch", "VALU", "if bound", "r03 meas.", "kernel"))
     # a VALU-issue-bound kernel on MI355X: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz, 128 cells per
     # wave instruction slot of a cell pair -> GCUPS = 256 * 4 * 2.4e9 / (4 * VALU per cell pair) * 128 / 1e9
     bound = lambda v: 256 * 4 * 2.4e9 / (4.0 * v) * 128 / 1e9
     measured = {("protein", 5, "exact"): 7600, ("protein", 10, "exact"): 8800, ("protein", 20, "exact"): 9700, ("protein", 48, "exact"): 9736,
                 ("protein", 49, "exact"): 8950, ("protein", 375, "exact"): 9539, ("protein", 5, "bound"): 8400, ("protein", 10, "bound"): 10500,
                 ("protein", 375, "bound"): 11614, ("nucleotide", 1000, "both strands"): 10734}
-    for kind, qlen, mode in (("protein", 5, "exact"), ("protein", 10, "exact"), ("protein", 20, "exact"), ("protein", 48, "exact"),
-                             ("protein", 49, "exact"), ("protein", 375, "exact"), ("protein", 5, "bound"), ("protein", 10, "bound"),
-                             ("protein", 60, "bound"), ("protein", 375, "bound"), ("nucleotide", 1000, "both strands")):
-        meta, rows = run(CHILD, [kind, qlen, mode])
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    table = [("protein", 5, "exact", None), ("protein", 10, "exact", None), ("protein", 20, "exact", None), ("protein", 48, "exact", None),
+             ("protein", 49, "exact", None), ("protein", 375, "exact", None), ("protein", 5, "bound", None), ("protein", 10, "bound", None),
+             ("protein", 60, "bound", None), ("protein", 375, "bound", {"SWA_CONCAT": "1"}), ("protein", 375, "bound", {"SWA_CONCAT": "8"}),
+             ("protein", 375, "bound", {"SWA_CONCAT": "32"}), ("protein", 100, "bound", {"SWA_CONCAT": "1"}), ("protein", 100, "bound", {"SWA_CONCAT": "8"}),
+             ("nucleotide", 1000, "both strands", None)]
+    for kind, qlen, mode, extra in table:
+        label = "%s %d, %s%s" % (kind, qlen, mode, (", " + " ".join("%s=%s" % (k[4:].lower(), v) for k, v in extra.items())) if extra else "")
+        if only and not all(o in label for o in only):
+            continue
+        meta, rows = run(CHILD, [kind, qlen, mode], extra)
         d = max((x for x in rows if x["vop3p"] > 0), key=lambda x: x["vop3p"])
         pairs = meta["cells"] / 2 / 64 / (2 if kind == "nucleotide" else 1) * (2 if kind == "nucleotide" else 1)
         v = (d["vop3p"] + d["valu"]) / pairs
         m = measured.get((kind, qlen, mode))
-        print("%-34s %4d %4d | %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f | %6.2f %8.0f %9s | %s" % (
-            "%s %d, %s" % (kind, qlen, mode), meta["rows"], meta["form"], d["vop3p"] / pairs, d["valu"] / pairs, d["salu"] / pairs,
+        print("%-40s %4d %4d | %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f | %6.2f %8.0f %9s | %s" % (
+            label, meta["rows"], meta["form"], d["vop3p"] / pairs, d["valu"] / pairs, d["salu"] / pairs,
             d["lds"] / pairs, d["other"] / pairs, d["branch"] / pairs, v, bound(v), ("%d" % m) if m else "-", d["kernel"][:52]))
     print("\n('if bound' = GCUPS of a kernel that does nothing but issue these VALU instructions, 4 cycles each per SIMD, 256 CUs, 2.4 GHz;")
     print(" 'r03 meas.' = GCUPS measured on MI355X in round 3 on the 10 M-sequence database (profiles/r03_sweep_protein_qlen_10M.txt, BENCH_r03).")
@@ -109,6 +116,8 @@ def main():
     print(" something the count does not see holds it back.)")
     print("(MI355X, r03 PMC pass of the bench command: SQ_INSTS_VALU = 6.63 per cell pair for swa_narrow_bound_kernel<47,2,8,16>; floor 6.0;")
     print(" the exact form's floor is 7.5, the two-query form's 6.5 / 5.)\n")
+    if only:
+        return
     print("Re-queue behind the first pass: wave-instructions per step of ONE wave, and on the critical path of a 6 000-column entry")
     print("%5s %-6s %5s | %8s %7s %7s %6s | %9s" % ("qlen", "form", "K", "all/step", "valu", "salu", "lds", "path, M"))
     for qlen in (200, 375, 768, 1024):
