@@ -69,6 +69,8 @@ struct swa_narrow_params {
   int32_t concat;              /* batches a chain works through back to back, without draining or resetting in between
                                   (an item of the work queue = concat x 16 / G batches); <= 1: one, the round-3 kernel */
   int32_t concat_items;        /* items of that size at the head of the queue; the batches behind them go one set of 16 / G at a time */
+  int32_t twin;                /* builds at two waves per SIMD: blocks of 8 waves with the profile twice, the second copy - N R (step 0
+                                  of a period renormalises H through it); 0: blocks of 4 waves, one copy, the round-3 form */
 };
 
 /* generic multi-pass kernel (sw_mp_kernel.inc) */

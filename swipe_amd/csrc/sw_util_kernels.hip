@@ -237,10 +237,16 @@ swa_endpoints_kernel(swa_seqs sq, const int32_t* __restrict__ ids, const uint8_t
 // (row 0 keeps the 0), row_shr:1 then overwrites every lane that has a left neighbour in its own row of 16 and leaves the
 // four row heads alone (bound_ctrl off: an invalid source lane keeps what is there).  Both controls are what rocPRIM's
 // warp scans use on every non-Navi target.
+// (-DSWA_LANE_UP_BPERMUTE builds the form that ran on hardware until round 4 - ds_bpermute through the LDS crossbar - for an A/B.)
 __device__ __forceinline__ int lane_up1(int x)
 {
+#ifdef SWA_LANE_UP_BPERMUTE
+  const int up = __shfl_up(x, 1);
+  return (threadIdx.x & 63) == 0 ? 0 : up;
+#else
   const int heads = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xe, 0xf, false);
   return __builtin_amdgcn_update_dpp(heads, x, 0x111, 0xf, 0xf, false);
+#endif
 }
 
 template <int K, bool POS>

@@ -219,7 +219,9 @@ struct Options {
   int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
-  int64_t concat = -1;           // bound builds on chains of lanes: sets of batches a chain works through back to back without draining (sw_cb_kernel.inc); -1 = 8, the last four sets per resident wave singly; N > 1 = N, the last quarter of the sets singly (tests); 1 or 0 = every set on its own (the round-3 kernel)
+  int64_t concat = -1;           // bound builds on chains of lanes: sets of batches a chain works through back to back without draining (sw_cb_kernel.inc); -1 = 8; N > 1 = N; 1 or 0 = every set on its own (the round-3 kernel)
+  int64_t concat_tail = -1;      // ... except the last concat_tail sets of the queue, which are handed out one at a time; -1 = four per resident wave
+  int64_t twin = -1;             // bound builds at two waves per SIMD: blocks of 8 waves holding the profile twice, the second copy renormalising H on the way (sw_cb_kernel.inc TWIN); 0 = blocks of 4 waves, one copy (the round-3 form); -1 = on
   int64_t requeue_block = 0;     // device-driven re-queue, a BLOCK of four waves per sequence instead of one wave: 1 whenever the query fits (<= 1024 rows), else never. Off until tools/rq_probe.py has priced its barrier per DP step on hardware
   int64_t requeue_follow = 0;    // (rounds 2-3: a re-queue kernel beside the first pass on a second stream; gone - the key is accepted and ignored)
   int64_t window = -1;           // long database sequences as overlapping windows: -1 auto, 0 never, n > 0: every sequence longer than n
@@ -242,7 +244,7 @@ const OptionKey kOptionKeys[] = {
   {"mp_w", &Options::mp_w}, {"boundary_mb", &Options::boundary_mb}, {"wave_requeue", &Options::wave_requeue},
   {"dual_mp", &Options::dual_mp}, {"dual_kmax", &Options::dual_kmax}, {"narrow_variant", &Options::narrow_variant},
   {"endpoints_thread", &Options::endpoints_thread}, {"requeue_host", &Options::requeue_host},
-  {"requeue_follow", &Options::requeue_follow}, {"requeue_block", &Options::requeue_block}, {"concat", &Options::concat}, {"window", &Options::window}, {"window_step", &Options::window_step},
+  {"requeue_follow", &Options::requeue_follow}, {"requeue_block", &Options::requeue_block}, {"concat", &Options::concat}, {"concat_tail", &Options::concat_tail}, {"twin", &Options::twin}, {"window", &Options::window}, {"window_step", &Options::window_step},
   {"long_lanes", &Options::long_lanes}, {"watchdog_s", &Options::watchdog_s}, {"pipelined", &Options::pipelined},
   {"load_part", &Options::load_part}, {"load_chunk", &Options::load_chunk}, {"load_threads", &Options::load_threads},
   {"load_delay_ms", &Options::load_delay_ms}, {"load_trace", &Options::load_trace}, {"stream_reserve", &Options::stream_reserve},
@@ -1637,13 +1639,14 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       if (pick.bound && G > 1 && db->opt.concat != 1 && db->opt.concat != 0) {
         const int M = db->opt.concat > 0 ? int(std::min<int64_t>(db->opt.concat, 64)) : 8;
         const int64_t resident = int64_t(db->cus) * 4 * waves_for_rows(K, true);
-        const int tail = db->opt.concat > 0 ? sets / 4 : int(std::min<int64_t>(sets, 4 * resident));
+        const int tail = int(std::min<int64_t>(sets, db->opt.concat_tail >= 0 ? db->opt.concat_tail : 4 * resident));
         q.concat_items = (sets - tail) / M;
         if (q.concat_items > 0) q.concat = M;
       }
       return q.concat_items + (sets - q.concat_items * q.concat);
     };
     const int items = plan_items(p);
+    p.twin = db->opt.twin != 0 ? 1 : 0;
     int blocks = persistent_blocks(db, items);
     p.pipe = int32_t(db->opt.pipe);
     if (db->opt.blocks_per_cu > 0) blocks = std::max(1, std::min((items + 3) / 4, db->cus * int(db->opt.blocks_per_cu)));

@@ -224,7 +224,9 @@ def test_bound_build_with_sequences_back_to_back(lanes, concat, monkeypatch):
     recomputed exactly) - the skew of a chain is paid once per item instead of once per batch.  Hits, totalhits and obvious
     must be the exact ones at every threshold, for the shortest, a middle and the longest build of every chain length, with
     hits planted in front of ordinary sequences, sequences shorter than a period, empty ones, and a tail of the queue that
-    is handed out one set at a time (the last quarter under the option)"""
+    is handed out one set at a time (here: the last quarter of the sets).  Builds at two waves per SIMD (30+ rows) run as blocks of
+    8 waves with the profile twice, the second copy - N R, which step 0 of a period reads instead of renormalising H (option
+    twin; beyond 56 rows the copy is out of reach of ds_read's immediate offset): same hits, same re-queue counts"""
     monkeypatch.setenv("SWA_LANES", str(lanes))
     monkeypatch.setenv("SWA_BOUND", "1")
     rtab = synth.residue_table_protein()
@@ -252,14 +254,17 @@ def test_bound_build_with_sequences_back_to_back(lanes, concat, monkeypatch):
         want = oracle.search_all63(r2, o2, q, Mo, go + ge, ge, threads=THREADS)
         for minscore, maxscore in ((1, 1 << 62), (35, 90), (60, 1 << 62), (100, 300), (400, 1 << 62)):
             got = {}
-            for m in (1, concat):
+            db.set_option("concat_tail", (len(seqs) // 8 // (16 // lanes)) // 4)      # the last quarter of the sets one at a time
+            for m, twin in ((1, 1), (concat, 1), (concat, 0), (1, 0)):
                 db.set_option("concat", m)
+                db.set_option("twin", twin)       # builds at two waves per SIMD: 8-wave blocks with the profile twice / the round-3 form
                 hits, tot, obv, c = db.search_topk(q, keep=40, minscore=minscore, maxscore=maxscore)
                 assert c["narrow_rows"] == K and c["narrow_shifted"] == 8, (K, c)
-                assert (hits, tot, obv) == _expected_topk(want, 40, minscore, maxscore), (K, minscore, m)
-                got[m] = c["wide"]
-            back += got[concat]
-            single += got[1]
+                assert (hits, tot, obv) == _expected_topk(want, 40, minscore, maxscore), (K, minscore, m, twin)
+                got[(m, twin)] = c["wide"]
+            assert got[(concat, 1)] == got[(concat, 0)] and got[(1, 1)] == got[(1, 0)]     # the second copy of the profile changes no value
+            back += got[(concat, 1)]
+            single += got[(1, 1)]
     assert back >= single > 0            # what crosses a junction can only send MORE sequences back
     db.close()
 
