@@ -37,12 +37,21 @@ __device__ __forceinline__ u32 pair_offsets(u32 raw, u32 cs)
 {
   return __umul24(raw & 0xFFu, cs) + __umul24(raw & 0xFF00u, cs << 8);
 }
+// (round 6) ... and rotate and select are ONE instruction: v_cndmask_b32 is VOP2, so its first source can come through DPP -
+// dst = vcc ? fresh : row_ror:1(cur).  The compiler keeps the lane-0 condition in an SGPR pair and emits the VOP3 form, which
+// cannot, so the instruction is written out; the lanes that start a chain are a constant of G, loaded into vcc in front of it
+// (two SALU moves, which are also the two wait states a DPP read wants behind a VALU write of its source).
 template <int G>
 __device__ __forceinline__ u32 chain_advance(u32 cur, u32 fresh, bool first)
 {
   if constexpr (G < 16) {
-    const u32 r = (u32)__builtin_amdgcn_mov_dpp((int)cur, DPP_ROW_ROR1, 0xF, 0xF, false);
-    return first ? fresh : r;
+    static_assert(G == 2 || G == 4 || G == 8, "chains inside a DPP row");
+    constexpr u32 heads = G == 8 ? 0x01010101u : G == 4 ? 0x11111111u : 0x55555555u;       // lanes with lane % G == 0
+    (void)first;
+    u32 out;
+    asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %3\n\tv_cndmask_b32_dpp %0, %1, %2, vcc row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "=v"(out) : "v"(cur), "v"(fresh), "n"(heads) : "vcc");
+    return out;
   } else {
     return row_shr1(cur, fresh);
   }

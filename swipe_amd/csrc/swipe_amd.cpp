@@ -219,7 +219,7 @@ struct Options {
   int64_t narrow_variant = 0;    // 0 auto, 1 plain (8.5-instruction) form, 2 row-shifted form
   int64_t endpoints_thread = 0;  // 1: one-thread 64-bit end-point kernel instead of the wave kernel
   int64_t requeue_host = 0;      // 1: the host reads the re-queue list before launching the wide kernels (two extra syncs)
-  int64_t concat = -1;           // bound builds on chains of lanes: sets of batches a chain works through back to back without draining (sw_cb_kernel.inc); -1 = 8; N > 1 = N; 1 or 0 = every set on its own (the round-3 kernel)
+  int64_t concat = -1;           // bound builds on chains of lanes: sets of batches a chain works through back to back without draining (sw_cb_kernel.inc); -1 = 16; N > 1 = N; 1 or 0 = every set on its own (the round-3 kernel)
   int64_t concat_tail = -1;      // ... except the last concat_tail sets of the queue, which are handed out one at a time; -1 = four per resident wave
   int64_t twin = -1;             // bound builds at two waves per SIMD: blocks of 8 waves holding the profile twice, the second copy renormalising H on the way (sw_cb_kernel.inc TWIN); 0 = blocks of 4 waves, one copy (the round-3 form); -1 = on
   int64_t requeue_block = 0;     // device-driven re-queue, a BLOCK of four waves per sequence instead of one wave: 1 whenever the query fits (<= 1024 rows), else never. Off until tools/rq_probe.py has priced its barrier per DP step on hardware
@@ -1637,7 +1637,7 @@ int run_search(swa_db* db, const uint8_t* query, int64_t qlen, int64_t bound_min
       q.concat = 1;
       q.concat_items = 0;
       if (pick.bound && G > 1 && db->opt.concat != 1 && db->opt.concat != 0) {
-        const int M = db->opt.concat > 0 ? int(std::min<int64_t>(db->opt.concat, 64)) : 8;
+        const int M = db->opt.concat > 0 ? int(std::min<int64_t>(db->opt.concat, 64)) : 16;
         const int64_t resident = int64_t(db->cus) * 4 * waves_for_rows(K, true);
         const int tail = int(std::min<int64_t>(sets, db->opt.concat_tail >= 0 ? db->opt.concat_tail : 4 * resident));
         q.concat_items = (sets - tail) / M;

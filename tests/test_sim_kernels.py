@@ -264,3 +264,57 @@ def test_interpreter_async_mode_shows_a_missing_event_edge(tmp_path):
     assert all(w[1] == "fresh" and w[3] == "execution" for w in with_edge), with_edge
     without = [run("noedge", s)[1] for s in (0, 1, 2, 3, 4, 5)]
     assert "stale" in without and without[1] == "stale", without                   # seed % 3 == 1: the lazy policy
+
+
+_CNDMASK_DPP = r"""
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned int u32;
+template <int G> __global__ void k(const u32* in, u32* fused, u32* plain)
+{
+  const int lane = threadIdx.x & 63;
+  const u32 cur = in[lane], fresh = in[64 + lane];
+  constexpr u32 heads = G == 8 ? 0x01010101u : G == 4 ? 0x11111111u : 0x55555555u;
+  u32 out;
+  asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %3\n\tv_cndmask_b32_dpp %0, %1, %2, vcc row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "=v"(out) : "v"(cur), "v"(fresh), "n"(heads) : "vcc");
+  fused[lane] = out;
+  const u32 rot = (u32)__shfl((int)cur, (lane & 48) | ((lane + 15) & 15));       // lane l of a row of 16 takes lane l - 1, lane 0 takes lane 15
+  plain[lane] = (lane % G) == 0 ? fresh : rot;
+}
+int main()
+{
+  u32 h[128], *d, *a, *b, ra[64], rb[64];
+  for (int i = 0; i < 128; ++i) h[i] = 0x9E3779B9u * (i + 1);
+  hipMalloc(&d, sizeof h); hipMalloc(&a, 256); hipMalloc(&b, 256);
+  hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+  int bad = 0;
+  for (int g = 0; g < 3; ++g) {
+    if (g == 0) hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, d, a, b);
+    if (g == 1) hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, d, a, b);
+    if (g == 2) hipLaunchKernelGGL(k<8>, dim3(1), dim3(64), 0, 0, d, a, b);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    hipMemcpy(ra, a, 256, hipMemcpyDeviceToHost); hipMemcpy(rb, b, 256, hipMemcpyDeviceToHost);
+    for (int l = 0; l < 64; ++l) {
+      const u32 want = (l % (2 << g)) == 0 ? h[64 + l] : h[(l & 48) | ((l + 15) & 15)];
+      bad += ra[l] != want || rb[l] != want;
+    }
+  }
+  std::printf("mismatches %d\n", bad);
+  return bad != 0;
+}
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_interpreter_cndmask_through_dpp_equals_rotate_then_select(tmp_path):
+    """round 6: the residue shift register of a chain advances with ONE instruction, v_cndmask_b32_dpp (sw_common.cuh
+    chain_advance: vcc ? fresh : row_ror:1(cur)), written out in inline assembly.  The interpreter's definition of it against the
+    host's statement of what it must do and against the two-instruction form through ds_bpermute, for chains of 2, 4 and 8 lanes"""
+    src = tmp_path / "cnd.hip"
+    src.write_text(_CNDMASK_DPP)
+    exe = str(tmp_path / "cnd")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", str(src), "-o", exe], check=True, capture_output=True, timeout=300)
+    r = _sim([exe], 120)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr

@@ -1262,7 +1262,24 @@ static bool step(Ctx& c, Wave& w) {
             const uint64_t exec = EXEC(w), m = rs64(w, in.o[3]);
             Src A, B; mk_src(w, in.o[1], A); mk_src(w, in.o[2], B);
             uint32_t* dst = w.v[in.o[0].reg];
-            if (in.enc) throw Fault("v_cndmask with dpp/sdwa not modelled");
+            if (in.enc == 2) throw Fault("v_cndmask with sdwa not modelled");
+            if (in.enc == 1) {        // VOP2: the first source comes through DPP (a lane without a valid source keeps its destination unless bound_ctrl)
+                if (in.o[1].kind != K_VGPR) throw Fault("v_cndmask_b32_dpp: src0 must be a VGPR");
+                uint32_t snap[64], res[64];
+                memcpy(snap, w.v[in.o[1].reg], sizeof snap);
+                for (int l = 0; l < 64; l++) res[l] = L32(B, l);
+                for (int l = 0; l < 64; l++) {
+                    if (!((exec >> l) & 1)) continue;
+                    if (!((in.row_mask >> (l >> 4)) & 1) || !((in.bank_mask >> ((l >> 2) & 3)) & 1)) continue;
+                    uint32_t a;
+                    int sl;
+                    if (dpp_source(in, l, exec, sl)) a = snap[sl];
+                    else if (in.bound_ctrl) a = 0;
+                    else continue;
+                    dst[l] = ((m >> l) & 1) ? res[l] : a;
+                }
+                break;
+            }
             for (int l = 0; l < 64; l++) if ((exec >> l) & 1) dst[l] = ((m >> l) & 1) ? fmod32(L32(B, l), in.o[2]) : fmod32(L32(A, l), in.o[1]);
             break;
         }
