@@ -249,6 +249,14 @@ SWA_API void swa_db_close(swa_db* db);
      boundary_mb      cap of the pass hand-over buffer of long queries, MiB; -1 = from free memory
      wave_requeue     0: re-queued sequences always by the batch kernels; -1 auto
      requeue_host     1: the host reads the re-queue list between the passes (two more stream synchronisations)
+     requeue_block    1: the device-driven re-queue takes a block of four waves per sequence for queries of at most 1 024 rows
+                      (swa_requeue_block_kernel); 0 (default): one wave per sequence.  counters.requeue_form says which ran
+     concat           bound builds on chains of lanes: sets of batches a chain works through back to back, without draining or
+                      resetting its state in between; -1 = 16; 1 or 0 = every set on its own (the round-3 kernel)
+     concat_tail      ... except the last concat_tail sets of the work queue, handed out one at a time; -1 = four per resident wave
+     twin             bound builds at two waves per SIMD: 8-wave blocks holding the query profile twice, the second copy
+                      renormalising the stored H values on the way; 0 = 4-wave blocks, one copy (the round-3 form)
+     stream_reserve   bytes of a budgeted shard's device slot set aside for what does not scale with the part; -1 = 8 MiB
      requeue_follow   accepted and ignored (rounds 2-3 ran the re-queue kernel beside the first pass on a second stream; it now
                       always runs behind it in the same stream - no kernel waits for another kernel)
      pipelined, load_part, load_chunk, load_threads, load_delay_ms, load_trace      the pipelined open (swa_db_open_async),

@@ -99,10 +99,11 @@ def main():
              # the bench kernel: the round-3 form (every set of batches on its own, one copy of the profile), then round 6's two steps.
              # SWA_CONCAT_TAIL=16: 1.3 % of the 1 250 sets singly, which is what the default (four sets per resident wave) comes to on
              # the 10 M-sequence database (8 192 of 625 000 sets)
-             ("protein", 375, "bound", {"SWA_CONCAT": "1", "SWA_TWIN": "0"}), ("protein", 375, "bound", {"SWA_CONCAT": "8", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "0"}),
+             ("protein", 375, "bound", {"SWA_CONCAT": "1", "SWA_TWIN": "0"}), ("protein", 375, "bound", {"SWA_CONCAT": "16", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "0"}),
+             ("protein", 375, "bound", {"SWA_CONCAT": "16", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "1"}),
              ("protein", 375, "bound", {"SWA_CONCAT": "8", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "1"}),
              ("protein", 375, "bound", {"SWA_CONCAT": "32", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "1"}),
-             ("protein", 100, "bound", {"SWA_CONCAT": "1", "SWA_TWIN": "0"}), ("protein", 100, "bound", {"SWA_CONCAT": "8", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "1"}),
+             ("protein", 100, "bound", {"SWA_CONCAT": "1", "SWA_TWIN": "0"}), ("protein", 100, "bound", {"SWA_CONCAT": "16", "SWA_CONCAT_TAIL": "16", "SWA_TWIN": "1"}),
              ("nucleotide", 1000, "both strands", None)]
     for kind, qlen, mode, extra in table:
         label = "%s %d, %s%s" % (kind, qlen, mode, (", " + " ".join("%s=%s" % (k[4:].lower(), v) for k, v in extra.items())) if extra else "")
