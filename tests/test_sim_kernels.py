@@ -318,3 +318,21 @@ def test_interpreter_cndmask_through_dpp_equals_rotate_then_select(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", str(src), "-o", exe], check=True, capture_output=True, timeout=300)
     r = _sim([exe], 120)
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_py_runs_end_to_end_on_the_interpreter():
+    """bench.py has changed in rounds 5 and 6 without a GPU to run it on (budgeted open in cold_open, the round-3 A/B block).
+    tools/bench_dryrun.py runs the driver's script itself on the interpreter (torch.cuda's three calls stubbed): here a bounded
+    run - headline step, oracle verification, cpu_baseline against the compiled reference, the cold-open section with the
+    pipelined and the budgeted open - and the line must carry the blocks the contract names.  Numbers mean nothing here."""
+    r = _sim([sys.executable, "tools/bench_dryrun.py", "--nseq", "20000", "--steps", "1", "--warmup", "0", "--no-live-traffic", "--quick",
+              "--secondary-nt-nseq", "4000", "--secondary-protein-nseq", "8000"], 1500)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout + r.stderr)[-2000:]
+    line = json.loads(lines[-1])
+    assert line["unit"] == "GCUPS" and line["value"] > 0 and line["n_gpus"] == 1 and line["verified_vs_oracle"] >= 1
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0 and line["valu_roofline"]
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
+    cold = line["cold_open"]
+    assert cold["open_s"] is not None and cold["budgeted_open_s"] is not None, cold      # (at this size the budget holds the whole shard)
+    assert len(line["secondary"]) >= 3
