@@ -105,5 +105,9 @@ struct swa_mp_params {
   float gapextend_f;
   uint32_t negQR, negR, negKR;
   uint32_t rowc[80];
+  /* bound build of the two-query kernel (sw_cb_dual_kernel.inc, round 6): sets of batches a chain works through back to back;
+     concat_items is filled in by the launcher (items of that size at the head of the queue), concat_tail = sets handed out singly
+     at its end (-1: four per resident wave) */
+  int32_t concat, concat_items, concat_tail;
 };
 #endif

@@ -1905,6 +1905,9 @@ int run_search2(swa_db* db, const uint8_t* q1, const uint8_t* q2, int64_t qlen, 
     if (used_bound) {
       p.limit = std::min<int64_t>(f16_limit(db, Kd + Nb), bound_min);
       for (int i = 0; i <= Kd + Nb + 1; ++i) p.rowc[i] = f16_pair(float(int64_t(i) * db->ge));
+      // sequences back to back, as the one-query bound build (option concat; the launcher lays the queue out)
+      p.concat = db->opt.concat == 0 || db->opt.concat == 1 ? 1 : int32_t(db->opt.concat > 0 ? std::min<int64_t>(db->opt.concat, 64) : 16);
+      p.concat_tail = int32_t(std::min<int64_t>(db->opt.concat_tail, 0x7fffffff));
     }
     auto launch_first2 = [&](const swa_mp_params& q, hipStream_t s) -> hipError_t {
       if (used_bound) return swa_launch_dual_bound(Gd, Kd, &q, db->cus, s);

@@ -351,6 +351,61 @@ def test_bound_build_of_the_two_query_kernel(lanes, monkeypatch):
     db.close()
 
 
+@pytest.mark.late
+@pytest.mark.parametrize("lanes", [16, 8, 4])
+def test_bound_build_of_the_two_query_kernel_with_sequences_back_to_back(lanes, monkeypatch):
+    """round 6: the two-query bound build works through sets of batches back to back as the one-query one does
+    (sw_cb_dual_kernel.inc): the shortest, a middle and the longest build of each chain length, 1 / 3 / 8 sets per item with the
+    last quarter of the queue handed out singly, hits that end at a junction, sequences shorter than a period - both queries'
+    merged hit list, totalhits and obvious equal the exact ones, and more sets never send fewer sequences back"""
+    monkeypatch.setenv("SWA_LANES", str(lanes))
+    monkeypatch.setenv("SWA_BOUND", "1")
+    rtab = synth.residue_table_protein()
+    full = synth._random_residues(4321, 1, 1000, rtab)
+    rng = np.random.default_rng(lanes + 7)
+    res, off = swipe_amd.synth_db(16, 1100, query=full)
+    seqs = [res[off[i]:off[i + 1]] for i in range(1100)]
+    rev = full[::-1].copy()
+    for k in range(140):
+        src = full if k % 2 else rev
+        a = int(rng.integers(0, 430))
+        piece = src[a:a + int(rng.integers(8, 160))].copy()
+        mut = rng.random(len(piece)) < rng.random() * 0.4
+        piece[mut] = rtab[rng.integers(0, len(rtab), int(mut.sum()))]
+        seqs.append(np.concatenate([seqs[k][:int(rng.integers(0, 50))], piece, seqs[k + 1][:int(rng.integers(0, 3))]]))
+    seqs += [synth._random_residues(k, 1, int(rng.integers(1, 16)), rtab) for k in range(150)]
+    seqs += [full, rev, np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
+    r2, o2 = oracle.pack(seqs)
+    db = swipe_amd.Database.from_arrays(r2, o2)
+    Mo = oracle.matrix_builtin("BLOSUM62")
+    per_wave = 1 if lanes == 16 else 8 // lanes
+    db.set_option("concat_tail", (len(seqs) // (4 if lanes == 16 else 8) // per_wave) // 4)
+    back = single = 0
+    for K in (17, 25, 32 if lanes == 16 else 62):
+        go, ge = ((11, 1), (10, 2))[K % 2]
+        db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), go, ge)
+        qlen = lanes * K - (K % lanes)
+        q1 = full[:qlen]
+        q2 = rev[:qlen].copy()
+        w1 = oracle.search_all63(r2, o2, q1, Mo, go + ge, ge, threads=THREADS)
+        w2 = oracle.search_all63(r2, o2, q2, Mo, go + ge, ge, threads=THREADS)
+        for minscore, maxscore in ((1, 1 << 62), (40, 120), (70, 1 << 62), (500, 1 << 62)):
+            want = sorted([(int(s), i, 0) for i, s in enumerate(w1) if minscore <= s <= maxscore] +
+                          [(int(s), i, 1) for i, s in enumerate(w2) if minscore <= s <= maxscore], key=lambda t: (-t[0], -t[1], t[2]))[:30]
+            got = {}
+            for m in (1, 3, 8):
+                db.set_option("concat", m)
+                hits, tot, obv, c = db.search2_topk(q1, q2, keep=30, minscore=minscore, maxscore=maxscore)
+                assert c["narrow_rows"] == K and c["narrow_shifted"] == 10, (K, c)
+                assert hits == [(i, s, w) for s, i, w in want], (K, minscore, m)
+                assert tot == int((w1 >= minscore).sum() + (w2 >= minscore).sum()) and obv == int((w1 > maxscore).sum() + (w2 > maxscore).sum())
+                got[m] = c["wide"]
+            back += got[8]
+            single += got[1]
+    assert back >= single > 0
+    db.close()
+
+
 def test_bound_build_of_the_passes_of_long_queries(monkeypatch):
     """top-K searches of queries longer than 928 rows: passes of the bound build, 16 x K rows with K = 30..56, the hand-over
     stored without the step bias and re-biased on arrival; every K with two passes, then up to seven passes, hits that
