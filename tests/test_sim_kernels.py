@@ -336,3 +336,33 @@ def test_bench_py_runs_end_to_end_on_the_interpreter():
     cold = line["cold_open"]
     assert cold["open_s"] is not None and cold["budgeted_open_s"] is not None, cold      # (at this size the budget holds the whole shard)
     assert len(line["secondary"]) >= 3
+
+
+_TWIN_FALLBACK = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+np.seterr(over="ignore")
+import oracle, swipe_amd
+from swipe_amd import blastdb, synth
+q = blastdb.encode_protein(synth.QUERY_P07327)
+res, off = swipe_amd.synth_db(1, 6000, query=q)
+ref = oracle.search_all63(res, off, q, oracle.matrix_builtin("BLOSUM62"), 12, 1, threads=8)
+db = swipe_amd.Database.from_arrays(res, off); db.set_scoring(swipe_amd.matrix_builtin("BLOSUM62"), 11, 1)
+db.set_option("bound", 1); db.set_option("concat", 4); db.set_option("concat_tail", 50)
+order = sorted(((int(s), i) for i, s in enumerate(ref) if s >= 70), key=lambda t: (-t[0], -t[1]))[:100]
+hits, tot, obv, c = db.search_topk(q, keep=100, minscore=70)
+print("HITS", "ok" if hits == [(i, s) for s, i in order] and c["narrow_shifted"] == 8 else "WRONG")
+"""
+
+
+def test_twin_profile_build_falls_back_where_the_runtime_grants_less_lds():
+    """round 6: the bound build at two waves per SIMD asks for 96-128 KB of dynamic LDS per block (two copies of the profile).  No
+    hardware has seen that request yet; a runtime that refuses it must get the one-copy form, not a failed search.  The
+    interpreter's runtime plays both: all of gfx950's 160 KB, and 64 KB (HIPSIM_LDS_LIMIT) - same hits, different kernel"""
+    seen = {}
+    for limit in (160 << 10, 64 << 10):
+        r = _sim([sys.executable, "-c", _TWIN_FALLBACK % ROOT], 600, HIPSIM_LDS_LIMIT=limit, HIPSIM_TRACE=1)
+        assert r.returncode == 0 and "HITS ok" in r.stdout, (r.stdout + r.stderr)[-1500:]
+        seen[limit] = re.findall(r"launch _Z23swa_narrow_bound_kernelILi47ELi2ELi8ELi16ELb0ELb([01])E", r.stderr)
+    assert seen[160 << 10] and set(seen[160 << 10]) == {"1"} and seen[64 << 10] and set(seen[64 << 10]) == {"0"}, seen

@@ -455,7 +455,12 @@ hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args,
     return submit(stream, op);
 }
 
-hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+// HIPSIM_LDS_LIMIT=<bytes>: a runtime that grants less dynamic LDS per workgroup than gfx950 has (tests of the product's fallbacks)
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute a, int v) {
+    static const int limit = env_int("HIPSIM_LDS_LIMIT", 160 << 10);
+    if (a == hipFuncAttributeMaxDynamicSharedMemorySize && v > limit) return fail(hipErrorInvalidValue);
+    return hipSuccess;
+}
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : fail(hipErrorInvalidDevice); }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
