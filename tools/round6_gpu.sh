@@ -1,12 +1,12 @@
 #!/bin/bash
 # Everything that wants an MI355X, in one gpurun call, most important first; every step under its own timeout (a hang costs one
-# step, not the call):   bash tools/round6_gpu.sh [steps...]     steps: tests bench stats pmc first redzones rq dropin dasan (default: all)
+# step, not the call):   bash tools/round6_gpu.sh [steps...]     steps: tests bench stats pmc concat first redzones rq dropin dasan (default: all)
 # Output under gpurun_out/r06/ (merged back by gpurun); copy what is to be judged into profiles/r06_*.
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r06; mkdir -p $O
 export SWA_WATCHDOG_S=60
-STEPS="${*:-tests bench stats pmc first redzones rq dropin dasan}"
+STEPS="${*:-tests bench stats pmc concat first redzones rq dropin dasan}"
 for s in $STEPS; do
   t0=$(date +%s)
   case $s in
@@ -23,6 +23,7 @@ code = re.search(r'_REDZONE_SCRIPT = r"""(.*?)"""', src, re.S).group(1) % (os.ge
 exec(compile(code, "redzones", "exec"))
 PY
               tail -3 $O/redzones.txt ;;
+    concat)   timeout 900 python tools/concat_probe.py > $O/concat_probe.txt 2>&1; tail -28 $O/concat_probe.txt ;;
     rq)       timeout 900 python tools/rq_probe.py > $O/rq_probe.txt 2>&1; tail -20 $O/rq_probe.txt ;;
     dropin)   timeout 900 python tools/probe.py dropin > $O/dropin.txt 2>&1; tail -12 $O/dropin.txt ;;
     dasan)    timeout 1500 bash tools/device_asan.sh > /dev/null 2>&1; cp gpurun_out/device_asan.txt $O/ 2>/dev/null; tail -8 $O/device_asan.txt ;;
