@@ -57,6 +57,11 @@ ROUND5_SLICE = [
     ("tests/test_gpu_parity.py", "cli_nucleotide_ambiguity_tables_equal_reference_cli"),
     # round 6: both forms of the device-driven re-queue pinned by the option that selects them
     ("tests/test_gpu_parity.py", "both_device_requeue_forms and (129 or 256 or 257 or 1024 or 1025)"),
+    # round 6: the bound build with sequences back to back, twin profile on and off (8-lane chains, 5 sets per item), one- and two-query
+    ("tests/test_gpu_parity.py", "bound_build_with_sequences_back_to_back and 8-5"),
+    ("tests/test_gpu_parity.py", "two_query_kernel_with_sequences_back_to_back and 16"),
+    # round 6: ambiguity runs that overlap, in file order (old reader, device unpack, budgeted shard); the budgeted open straight from the files
+    ("tests/test_gpu_loading.py", "overlap_are_applied_in_file_order or budgeted_open_fills"),
 ]
 
 
@@ -64,7 +69,8 @@ def test_round_5_paths_under_the_interpreter():
     """what round 5 added, on the shipped kernels without a GPU: .nsq entries unpacked on the device (empty sequences, both
     ambiguity table forms, an entry larger than a staging chunk), an OID mask through the loader, a corrupt volume refused
     by a search that follows the loader, taxid lists and masks on budgeted shards byte for byte against the reference's
-    goldens, and both forms of the device-driven re-queue"""
+    goldens, and both forms of the device-driven re-queue; round 6: both re-queue forms by name, the bound builds with sequences back
+    to back (one- and two-query), overlapping ambiguity runs in file order, the budgeted open that fills its parts from the files"""
     for path, expr in ROUND5_SLICE:
         r = _sim([sys.executable, "-m", "pytest", path, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", expr], 1500)
         tail = (r.stdout + r.stderr)[-1500:]
