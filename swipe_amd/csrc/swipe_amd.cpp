@@ -2276,19 +2276,25 @@ try {
   *out = nullptr;
   {
     // the nucleotide volumes through the pipelined open (round 5), translated out of the 4-bit residues it leaves on the
-    // device; a masked alias keeps the old reader (its OID mask is wanted on the host below)
+    // device; a masked alias too (round 6): its OID mask is taken off the loader before the nucleotide handle adopts it and
+    // becomes the translated shard's inclusion set (six frames per member), its NSEQ / LENGTH the totals of the statistics
     uint8_t table[4096];
     if (swa_translate_table(db_gencode, table) != SWA_OK) return fail(SWA_EINVAL, "Illegal database genetic code specified.");
     swa_db* nt = nullptr;
     int prc = open_pipelined(basename, SWA_SYMTYPE_NUCLEOTIDE, device, first_seqno, last_seqno, &nt);
     if (prc != SWA_OK) return prc;
-    if (nt && nt->loading && nt->loading->masked) { swa_db_close(nt); nt = nullptr; }
     if (nt) {
+      std::vector<uint8_t> mask;
+      if (nt->loading && nt->loading->masked) mask = nt->loading->included;
       prc = settle_loading(nt, true, nullptr, true);
       if (prc == SWA_OK)
         prc = translated_shard(nullptr, nt->residues.p, nt->h_offsets.data(), nt->nseq, db_gencode, device, nt->first_seqno, nt->total_seq,
                                nt->total_sym, out);
       swa_db_close(nt);
+      if (prc == SWA_OK && !mask.empty()) {
+        prc = swa_db_set_inclusion(*out, mask.data(), int64_t(mask.size()));
+        if (prc != SWA_OK) { swa_db_close(*out); *out = nullptr; }
+      }
       return prc;
     }
   }

@@ -630,6 +630,38 @@ def test_masked_alias_streams_in(volumes, tmp_path, early):
         new.close()
 
 
+@pytest.mark.late
+def test_masked_alias_opened_as_six_translations_through_the_loader(tmp_path):
+    """round 6 (missing 4): a masked nucleotide alias held as its six translations (-p 3 / -p 4 on an OID-masked
+    database) opens through the pipelined loader too - the mask is taken off the loader and becomes the translated shard's
+    inclusion set.  Same frame-tagged hits, counts, scores of every frame and statistics totals as through the old reader"""
+    rng = np.random.default_rng(41)
+    res, off = swipe_amd.synth_db(3, 2500, protein=False)
+    seqs = [res[off[i]:off[i + 1]] for i in range(2500)]
+    vol = str(tmp_path / "ntv")
+    blastdb.write_volume(vol, seqs, protein=False, ids=[f"s{i}" for i in range(len(seqs))])
+    inc = rng.random(len(seqs)) < 0.55
+    alias = str(tmp_path / "ntmask")
+    blastdb.write_mask_alias(alias, vol, inc, memb_bit=1, length=int(sum(len(x) for x, k in zip(seqs, inc) if k)), protein=False)
+    q = Q[:180]
+    got = []
+    for env in (dict(SWA_PIPELINED=0), dict(SWA_LOAD_PART=1 << 15, SWA_LOAD_CHUNK=1 << 13, SWA_LOAD_THREADS=3)):
+        with _Env(**env):
+            db = swipe_amd.Database.open_translated(alias, db_gencode=1)
+        try:
+            db.set_scoring(_matrix(), 11, 1)
+            scores, _ = db.search(q)
+            hits = db.search_frames_topk([q], keep=60, minscore=30)[:3]
+            info = db.info()
+            got.append((scores, hits, {k: info[k] for k in ("seqcount", "symcount", "total_seqcount", "total_symcount", "frames")}))
+        finally:
+            db.close()
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1] and got[0][2] == got[1][2]
+    assert got[0][2]["frames"] == 6 and got[0][2]["total_seqcount"] == int(inc.sum())
+    excluded = np.repeat(~inc, 6)
+    assert (got[1][0][excluded] == -1).all() and (got[1][0][~excluded] >= 0).all() and got[1][1][1] > 0
+
+
 _REDZONE_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, %r)
