@@ -585,9 +585,24 @@ def test_two_queries_per_pass_on_a_loading_protein_shard(volumes):
         s1, s2, c = db.search2(qa, np.ascontiguousarray(Q[100:330]))
         assert c["loading_parts"] >= 8, c
         assert np.array_equal(s1, refa) and np.array_equal(s2, oracle.search_all63(res, off, Q[100:330], Mo, 12, 1, threads=cpus))
-        # a pair of 375-row queries takes 16-lane chains (one sequence per row): not what the parts hold - it waits, same answers
+        # a pair of 375-row queries: whatever has or has not arrived by now, same answers
         a3 = db.search_pair_topk(Q, Q[::-1].copy(), keep=(50, 50), minscore=(60, 60))
         assert a3[0][:2] == _expected_topk(volumes["ref"], 50, 60)
+    finally:
+        db.close()
+    # With a threshold clear of the bound's slack the pair has a bound build on 8 lanes (8 x 47 rows), which streams the parts' pair
+    # format: the search follows the loader.  (Round 6: where the table would pick a 16-lane build for a loading protein shard and a
+    # shorter chain has a build for the query, the shorter chain is taken instead of waiting for the whole shard.)
+    with _Env(**SLOW):
+        db = swipe_amd.Database.open(volumes["one"], wait=False)
+    try:
+        db.set_scoring(_matrix(), 11, 1)
+        a4, b4, c4 = db.search_pair_topk(Q, Q[::-1].copy(), keep=(50, 50), minscore=(70, 70))      # (70: clear of the bound's slack)
+        assert c4["loading_parts"] >= 8 and c4["narrow_rows"] * 8 >= 375 and c4["narrow_shifted"] == 10, c4
+        assert a4[:2] == _expected_topk(volumes["ref"], 50, 70)
+        db.wait()
+        a5, b5, c5 = db.search_pair_topk(Q, Q[::-1].copy(), keep=(50, 50), minscore=(70, 70))
+        assert c5["loading_parts"] == 0 and a5[:2] == a4[:2] and b5[:2] == b4[:2]
     finally:
         db.close()
 
